@@ -1,0 +1,136 @@
+"""ctypes binding of the C-ABI in include/fv3lm.h.
+
+`load_hip_library()` loads the product library libfv3lm_hip.so and raises if it is missing — the
+package has no CPU path.  `Fv3LmLibrary(path)` is the thin object wrapper the tests also use to
+drive the test-only host-emulation build of the same sources.
+"""
+import ctypes as C
+import os
+import numpy as np
+from .config import Options, Dims
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfv3lm_hip.so")
+_dp = C.POINTER(C.c_double)
+
+
+class Fv3LmError(RuntimeError):
+    pass
+
+
+class Fv3LmLibrary:
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise Fv3LmError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+        self.path = path
+        L = self.L = C.CDLL(path)
+        L.fv3lm_last_error.restype = C.c_char_p
+        L.fv3lm_metric_names.restype = C.c_char_p
+        L.fv3lm_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Dims), C.POINTER(Options), C.POINTER(_dp),
+                                   C.c_double, C.c_double, _dp, _dp, _dp]
+        L.fv3lm_destroy.argtypes = [C.c_void_p]
+        L.fv3lm_field_put.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _dp]
+        L.fv3lm_field_get.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _dp]
+        L.fv3lm_field_levels.argtypes = [C.c_void_p, C.c_char_p]
+        L.fv3lm_run_group.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.fv3lm_dyn_core.argtypes = [C.c_void_p, C.c_int]
+        L.fv3lm_zero_work_adjoint.argtypes = [C.c_void_p]
+        L.fv3lm_sync.argtypes = [C.c_void_p]
+        L.fv3lm_launch_count.argtypes = [C.c_void_p]
+        L.fv3lm_launch_count.restype = C.c_long
+        L.fv3lm_level_params.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), _dp]
+
+    def err(self):
+        return self.L.fv3lm_last_error().decode()
+
+    def metric_names(self):
+        return self.L.fv3lm_metric_names().decode().split(",")
+
+
+def load_hip_library():
+    return Fv3LmLibrary(LIB_PATH)
+
+
+def _ptr(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_dp)
+
+
+class Dycore:
+    """Device-resident dycore instance (one per GPU / MPI rank), cf. fv3jedi_lm_dynamics_type."""
+
+    NL, TL, AD = 0, 1, 2
+
+    def __init__(self, lib, dims, options, metrics, da_min, da_min_c, phis, ak, bk):
+        self.lib, self.dims, self.options = lib, dims, options
+        names = lib.metric_names()
+        self.pj, self.pi = dims.ny + 7, dims.nx + 7
+        arrs = []
+        for n in names:
+            a = np.ascontiguousarray(metrics[n], dtype=np.float64)
+            assert a.shape == (dims.ntile, self.pj, self.pi), (n, a.shape)
+            arrs.append(a)
+        self._keep = arrs
+        mp = (_dp * len(arrs))(*[_ptr(a) for a in arrs])
+        self.h = C.c_void_p()
+        phis = np.ascontiguousarray(phis, dtype=np.float64)
+        ak = np.ascontiguousarray(ak, dtype=np.float64); bk = np.ascontiguousarray(bk, dtype=np.float64)
+        rc = lib.L.fv3lm_create(C.byref(self.h), C.byref(dims), C.byref(options), mp, da_min, da_min_c,
+                                _ptr(phis), _ptr(ak), _ptr(bk))
+        if rc != 0:
+            raise Fv3LmError(lib.err())
+
+    def close(self):
+        if self.h:
+            self.lib.L.fv3lm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def levels(self, name):
+        n = self.lib.L.fv3lm_field_levels(self.h, name.encode())
+        if n < 0:
+            raise Fv3LmError(self.lib.err())
+        return n
+
+    def shape(self, name):
+        return (self.dims.ntile, self.levels(name), self.pj, self.pi)
+
+    def put(self, name, arr, which=0):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        assert a.shape == self.shape(name), (name, a.shape, self.shape(name))
+        if self.lib.L.fv3lm_field_put(self.h, name.encode(), which, _ptr(a)) != 0:
+            raise Fv3LmError(self.lib.err())
+
+    def get(self, name, which=0):
+        a = np.empty(self.shape(name), dtype=np.float64)
+        if self.lib.L.fv3lm_field_get(self.h, name.encode(), which, _ptr(a)) != 0:
+            raise Fv3LmError(self.lib.err())
+        return a
+
+    def run_group(self, group, mode):
+        if self.lib.L.fv3lm_run_group(self.h, group.encode(), mode) != 0:
+            raise Fv3LmError(self.lib.err())
+
+    def dyn_core(self, mode):
+        if self.lib.L.fv3lm_dyn_core(self.h, mode) != 0:
+            raise Fv3LmError(self.lib.err())
+
+    def zero_work_adjoint(self):
+        self.lib.L.fv3lm_zero_work_adjoint(self.h)
+
+    def sync(self):
+        self.lib.L.fv3lm_sync(self.h)
+
+    def launch_count(self):
+        return self.lib.L.fv3lm_launch_count(self.h)
+
+    def level_params(self, k):
+        ip = (C.c_int * 10)(); rp = (C.c_double * 6)()
+        if self.lib.L.fv3lm_level_params(self.h, k, ip, rp) != 0:
+            raise Fv3LmError(self.lib.err())
+        return list(ip), list(rp)

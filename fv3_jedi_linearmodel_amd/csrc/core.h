@@ -1,0 +1,171 @@
+// fv3lm-hip core: scalar types, field/geometry descriptors and the generic stage launchers.
+//
+// Design: the TL/AD dycore is expressed as a sequence of *stages*.  A stage is a
+// small struct that computes its outputs at one grid point (i,j,k) from its inputs at fixed stencil
+// offsets — the nonlinear formula only, written once on a generic scalar T.  Three generic kernels
+// run a stage over all levels and tiles:
+//   nonlinear  T = double          (trajectory recompute of the adjoint sweep; FV_DYNAMICS_FWD role)
+//   tangent    T = Dual            (value + tangent in registers; the *_TLM role)
+//   adjoint    gather form: the thread that owns input point p sums dOut(o)/dIn(p) * out_ad(o) over
+//              the outputs o in the stage's declared stencil box, each local derivative obtained by
+//              seeding a Dual at p — no atomics, no tape (the *_BWD role; replaces adStack.c).
+// Branches test trajectory values only, like the Tapenade code (`IF (c(i,j) .GT. 0.)`).
+//
+// This header compiles two ways: with hipcc for gfx950 (the product), and with g++ under
+// -DFV3LM_HOST_EMUL (a test-only build that runs the same stage code in host loops so that the
+// stage logic can be checked against the oracle on machines without a GPU; it is never loaded by
+// the package).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#ifdef FV3LM_HOST_EMUL
+#define HD inline
+#define DEV inline
+#else
+#include <hip/hip_runtime.h>
+#define HD __host__ __device__ inline
+#define DEV __device__ inline
+#endif
+
+namespace fv3 {
+
+// ------------------------------------------------------------------ scalars
+struct Dual {
+  double v, d;
+  HD Dual() : v(0.0), d(0.0) {}
+  HD Dual(double v_) : v(v_), d(0.0) {}
+  HD Dual(double v_, double d_) : v(v_), d(d_) {}
+};
+HD Dual operator+(Dual a, Dual b) { return Dual(a.v + b.v, a.d + b.d); }
+HD Dual operator-(Dual a, Dual b) { return Dual(a.v - b.v, a.d - b.d); }
+HD Dual operator*(Dual a, Dual b) { return Dual(a.v * b.v, a.d * b.v + a.v * b.d); }
+HD Dual operator/(Dual a, Dual b) { double r = 1.0 / b.v, q = a.v * r; return Dual(q, (a.d - q * b.d) * r); }
+HD Dual operator-(Dual a) { return Dual(-a.v, -a.d); }
+HD Dual operator+(Dual a, double b) { return Dual(a.v + b, a.d); }
+HD Dual operator+(double a, Dual b) { return Dual(a + b.v, b.d); }
+HD Dual operator-(Dual a, double b) { return Dual(a.v - b, a.d); }
+HD Dual operator-(double a, Dual b) { return Dual(a - b.v, -b.d); }
+HD Dual operator*(Dual a, double b) { return Dual(a.v * b, a.d * b); }
+HD Dual operator*(double a, Dual b) { return Dual(a * b.v, a * b.d); }
+HD Dual operator/(Dual a, double b) { double r = 1.0 / b; return Dual(a.v * r, a.d * r); }
+HD Dual operator/(double a, Dual b) { double q = a / b.v; return Dual(q, -q * b.d / b.v); }
+HD Dual dlog(Dual a) { return Dual(log(a.v), a.d / a.v); }
+HD Dual dexp(Dual a) { double e = exp(a.v); return Dual(e, a.d * e); }
+HD Dual dsqrt(Dual a) { double s = sqrt(a.v); return Dual(s, a.v == 0.0 ? 0.0 : a.d / (2.0 * s)); }
+HD double dlog(double a) { return log(a); }
+HD double dexp(double a) { return exp(a); }
+HD double dsqrt(double a) { return sqrt(a); }
+HD double val(double a) { return a; }
+HD double val(const Dual& a) { return a.v; }
+// value of a, tangent of b (trajectory and perturbation evaluated with different coefficients,
+// sw_core_tlm.F90:2436-2452)
+HD double combine(double a, double) { return a; }
+HD Dual combine(const Dual& a, const Dual& b) { return Dual(a.v, b.d); }
+
+// ------------------------------------------------------------------ geometry
+// All 2-D planes share one padded index map: (isd:ied+1, jsd:jed+1), isd = 1-ng, ng = 3.
+struct Geom {
+  int nx, ny, ng, npz, ntile;
+  int pi, pj;          // padded plane dims
+  int plane;           // pi*pj
+  HD int idx(int i, int j) const { return (j + ng - 1) * pi + (i + ng - 1); }   // local i,j (1-based)
+  HD int is() const { return 1; }
+  HD int ie() const { return nx; }
+  HD int js() const { return 1; }
+  HD int je() const { return ny; }
+  HD int isd() const { return 1 - ng; }
+  HD int ied() const { return nx + ng; }
+  HD int jsd() const { return 1 - ng; }
+  HD int jed() const { return ny + ng; }
+};
+
+// A 3-D field: trajectory and perturbation(TL)/adjoint(AD) buffers, [ntile*nk][pj][pi].
+struct Fld {
+  double* t = nullptr;
+  double* p = nullptr;
+  int nk = 0;          // levels per tile (npz or npz+1, or 1 for a 2-D field)
+};
+
+struct Rect { int i0, i1, j0, j1; HD bool has(int i, int j) const { return i >= i0 && i <= i1 && j >= j0 && j <= j1; } };
+struct Box { int di0, di1, dj0, dj1, dk0, dk1; };
+
+// Metric terms, each [ntile][pj][pi] (NLM/fv_arrays_nlm.F90:115-234).
+struct Metrics {
+  const double *area, *rarea, *rarea_c, *dx, *dy, *dxa, *dya, *dxc, *dyc, *rdx, *rdy, *rdxa, *rdya, *rdxc, *rdyc;
+  const double *cosa, *sina, *rsina, *cosa_u, *cosa_v, *cosa_s, *sina_u, *sina_v, *rsin_u, *rsin_v, *rsin2;
+  const double *f0, *fC, *del6_u, *del6_v, *divg_u, *divg_v;
+  const double* sin_sg[10];
+  const double* cos_sg[10];
+  double da_min, da_min_c;
+};
+constexpr int NMETRIC = 32 + 18;
+
+// Per-level resolved options (dyn_core_tlm.F90:741-921), device array of npz entries.
+struct LevelParams {
+  int hord_mt, hord_vt, hord_tm, hord_dp, hord_tr;
+  int nord, nord_v, nord_w, nord_t, nord_v_pert;
+  double d2_divg, damp_vt, damp_w, damp_t, d_con, damp_vt_pert;
+};
+
+// Point context handed to every stage evaluation.
+struct Ctx {
+  Geom g;
+  Metrics m;
+  const LevelParams* lev;   // [npz]
+  int nlev;                 // levels per tile in this launch
+  HD int mi(int tile, int i, int j) const { return tile * g.plane + g.idx(i, j); }
+};
+
+// ------------------------------------------------------------------ accessors
+// z = tile*nlev + (k-1) is the launch's plane index; a field with nk levels per tile maps level
+// k+dk of tile to plane tile*nk + (k-1) + dk.
+template <class S>
+struct AccNL {
+  const S& s; const Ctx& c; int tile, k;
+  template <int M> HD double in(int i, int j, int dk = 0) const {
+    const Fld& f = s.in[M];
+    return f.t[(size_t)(tile * f.nk + k - 1 + dk) * c.g.plane + c.g.idx(i, j)];
+  }
+};
+template <class S>
+struct AccTL {
+  const S& s; const Ctx& c; int tile, k;
+  template <int M> HD Dual in(int i, int j, int dk = 0) const {
+    const Fld& f = s.in[M];
+    size_t n = (size_t)(tile * f.nk + k - 1 + dk) * c.g.plane + c.g.idx(i, j);
+    return Dual(f.t[n], f.p ? f.p[n] : 0.0);
+  }
+};
+template <class S, int MS>
+struct AccAD {
+  const S& s; const Ctx& c; int tile, k; int si, sj, sk;   // seed point (absolute i, j, level)
+  template <int M> HD Dual in(int i, int j, int dk = 0) const {
+    const Fld& f = s.in[M];
+    double t = f.t[(size_t)(tile * f.nk + k - 1 + dk) * c.g.plane + c.g.idx(i, j)];
+    return Dual(t, (M == MS && i == si && j == sj && k + dk == sk) ? 1.0 : 0.0);
+  }
+};
+#ifdef FV3LM_HOST_EMUL
+// Debug accessor: checks every access against the stage's declared stencil box.
+template <class S>
+struct AccChk {
+  const S& s; const Ctx& c; int tile, k; int ei, ej;   // evaluation point
+  template <int M> Dual in(int i, int j, int dk = 0) const {
+    Box b = S::box(M);
+    if (i - ei < b.di0 || i - ei > b.di1 || j - ej < b.dj0 || j - ej > b.dj1 || dk < b.dk0 || dk > b.dk1) {
+      std::fprintf(stderr, "stage %s: input %d accessed at offset (%d,%d,%d) outside declared box\n", S::name(), M,
+                   i - ei, j - ej, dk);
+      std::abort();
+    }
+    const Fld& f = s.in[M];
+    size_t n = (size_t)(tile * f.nk + k - 1 + dk) * c.g.plane + c.g.idx(i, j);
+    return Dual(f.t[n], f.p ? f.p[n] : 0.0);
+  }
+};
+#endif
+
+}  // namespace fv3

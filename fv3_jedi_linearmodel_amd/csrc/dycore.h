@@ -1,0 +1,399 @@
+// fv3lm-hip: the dynamics driver — device state, the acoustic-step program (DYN_CORE_TLM /
+// DYN_CORE_FWD+BWD, dyn_core_tlm.F90:467-1346, dyn_core_adm.F90:115/1686) and its execution in
+// nonlinear, tangent-linear and adjoint order.
+//
+// Adjoint strategy (replaces the Tapenade tape, utils/tapenade/adStack.c): the forward nonlinear
+// sweep stores only the prognostic state at the start of every acoustic step (4 fields); the
+// backward sweep, for each step in reverse, reloads that checkpoint, recomputes the step's
+// nonlinear intermediates (every work array is written once per step), zeroes the work adjoints
+// with one memset and runs the stage list backwards in gather form.
+#pragma once
+#include "../../include/fv3lm.h"
+#include "stages.h"
+#include "column.h"
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace fv3 {
+
+// ------------------------------------------------------------------ device memory helpers
+#ifdef FV3LM_HOST_EMUL
+inline void* dev_alloc(size_t n) { void* p = std::calloc(n ? n : 1, 1); return p; }
+inline void dev_free(void* p) { std::free(p); }
+inline void dev_zero(Exec&, void* p, size_t n) { std::memset(p, 0, n); }
+inline void dev_copy(Exec&, void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
+inline void h2d(Exec&, void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
+inline void d2h(Exec&, void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
+inline void dev_sync(Exec&) {}
+#else
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); std::abort(); } } while (0)
+inline void* dev_alloc(size_t n) { void* p = nullptr; HIPCHK(hipMalloc(&p, n ? n : 8)); HIPCHK(hipMemset(p, 0, n ? n : 8)); return p; }
+inline void dev_free(void* p) { if (p) (void)hipFree(p); }
+inline void dev_zero(Exec& ex, void* p, size_t n) { HIPCHK(hipMemsetAsync(p, 0, n, ex.stream)); }
+inline void dev_copy(Exec& ex, void* d, const void* s, size_t n) { HIPCHK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, ex.stream)); }
+inline void h2d(Exec& ex, void* d, const void* s, size_t n) { HIPCHK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, ex.stream)); HIPCHK(hipStreamSynchronize(ex.stream)); }
+inline void d2h(Exec& ex, void* d, const void* s, size_t n) { HIPCHK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, ex.stream)); HIPCHK(hipStreamSynchronize(ex.stream)); }
+inline void dev_sync(Exec& ex) { HIPCHK(hipStreamSynchronize(ex.stream)); }
+#endif
+
+// One arena = one traj buffer + one pert buffer carved into fields; the pert side of the work arena
+// is cleared with a single memset per backward acoustic step.
+struct Arena {
+  double* t = nullptr; double* p = nullptr; size_t cap = 0, used = 0;
+  void init(size_t ndoubles) { cap = ndoubles; t = (double*)dev_alloc(cap * 8); p = (double*)dev_alloc(cap * 8); used = 0; }
+  void destroy() { dev_free(t); dev_free(p); t = p = nullptr; }
+  Fld take(size_t n, int nk) {
+    if (used + n > cap) { std::fprintf(stderr, "fv3lm: arena overflow\n"); std::abort(); }
+    Fld f; f.t = t + used; f.p = p + used; f.nk = nk; used += n; return f;
+  }
+};
+
+typedef fv3lm_options Options;   // include/fv3lm.h
+
+// Per-level selection, dyn_core_tlm.F90:741-921.  Returns false on a trajectory/perturbation
+// advection-order split at level k (that recompute path is not built yet).
+inline bool resolve_level(const Options& o, int k, int npz, LevelParams& lp) {
+  int hord_m = o.hord_mt, hord_t = o.hord_tm, hord_v = o.hord_vt, hord_p = o.hord_dp;
+  int nord_k = o.nord, nord_v = (2 > o.nord) ? o.nord : 2;
+  double d2_divg = (0.20 > o.d2_bg) ? o.d2_bg : 0.20;
+  double damp_vt = o.do_vort_damp ? o.vtdm4 : 0.;
+  int nord_w = nord_v, nord_t = nord_v;
+  double damp_w = damp_vt, damp_t = damp_vt, d_con_k = o.d_con;
+  if (npz == 1 || o.n_sponge < 0) {
+    d2_divg = o.d2_bg;
+  } else if (k == 1) {
+    nord_k = 0;
+    if (0.01 < o.d2_bg) d2_divg = (o.d2_bg < o.d2_bg_k1) ? o.d2_bg_k1 : o.d2_bg;
+    else if (0.01 < o.d2_bg_k1) d2_divg = o.d2_bg_k1;
+    else d2_divg = 0.01;
+    nord_w = 0; damp_w = d2_divg;
+    if (o.do_vort_damp) { nord_v = 0; damp_vt = 0.5 * d2_divg; }
+    d_con_k = 0.;
+  } else {
+    const int max1 = (2 < o.n_sponge - 1) ? o.n_sponge - 1 : 2;
+    if (k == max1 && o.d2_bg_k2 > 0.01) {
+      nord_k = 0; d2_divg = (o.d2_bg < o.d2_bg_k2) ? o.d2_bg_k2 : o.d2_bg;
+      nord_w = 0; damp_w = d2_divg;
+      if (o.do_vort_damp) { nord_v = 0; damp_vt = 0.5 * d2_divg; }
+      d_con_k = 0.;
+    } else {
+      const int max2 = (3 < o.n_sponge) ? o.n_sponge : 3;
+      if (k == max2 && o.d2_bg_k2 > 0.05) {
+        nord_k = 0; d2_divg = (o.d2_bg < 0.2 * o.d2_bg_k2) ? 0.2 * o.d2_bg_k2 : o.d2_bg;
+        nord_w = 0; damp_w = d2_divg; d_con_k = 0.;
+      }
+    }
+  }
+  int hmp = o.hord_mt_pert, htp = o.hord_tm_pert, hvp = o.hord_vt_pert, hpp = o.hord_dp_pert;
+  int nord_v_pert = (2 > o.nord_pert) ? o.nord_pert : 2;
+  double damp_vt_pert = o.do_vort_damp_pert ? o.vtdm4_pert : 0.;
+  if (k <= o.n_sponge_pert) {
+    if (k <= o.n_sponge_pert - 1) {
+      if (o.hord_ks_traj) { hord_m = o.hord_mt_ks_traj; hord_t = o.hord_tm_ks_traj; hord_v = o.hord_vt_ks_traj; hord_p = o.hord_dp_ks_traj; }
+      if (o.hord_ks_pert) { hmp = o.hord_mt_ks_pert; htp = o.hord_tm_ks_pert; hvp = o.hord_vt_ks_pert; hpp = o.hord_dp_ks_pert; }
+    }
+    const double kfac = (k == 1) ? o.d2_bg_k1_pert : (k == 2) ? o.d2_bg_k2_pert : o.d2_bg_ks_pert;
+    double d2p;
+    if (0.01 < o.d2_bg_pert) d2p = (o.d2_bg_pert < kfac) ? kfac : o.d2_bg_pert;
+    else if (0.01 < kfac) d2p = kfac;
+    else d2p = 0.01;
+    if (o.do_vort_damp_pert) { nord_v_pert = 0; damp_vt_pert = 0.5 * d2p; }
+  }
+  lp.hord_mt = hord_m; lp.hord_vt = hord_v; lp.hord_tm = hord_t; lp.hord_dp = hord_p; lp.hord_tr = o.hord_tr;
+  lp.nord = nord_k; lp.nord_v = nord_v; lp.nord_w = nord_w; lp.nord_t = nord_t; lp.nord_v_pert = nord_v_pert;
+  lp.d2_divg = d2_divg; lp.damp_vt = damp_vt; lp.damp_w = damp_w; lp.damp_t = damp_t; lp.d_con = d_con_k;
+  lp.damp_vt_pert = damp_vt_pert;
+  return hord_m == hmp && hord_t == htp && hord_v == hvp && hord_p == hpp;
+}
+
+struct Op {
+  std::string group;
+  std::function<void(Exec&, int)> fn;   // mode-aware
+  bool accum = false;                   // flux-capacitor update: skipped in the adjoint's trajectory recompute
+};
+typedef std::vector<Op> Program;
+
+struct Dycore {
+  Geom g{}; Options opt; Exec ex; Ctx ctx{};
+  double bdt = 0; int n_split = 1, k_split = 1, nq = 0;
+  std::vector<double*> metric_dev;
+  LevelParams* lev_dev = nullptr;
+  std::vector<LevelParams> lev_host;
+  double* hs_dev = nullptr;
+  Arena state, work;
+  std::map<std::string, Fld> F;       // field registry (debug/test access + driver)
+  Program acoustic;                   // one acoustic step
+  double* ckpt = nullptr;             // [n_split*k_split][4][field3]
+  size_t n3 = 0, n3p = 0;             // doubles per npz / npz+1 field
+  std::string err;
+
+  Fld& f(const char* n) {
+    auto it = F.find(n);
+    if (it == F.end()) { std::fprintf(stderr, "fv3lm: unknown field %s\n", n); std::abort(); }
+    return it->second;
+  }
+  Fld S(const char* n, int nk) { Fld x = state.take((size_t)g.ntile * nk * g.plane, nk); F[n] = x; return x; }
+  Fld W(const char* n, int nk) { Fld x = work.take((size_t)g.ntile * nk * g.plane, nk); F[n] = x; return x; }
+
+  Rect R(int i0, int i1, int j0, int j1) const { return Rect{i0, i1, j0, j1}; }
+
+  template <class St>
+  void add(Program& P, const char* group, const St& s) {
+    Ctx* cp = &ctx;
+    P.push_back(Op{group, [s, cp](Exec& e, int mode) { run(e, mode, s, *cp); }});
+  }
+  void add_halo(Program& P, const char* group, Fld fld) {
+    Geom gg = g;
+    P.push_back(Op{group, [fld, gg](Exec& e, int mode) { run_halo(e, mode, gg, fld); }});
+  }
+  void add_accum(Program& P, const char* group, Fld acc, Fld x, Rect r) {
+    Geom gg = g;
+    P.push_back(Op{group, [acc, x, r, gg](Exec& e, int mode) { run_accum(e, mode, gg, acc, x, r); }, true});
+  }
+
+  // fv_tp_2d as a stage sequence (tp_core_tlm.F90:83-236): q -> fx, fy.  mx/my = xfx/yfx or mass fluxes.
+  void build_tp(Program& P, const char* grp, const std::string& pre, Fld q, Fld crx, Fld cry, Fld xfx, Fld yfx, Fld rax,
+                Fld ray, Fld mx, Fld my, Fld mass, int hsel, int dsel, bool use_mass, Fld fx, Fld fy) {
+    const int is = 1, ie = g.nx, js = 1, je = g.ny, isd = g.isd(), ied = g.ied(), jsd = g.jsd(), jed = g.jed(), npz = g.npz;
+    Fld fy2 = W((pre + "_fy2").c_str(), npz), q_i = W((pre + "_qi").c_str(), npz), fxo = W((pre + "_fxo").c_str(), npz);
+    Fld fx2 = W((pre + "_fx2").c_str(), npz), q_j = W((pre + "_qj").c_str(), npz), fyo = W((pre + "_fyo").c_str(), npz);
+    TpPpmY a; a.in[0] = q; a.in[1] = cry; a.out[0] = fy2; a.orect[0] = R(isd, ied, js, je + 1); a.k1 = npz; a.hsel = hsel;
+    add(P, grp, a);
+    TpQi b; b.in[0] = q; b.in[1] = fy2; b.in[2] = yfx; b.in[3] = ray; b.out[0] = q_i; b.orect[0] = R(isd, ied, js, je); b.k1 = npz;
+    add(P, grp, b);
+    TpPpmX c_; c_.in[0] = q_i; c_.in[1] = crx; c_.out[0] = fxo; c_.orect[0] = R(is, ie + 1, js, je); c_.k1 = npz; c_.hsel = hsel;
+    add(P, grp, c_);
+    TpPpmX d; d.in[0] = q; d.in[1] = crx; d.out[0] = fx2; d.orect[0] = R(is, ie + 1, jsd, jed); d.k1 = npz; d.hsel = hsel;
+    add(P, grp, d);
+    TpQj e; e.in[0] = q; e.in[1] = fx2; e.in[2] = xfx; e.in[3] = rax; e.out[0] = q_j; e.orect[0] = R(is, ie, jsd, jed); e.k1 = npz;
+    add(P, grp, e);
+    TpPpmY f_; f_.in[0] = q_j; f_.in[1] = cry; f_.out[0] = fyo; f_.orect[0] = R(is, ie, js, je + 1); f_.k1 = npz; f_.hsel = hsel;
+    add(P, grp, f_);
+    Fld d2b{};
+    if (dsel != DAMP_NONE) {
+      d2b = W((pre + "_d2b").c_str(), npz);
+      TpD2 h; h.in[0] = q; h.out[0] = d2b; h.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); h.k1 = npz; h.dsel = dsel; h.use_mass = use_mass;
+      add(P, grp, h);
+    }
+    TpFlux t; t.in[0] = fxo; t.in[1] = fx2; t.in[2] = mx; t.in[3] = fyo; t.in[4] = fy2; t.in[5] = my;
+    t.in[6] = (dsel != DAMP_NONE) ? q : Fld{}; t.in[7] = d2b; t.in[8] = use_mass ? mass : Fld{};
+    for (int n = 6; n < 9; ++n) if (!t.in[n].t) t.in[n].nk = npz;
+    t.out[0] = fx; t.out[1] = fy; t.orect[0] = R(is, ie + 1, js, je); t.orect[1] = R(is, ie, js, je + 1); t.k1 = npz;
+    t.dsel = dsel; t.use_mass = use_mass;
+    add(P, grp, t);
+  }
+  // a2b_ord4 (a2b_edge_tlm.F90:48-542), interior: q (nk levels) -> qb on is..ie+1, js..je+1
+  void build_a2b(Program& P, const char* grp, const std::string& pre, Fld q, Fld qb, int nk) {
+    const int is = 1, ie = g.nx, js = 1, je = g.ny;
+    Fld qx = W((pre + "_qx").c_str(), nk), qy = W((pre + "_qy").c_str(), nk);
+    A2bA a; a.in[0] = q; a.out[0] = qx; a.out[1] = qy; a.orect[0] = R(is, ie + 1, js - 2, je + 2); a.orect[1] = R(is - 2, ie + 2, js, je + 1); a.k1 = nk;
+    add(P, grp, a);
+    A2bB b; b.in[0] = qx; b.in[1] = qy; b.out[0] = qb; b.orect[0] = R(is, ie + 1, js, je + 1); b.k1 = nk;
+    add(P, grp, b);
+  }
+
+  void build_acoustic();
+  bool init(int nx, int ny, int npz, int ntile, int nq_, double bdt_, int n_split_, int k_split_, const Options& o,
+            const double* const* metrics_host, double da_min, double da_min_c, const double* phis_host);
+  void destroy();
+
+  void run_group(const Program& P, const char* group, int mode, bool skip_accum = false);
+  void zero_work_adjoint() { dev_zero(ex, work.p, work.used * 8); }
+  void dyn_core(int mode);
+};
+
+inline void Dycore::run_group(const Program& P, const char* group, int mode, bool skip_accum) {
+  const bool all = (group == nullptr) || (group[0] == 0);
+  if (mode != MODE_AD) {
+    for (const Op& op : P) if ((all || op.group == group) && !(skip_accum && op.accum)) op.fn(ex, mode);
+  } else {
+    for (auto it = P.rbegin(); it != P.rend(); ++it) if (all || it->group == group) it->fn(ex, mode);
+  }
+}
+
+inline bool Dycore::init(int nx, int ny, int npz, int ntile, int nq_, double bdt_, int n_split_, int k_split_,
+                         const Options& o, const double* const* metrics_host, double da_min, double da_min_c,
+                         const double* phis_host) {
+  g.nx = nx; g.ny = ny; g.ng = 3; g.npz = npz; g.ntile = ntile; g.pi = nx + 2 * g.ng + 1; g.pj = ny + 2 * g.ng + 1;
+  g.plane = g.pi * g.pj;
+  opt = o; bdt = bdt_; n_split = n_split_; k_split = k_split_; nq = nq_;
+  if (nx < 8 || ny < 8 || npz < 1) { err = "tile too small (need nx,ny >= 8)"; return false; }
+  if (ntile != 1) { err = "multi-tile cube exchange not built yet: ntile must be 1 (doubly-periodic tile)"; return false; }
+  if (o.nord > 1 || o.nord_pert > 1 || o.nord < 0) { err = "nord/nord_pert in {0,1} only"; return false; }
+  if (!o.hydrostatic) { err = "non-hydrostatic path (nh_core) not built yet"; return false; }
+  lev_host.resize(npz);
+  for (int k = 1; k <= npz; ++k) {
+    if (!resolve_level(o, k, npz, lev_host[k - 1])) { err = "trajectory/perturbation hord split (split_hord) not supported"; return false; }
+    const LevelParams& l = lev_host[k - 1];
+    for (int h : {l.hord_mt, l.hord_vt, l.hord_tm, l.hord_dp, l.hord_tr})
+      if (h != 1 && h != 2 && h != 333) { err = "hord must be 1, 2 or 333 (the schemes the TL/AD reference implements)"; return false; }
+  }
+#ifndef FV3LM_HOST_EMUL
+  HIPCHK(hipStreamCreate(&ex.stream));
+#endif
+  lev_dev = (LevelParams*)dev_alloc(sizeof(LevelParams) * npz);
+  h2d(ex, lev_dev, lev_host.data(), sizeof(LevelParams) * npz);
+  const size_t np = (size_t)ntile * g.plane;
+  metric_dev.resize(NMETRIC);
+  for (int m = 0; m < NMETRIC; ++m) { metric_dev[m] = (double*)dev_alloc(np * 8); h2d(ex, metric_dev[m], metrics_host[m], np * 8); }
+  Metrics& M = ctx.m; int m = 0;
+  const double** slots[] = {&M.area, &M.rarea, &M.rarea_c, &M.dx, &M.dy, &M.dxa, &M.dya, &M.dxc, &M.dyc, &M.rdx, &M.rdy, &M.rdxa,
+                            &M.rdya, &M.rdxc, &M.rdyc, &M.cosa, &M.sina, &M.rsina, &M.cosa_u, &M.cosa_v, &M.cosa_s, &M.sina_u,
+                            &M.sina_v, &M.rsin_u, &M.rsin_v, &M.rsin2, &M.f0, &M.fC, &M.del6_u, &M.del6_v, &M.divg_u, &M.divg_v};
+  for (auto s : slots) *s = metric_dev[m++];
+  M.sin_sg[0] = M.cos_sg[0] = nullptr;
+  for (int n = 1; n <= 9; ++n) M.sin_sg[n] = metric_dev[m++];
+  for (int n = 1; n <= 9; ++n) M.cos_sg[n] = metric_dev[m++];
+  M.da_min = da_min; M.da_min_c = da_min_c;
+  hs_dev = (double*)dev_alloc(np * 8);
+  if (phis_host) h2d(ex, hs_dev, phis_host, np * 8);
+  ctx.g = g; ctx.lev = lev_dev; ctx.nlev = npz;
+  n3 = np * npz; n3p = np * (npz + 1);
+  state.init(n3 * (16 + 2 * (size_t)nq) + n3p * 4);
+  work.init(n3 * 110 + n3p * 14);
+  build_acoustic();
+  ckpt = (double*)dev_alloc((size_t)n_split * k_split * 4 * n3 * 8);
+  return true;
+}
+
+inline void Dycore::destroy() {
+  for (double* p : metric_dev) dev_free(p);
+  dev_free(lev_dev); dev_free(hs_dev); dev_free(ckpt);
+  state.destroy(); work.destroy();
+#ifndef FV3LM_HOST_EMUL
+  if (ex.stream) (void)hipStreamDestroy(ex.stream);
+#endif
+}
+
+// One acoustic step, hydrostatic (dyn_core_tlm.F90:1736-2466).  Inputs u,v,delp,pt (halos valid);
+// outputs u_o,v_o,delp_o,pt_o (halos valid) + accumulated mfx,mfy,cx,cy + pe,peln,pk,pkz.
+inline void Dycore::build_acoustic() {
+  const int is = 1, ie = g.nx, js = 1, je = g.ny, isd = g.isd(), ied = g.ied(), jsd = g.jsd(), jed = g.jed(), npz = g.npz;
+  const double dt = bdt / double(n_split) / double(k_split), dt2 = 0.5 * dt;
+  Program& P = acoustic;
+  // prognostic state (step input / output) and accumulators
+  Fld u = S("u", npz), v = S("v", npz), delp = S("delp", npz), pt = S("pt", npz);
+  Fld u_o = S("u_o", npz), v_o = S("v_o", npz), delp_o = S("delp_o", npz), pt_o = S("pt_o", npz);
+  Fld mfx = S("mfx", npz), mfy = S("mfy", npz), cx = S("cx", npz), cy = S("cy", npz);
+  Fld pe = S("pe", npz + 1), peln = S("peln", npz + 1), pk = S("pk", npz + 1), pkz = S("pkz", npz);
+  // ---- c_sw
+  Fld utmp = W("utmp", npz), vtmp = W("vtmp", npz), ua = W("ua", npz), va = W("va", npz);
+  { CswInterpA s; s.in[0] = u; s.in[1] = v; s.out[0] = utmp; s.out[1] = vtmp; s.out[2] = ua; s.out[3] = va;
+    s.orect[0] = R(isd, ied, js - 1, je + 1); s.orect[1] = R(is - 1, ie + 1, jsd, jed);
+    s.orect[2] = s.orect[3] = R(is - 1, ie + 1, js - 1, je + 1); s.k1 = npz; add(P, "c_sw", s); }
+  Fld uc0 = W("uc0", npz), utf = W("utf", npz), vc0 = W("vc0", npz), vtf = W("vtf", npz);
+  { CswInterpC s; s.in[0] = utmp; s.in[1] = vtmp; s.in[2] = u; s.in[3] = v; s.out[0] = uc0; s.out[1] = utf; s.out[2] = vc0; s.out[3] = vtf;
+    s.orect[0] = s.orect[1] = R(is - 1, ie + 2, js - 1, je + 1); s.orect[2] = s.orect[3] = R(is - 1, ie + 1, js - 1, je + 2);
+    s.dt2 = dt2; s.k1 = npz; add(P, "c_sw", s); }
+  Fld divgd = W("divgd", npz);
+  if (opt.nord > 0) {
+    CswDivg s; s.in[0] = u; s.in[1] = v; s.in[2] = ua; s.in[3] = va; s.out[0] = divgd; s.orect[0] = R(is, ie + 1, js, je + 1); s.k1 = npz;
+    add(P, "c_sw", s);
+  }
+  Fld delpc = W("delpc", npz), ptc = W("ptc", npz);
+  { CswTransport s; s.in[0] = delp; s.in[1] = pt; s.in[2] = utf; s.in[3] = vtf; s.out[0] = delpc; s.out[1] = ptc;
+    s.orect[0] = s.orect[1] = R(is - 1, ie + 1, js - 1, je + 1); s.k1 = npz; add(P, "c_sw", s); }
+  Fld ke_c = W("ke_c", npz), vort_c = W("vort_c", npz);
+  { CswKeVort s; s.in[0] = ua; s.in[1] = va; s.in[2] = uc0; s.in[3] = vc0; s.out[0] = ke_c; s.out[1] = vort_c;
+    s.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); s.orect[1] = R(is, ie + 1, js, je + 1); s.dt2 = dt2; s.k1 = npz; add(P, "c_sw", s); }
+  Fld uc1 = W("uc1", npz), vc1 = W("vc1", npz);
+  { CswUpdate s; s.in[0] = uc0; s.in[1] = vc0; s.in[2] = u; s.in[3] = v; s.in[4] = vort_c; s.in[5] = ke_c; s.out[0] = uc1; s.out[1] = vc1;
+    s.orect[0] = R(is, ie + 1, js, je); s.orect[1] = R(is, ie, js, je + 1); s.dt2 = dt2; s.k1 = npz; add(P, "c_sw", s); }
+  if (opt.nord > 0) add_halo(P, "halo_divgd", divgd);
+  // ---- geopk (C grid) + p_grad_c
+  Fld pe_c = W("pe_c", npz + 1), peln_c = W("peln_c", npz + 1), pkc = W("pkc", npz + 1), gz = W("gz", npz + 1);
+  { GeopkArgs a; a.g = g; a.R = R(is - 1, ie + 1, js - 1, je + 1); a.delp = delpc; a.pt = ptc; a.pe = pe_c; a.peln = peln_c; a.pk = pkc;
+    a.gz = gz; a.pkz = Fld{}; a.hs = hs_dev; a.ptop = opt.ptop; a.akap = opt.akap; a.cp_air = opt.cp_air; a.cg = 1;
+    P.push_back(Op{"geopk_c", [a](Exec& e, int mode) { run_geopk(e, mode, a); }}); }
+  Fld uc = W("uc", npz), vc = W("vc", npz);
+  { PGradC s; s.in[0] = pkc; s.in[1] = gz; s.in[2] = uc1; s.in[3] = vc1; s.out[0] = uc; s.out[1] = vc;
+    s.orect[0] = R(is, ie + 1, js, je); s.orect[1] = R(is, ie, js, je + 1); s.dt2 = dt2; s.k1 = npz; add(P, "p_grad_c", s); }
+  add_halo(P, "halo_uc", uc); add_halo(P, "halo_uc", vc);
+  // ---- d_sw
+  Fld ut = W("ut", npz), crx = W("crx", npz), xfx = W("xfx", npz), vt = W("vt", npz), cry = W("cry", npz), yfx = W("yfx", npz);
+  { DswWinds s; s.in[0] = uc; s.in[1] = vc; s.out[0] = ut; s.out[1] = crx; s.out[2] = xfx; s.out[3] = vt; s.out[4] = cry; s.out[5] = yfx;
+    s.orect[0] = R(is - 1, ie + 2, jsd, jed); s.orect[1] = s.orect[2] = R(is, ie + 1, jsd, jed);
+    s.orect[3] = R(isd, ied, js - 1, je + 2); s.orect[4] = s.orect[5] = R(isd, ied, js, je + 1); s.dt = dt; s.k1 = npz; add(P, "d_sw", s); }
+  Fld rax = W("ra_x", npz), ray = W("ra_y", npz);
+  { DswRa s; s.in[0] = xfx; s.in[1] = yfx; s.out[0] = rax; s.out[1] = ray; s.orect[0] = R(is, ie, jsd, jed); s.orect[1] = R(isd, ied, js, je);
+    s.k1 = npz; add(P, "d_sw", s); }
+  Fld fx = W("fx", npz), fy = W("fy", npz), gx = W("gx", npz), gy = W("gy", npz);
+  build_tp(P, "d_sw", "tpd", delp, crx, cry, xfx, yfx, rax, ray, xfx, yfx, Fld{}, HORD_DP, DAMP_V, false, fx, fy);
+  add_accum(P, "d_sw", cx, crx, R(is, ie + 1, jsd, jed)); add_accum(P, "d_sw", mfx, fx, R(is, ie + 1, js, je));
+  add_accum(P, "d_sw", cy, cry, R(isd, ied, js, je + 1)); add_accum(P, "d_sw", mfy, fy, R(is, ie, js, je + 1));
+  build_tp(P, "d_sw", "tpt", pt, crx, cry, xfx, yfx, rax, ray, fx, fy, delp, HORD_TM, DAMP_T, true, gx, gy);
+  { DswUpdateDp s; s.in[0] = delp; s.in[1] = pt; s.in[2] = fx; s.in[3] = fy; s.in[4] = gx; s.in[5] = gy; s.out[0] = delp_o; s.out[1] = pt_o;
+    s.orect[0] = s.orect[1] = R(is, ie, js, je); s.k1 = npz; add(P, "d_sw", s); }
+  Fld vb = W("vb", npz), ub = W("ub", npz), ke = W("ke", npz);
+  { DswKeWinds s; s.in[0] = uc; s.in[1] = vc; s.out[0] = vb; s.out[1] = ub; s.orect[0] = s.orect[1] = R(is, ie + 1, js, je + 1); s.dt = dt;
+    s.k1 = npz; add(P, "d_sw", s); }
+  { DswKe s; s.in[0] = vb; s.in[1] = ub; s.in[2] = u; s.in[3] = v; s.out[0] = ke; s.orect[0] = R(is, ie + 1, js, je + 1); s.k1 = npz; add(P, "d_sw", s); }
+  Fld wk = W("wk", npz), vorta = W("vort_abs", npz);
+  { DswVort s; s.in[0] = u; s.in[1] = v; s.out[0] = wk; s.out[1] = vorta; s.orect[0] = s.orect[1] = R(isd, ied, jsd, jed); s.k1 = npz; add(P, "d_sw", s); }
+  Fld da = W("dd_a", npz), db = W("dd_b", npz), dc = W("dd_c", npz), vortb = W("vort_b", npz), ke2 = W("ke2", npz);
+  { DdA s; s.in[0] = divgd; s.in[1] = u; s.in[2] = v; s.in[3] = ua; s.in[4] = va; s.out[0] = da; s.out[1] = db;
+    s.orect[0] = R(is - 1, ie + 1, js, je + 1); s.orect[1] = R(is, ie + 1, js - 1, je + 1); s.k1 = npz; add(P, "d_sw", s); }
+  { DdB s; s.in[0] = da; s.in[1] = db; s.out[0] = dc; s.orect[0] = R(is, ie + 1, js, je + 1); s.k1 = npz; add(P, "d_sw", s); }
+  build_a2b(P, "d_sw", "a2bw", wk, vortb, npz);
+  { DdC s; s.in[0] = ke; s.in[1] = dc; s.in[2] = divgd; s.in[3] = vortb; s.out[0] = ke2; s.orect[0] = R(is, ie + 1, js, je + 1);
+    s.dt = dt; s.dddmp = opt.dddmp; s.d4_bg = opt.d4_bg; s.k1 = npz; add(P, "d_sw", s); }
+  Fld fxv = W("fxv", npz), fyv = W("fyv", npz);
+  build_tp(P, "d_sw", "tpv", vorta, crx, cry, xfx, yfx, rax, ray, xfx, yfx, Fld{}, HORD_VT, DAMP_NONE, false, fxv, fyv);
+  Fld d6 = W("del6_d2", npz);
+  { Del6A s; s.in[0] = wk; s.out[0] = d6; s.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); s.k1 = npz; add(P, "d_sw", s); }
+  Fld u_m = W("u_m", npz), v_m = W("v_m", npz);
+  { DswUpdateUV s; s.in[0] = u; s.in[1] = v; s.in[2] = ke2; s.in[3] = fxv; s.in[4] = fyv; s.in[5] = wk; s.in[6] = d6; s.out[0] = u_m; s.out[1] = v_m;
+    s.orect[0] = R(is, ie, js, je + 1); s.orect[1] = R(is, ie + 1, js, je); s.k1 = npz; add(P, "d_sw", s); }
+  add_halo(P, "halo_dp", delp_o); add_halo(P, "halo_dp", pt_o);
+  // ---- geopk (D grid) + one_grad_p
+  Fld pkd = pk, gzd = W("gzd", npz + 1);
+  { GeopkArgs a; a.g = g; a.R = R(is - 2, ie + 2, js - 2, je + 2); a.delp = delp_o; a.pt = pt_o; a.pe = pe; a.peln = peln; a.pk = pkd;
+    a.gz = gzd; a.pkz = pkz; a.hs = hs_dev; a.ptop = opt.ptop; a.akap = opt.akap; a.cp_air = opt.cp_air; a.cg = 0;
+    P.push_back(Op{"geopk_d", [a](Exec& e, int mode) { run_geopk(e, mode, a); }}); }
+  Fld pkb = W("pk_b", npz + 1), gzb = W("gz_b", npz + 1);
+  build_a2b(P, "one_grad_p", "a2bp", pkd, pkb, npz + 1);
+  build_a2b(P, "one_grad_p", "a2bg", gzd, gzb, npz + 1);
+  { OneGradP s; s.in[0] = u_m; s.in[1] = v_m; s.in[2] = pkb; s.in[3] = gzb; s.out[0] = u_o; s.out[1] = v_o;
+    s.orect[0] = R(is, ie, js, je + 1); s.orect[1] = R(is, ie + 1, js, je); s.dt = dt; s.ptk = std::pow(opt.ptop, opt.akap); s.k1 = npz;
+    add(P, "one_grad_p", s); }
+  add_halo(P, "halo_uv", u_o); add_halo(P, "halo_uv", v_o);
+}
+
+// n_split acoustic steps.  NL/TL: state fields u,v,delp,pt are advanced in place (via the *_o
+// buffers).  AD: on entry the .p of u,v,delp,pt (and of mfx..cy, pe..pkz) hold the adjoint of the
+// outputs; on exit the adjoint of the inputs.  Trajectory checkpoints must have been stored by a
+// preceding MODE_NL sweep (store_ckpt=true).
+inline void Dycore::dyn_core(int mode) {
+  const char* names[4] = {"u", "v", "delp", "pt"};
+  const char* onames[4] = {"u_o", "v_o", "delp_o", "pt_o"};
+  const size_t b3 = n3 * 8;
+  if (mode != MODE_AD) {
+    for (const char* a : {"mfx", "mfy", "cx", "cy"}) { dev_zero(ex, f(a).t, b3); if (mode == MODE_TL) dev_zero(ex, f(a).p, b3); }
+    for (int it = 0; it < n_split; ++it) {
+      if (mode == MODE_NL)
+        for (int n = 0; n < 4; ++n) dev_copy(ex, ckpt + ((size_t)it * 4 + n) * n3, f(names[n]).t, b3);
+      run_group(acoustic, nullptr, mode);
+      for (int n = 0; n < 4; ++n) {
+        dev_copy(ex, f(names[n]).t, f(onames[n]).t, b3);
+        if (mode == MODE_TL) dev_copy(ex, f(names[n]).p, f(onames[n]).p, b3);
+      }
+    }
+  } else {
+    // incoming adjoint lives in the input-named buffers; move it to the *_o side of the last step
+    for (int it = n_split - 1; it >= 0; --it) {
+      for (int n = 0; n < 4; ++n) dev_copy(ex, f(names[n]).t, ckpt + ((size_t)it * 4 + n) * n3, b3);
+      // recompute this step's nonlinear intermediates (flux capacitors left alone)
+      run_group(acoustic, nullptr, MODE_NL, true);
+      zero_work_adjoint();
+      for (int n = 0; n < 4; ++n) { dev_copy(ex, f(onames[n]).p, f(names[n]).p, b3); dev_zero(ex, f(names[n]).p, b3); }
+      run_group(acoustic, nullptr, MODE_AD);
+      // pe, peln, pk, pkz of earlier steps are overwritten by later ones: their adjoint is zero there
+      for (const char* a : {"pe", "peln", "pk"}) dev_zero(ex, f(a).p, n3p * 8);
+      dev_zero(ex, f("pkz").p, b3);
+    }
+  }
+}
+
+}  // namespace fv3

@@ -1,0 +1,221 @@
+// fv3lm-hip: generic stage launchers (nonlinear / tangent / adjoint) — see core.h.
+//
+// Thread mapping (gfx950): one thread per grid point, block = 64 x 4 (one wavefront per row
+// segment, i fastest so that every global access of a wave is a contiguous 512-byte row piece),
+// grid.z = tiles x levels — at C48L72 that is already >10^3 workgroups per launch, C192L127 x 6
+// faces ~10^5, far above the 256 CUs.  Levels/tiles are the outermost index so that the planes of
+// one level stay together in an XCD's L2 while the stencil rows are re-read.
+#pragma once
+#include "core.h"
+
+namespace fv3 {
+
+struct Exec {
+#ifndef FV3LM_HOST_EMUL
+  hipStream_t stream = nullptr;
+#endif
+  bool check_boxes = false;   // host emulation only: verify declared stencil boxes
+  long launches = 0;
+};
+
+HD Rect rect_union(const Rect* r, int n) {
+  Rect u = r[0];
+  for (int m = 1; m < n; ++m) {
+    if (r[m].i0 < u.i0) u.i0 = r[m].i0;
+    if (r[m].i1 > u.i1) u.i1 = r[m].i1;
+    if (r[m].j0 < u.j0) u.j0 = r[m].j0;
+    if (r[m].j1 > u.j1) u.j1 = r[m].j1;
+  }
+  return u;
+}
+
+// ---- per-point bodies ---------------------------------------------------------------------
+template <class S>
+HD void body_nl(const S& s, const Ctx& c, int i, int j, int z) {
+  const int nl = s.k1 - s.k0 + 1, tile = z / nl, k = s.k0 + z % nl;
+  double o[S::NOUT];
+  AccNL<S> a{s, c, tile, k};
+  s.template eval<double>(a, c, tile, i, j, k, o);
+  for (int n = 0; n < S::NOUT; ++n)
+    if (s.orect[n].has(i, j)) s.out[n].t[(size_t)(tile * s.out[n].nk + k - 1) * c.g.plane + c.g.idx(i, j)] = o[n];
+}
+template <class S>
+HD void body_tl(const S& s, const Ctx& c, int i, int j, int z) {
+  const int nl = s.k1 - s.k0 + 1, tile = z / nl, k = s.k0 + z % nl;
+  Dual o[S::NOUT];
+  AccTL<S> a{s, c, tile, k};
+  s.template eval<Dual>(a, c, tile, i, j, k, o);
+  for (int n = 0; n < S::NOUT; ++n)
+    if (s.orect[n].has(i, j)) {
+      size_t m = (size_t)(tile * s.out[n].nk + k - 1) * c.g.plane + c.g.idx(i, j);
+      s.out[n].t[m] = o[n].v;
+      s.out[n].p[m] = o[n].d;
+    }
+}
+// Adjoint of input M at point (i,j) of plane z (z counts levels 1..in[M].nk per tile).
+template <class S, int M>
+HD void body_ad_one(const S& s, const Ctx& c, const Rect& R, int i, int j, int z) {
+  const Fld& f = s.in[M];
+  if (!f.p) return;
+  const int tile = z / f.nk, kk = 1 + z % f.nk;
+  const Box b = S::box(M);
+  if (i < R.i0 + b.di0 || i > R.i1 + b.di1 || j < R.j0 + b.dj0 || j > R.j1 + b.dj1) return;
+  double acc = 0.0;
+  for (int dk = b.dk0; dk <= b.dk1; ++dk) {
+    const int k = kk - dk;
+    if (k < s.k0 || k > s.k1) continue;
+    AccAD<S, M> a{s, c, tile, k, i, j, kk};
+    for (int dj = b.dj0; dj <= b.dj1; ++dj) {
+      const int oj = j - dj;
+      if (oj < R.j0 || oj > R.j1) continue;
+      for (int di = b.di0; di <= b.di1; ++di) {
+        const int oi = i - di;
+        if (oi < R.i0 || oi > R.i1) continue;
+        Dual o[S::NOUT];
+        s.template eval<Dual>(a, c, tile, oi, oj, k, o);
+        for (int n = 0; n < S::NOUT; ++n)
+          if (s.orect[n].has(oi, oj))
+            acc += o[n].d * s.out[n].p[(size_t)(tile * s.out[n].nk + k - 1) * c.g.plane + c.g.idx(oi, oj)];
+      }
+    }
+  }
+  f.p[(size_t)(tile * f.nk + kk - 1) * c.g.plane + c.g.idx(i, j)] += acc;
+}
+template <class S, int M, bool END = (M >= S::NIN)>
+struct AdLoop {
+  HD static void run(const S& s, const Ctx& c, const Rect& R, int i, int j, int z, int nkmax) {
+    if (z < c.g.ntile * s.in[M].nk) body_ad_one<S, M>(s, c, R, i, j, z);
+    AdLoop<S, M + 1>::run(s, c, R, i, j, z, nkmax);
+  }
+};
+template <class S, int M>
+struct AdLoop<S, M, true> {
+  HD static void run(const S&, const Ctx&, const Rect&, int, int, int, int) {}
+};
+
+template <class S>
+inline Rect ad_input_rect(const S& s, const Ctx& c, const Rect& R) {
+  Rect q = R;
+  for (int m = 0; m < S::NIN; ++m) {
+    Box b = S::box(m);
+    if (R.i0 + b.di0 < q.i0) q.i0 = R.i0 + b.di0;
+    if (R.i1 + b.di1 > q.i1) q.i1 = R.i1 + b.di1;
+    if (R.j0 + b.dj0 < q.j0) q.j0 = R.j0 + b.dj0;
+    if (R.j1 + b.dj1 > q.j1) q.j1 = R.j1 + b.dj1;
+  }
+  if (q.i0 < c.g.isd()) q.i0 = c.g.isd();
+  if (q.j0 < c.g.jsd()) q.j0 = c.g.jsd();
+  if (q.i1 > c.g.ied() + 1) q.i1 = c.g.ied() + 1;
+  if (q.j1 > c.g.jed() + 1) q.j1 = c.g.jed() + 1;
+  return q;
+}
+
+#ifndef FV3LM_HOST_EMUL
+// ---- HIP kernels ---------------------------------------------------------------------------
+constexpr int BX = 64, BY = 4;
+template <class S>
+__global__ void __launch_bounds__(BX* BY) k_stage_nl(S s, Ctx c, Rect R) {
+  const int i = R.i0 + blockIdx.x * BX + threadIdx.x, j = R.j0 + blockIdx.y * BY + threadIdx.y;
+  if (i <= R.i1 && j <= R.j1) body_nl(s, c, i, j, blockIdx.z);
+}
+template <class S>
+__global__ void __launch_bounds__(BX* BY) k_stage_tl(S s, Ctx c, Rect R) {
+  const int i = R.i0 + blockIdx.x * BX + threadIdx.x, j = R.j0 + blockIdx.y * BY + threadIdx.y;
+  if (i <= R.i1 && j <= R.j1) body_tl(s, c, i, j, blockIdx.z);
+}
+template <class S>
+__global__ void __launch_bounds__(BX* BY) k_stage_ad(S s, Ctx c, Rect R, Rect Q, int nkmax) {
+  const int i = Q.i0 + blockIdx.x * BX + threadIdx.x, j = Q.j0 + blockIdx.y * BY + threadIdx.y;
+  if (i <= Q.i1 && j <= Q.j1) AdLoop<S, 0>::run(s, c, R, i, j, blockIdx.z, nkmax);
+}
+inline dim3 grid_for(const Rect& R, int nz) {
+  return dim3((R.i1 - R.i0 + BX) / BX, (R.j1 - R.j0 + BY) / BY, nz);
+}
+template <class S>
+void run_nl(Exec& ex, const S& s, const Ctx& c) {
+  Rect R = rect_union(s.orect, S::NOUT);
+  hipLaunchKernelGGL(k_stage_nl<S>, grid_for(R, c.g.ntile * (s.k1 - s.k0 + 1)), dim3(BX, BY), 0, ex.stream, s, c, R);
+  ex.launches++;
+}
+template <class S>
+void run_tl(Exec& ex, const S& s, const Ctx& c) {
+  Rect R = rect_union(s.orect, S::NOUT);
+  hipLaunchKernelGGL(k_stage_tl<S>, grid_for(R, c.g.ntile * (s.k1 - s.k0 + 1)), dim3(BX, BY), 0, ex.stream, s, c, R);
+  ex.launches++;
+}
+template <class S>
+void run_ad(Exec& ex, const S& s, const Ctx& c) {
+  Rect R = rect_union(s.orect, S::NOUT);
+  Rect Q = ad_input_rect(s, c, R);
+  int nkmax = 0;
+  for (int m = 0; m < S::NIN; ++m) if (s.in[m].nk > nkmax) nkmax = s.in[m].nk;
+  hipLaunchKernelGGL(k_stage_ad<S>, grid_for(Q, c.g.ntile * nkmax), dim3(BX, BY), 0, ex.stream, s, c, R, Q, nkmax);
+  ex.launches++;
+}
+// generic per-point functor launch: f(i, j, z)
+template <class F>
+__global__ void __launch_bounds__(BX* BY) k_points(F f, Rect R) {
+  const int i = R.i0 + blockIdx.x * BX + threadIdx.x, j = R.j0 + blockIdx.y * BY + threadIdx.y;
+  if (i <= R.i1 && j <= R.j1) f(i, j, (int)blockIdx.z);
+}
+template <class F>
+void for_points(Exec& ex, const Rect& R, int nz, const F& f) {
+  if (nz <= 0) return;
+  hipLaunchKernelGGL(k_points<F>, grid_for(R, nz), dim3(BX, BY), 0, ex.stream, f, R);
+  ex.launches++;
+}
+#else
+// ---- host emulation (tests only) -----------------------------------------------------------
+template <class S>
+void run_nl(Exec& ex, const S& s, const Ctx& c) {
+  Rect R = rect_union(s.orect, S::NOUT);
+  for (int z = 0; z < c.g.ntile * (s.k1 - s.k0 + 1); ++z)
+    for (int j = R.j0; j <= R.j1; ++j)
+      for (int i = R.i0; i <= R.i1; ++i) body_nl(s, c, i, j, z);
+  ex.launches++;
+}
+template <class S>
+void run_tl(Exec& ex, const S& s, const Ctx& c) {
+  Rect R = rect_union(s.orect, S::NOUT);
+  const int nl = s.k1 - s.k0 + 1;
+  for (int z = 0; z < c.g.ntile * nl; ++z)
+    for (int j = R.j0; j <= R.j1; ++j)
+      for (int i = R.i0; i <= R.i1; ++i) {
+        if (ex.check_boxes) {
+          Dual o[S::NOUT];
+          AccChk<S> a{s, c, z / nl, s.k0 + z % nl, i, j};
+          s.template eval<Dual>(a, c, z / nl, i, j, s.k0 + z % nl, o);
+        }
+        body_tl(s, c, i, j, z);
+      }
+  ex.launches++;
+}
+template <class S>
+void run_ad(Exec& ex, const S& s, const Ctx& c) {
+  Rect R = rect_union(s.orect, S::NOUT);
+  Rect Q = ad_input_rect(s, c, R);
+  int nkmax = 0;
+  for (int m = 0; m < S::NIN; ++m) if (s.in[m].nk > nkmax) nkmax = s.in[m].nk;
+  for (int z = 0; z < c.g.ntile * nkmax; ++z)
+    for (int j = Q.j0; j <= Q.j1; ++j)
+      for (int i = Q.i0; i <= Q.i1; ++i) AdLoop<S, 0>::run(s, c, R, i, j, z, nkmax);
+  ex.launches++;
+}
+template <class F>
+void for_points(Exec& ex, const Rect& R, int nz, const F& f) {
+  for (int z = 0; z < nz; ++z)
+    for (int j = R.j0; j <= R.j1; ++j)
+      for (int i = R.i0; i <= R.i1; ++i) f(i, j, z);
+  ex.launches++;
+}
+#endif
+
+enum Mode { MODE_NL = 0, MODE_TL = 1, MODE_AD = 2 };
+template <class S>
+void run(Exec& ex, int mode, const S& s, const Ctx& c) {
+  if (mode == MODE_NL) run_nl(ex, s, c);
+  else if (mode == MODE_TL) run_tl(ex, s, c);
+  else run_ad(ex, s, c);
+}
+
+}  // namespace fv3

@@ -1,0 +1,89 @@
+// fv3lm-hip: implementation of the C-ABI declared in include/fv3lm.h.
+// Built with `hipcc -x hip --offload-arch=gfx950` into libfv3lm_hip.so (the product), and with
+// `g++ -DFV3LM_HOST_EMUL` into tests/_emul/libfv3lm_emul.so (test-only host emulation, never
+// loaded by the package).
+#include "dycore.h"
+#include <string>
+
+using namespace fv3;
+
+struct fv3lm_handle { Dycore d; };
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) { g_err = m; return 1; }
+
+extern "C" {
+
+const char* fv3lm_last_error(void) { return g_err.c_str(); }
+
+const char* fv3lm_metric_names(void) {
+  return "area,rarea,rarea_c,dx,dy,dxa,dya,dxc,dyc,rdx,rdy,rdxa,rdya,rdxc,rdyc,cosa,sina,rsina,cosa_u,cosa_v,cosa_s,"
+         "sina_u,sina_v,rsin_u,rsin_v,rsin2,f0,fC,del6_u,del6_v,divg_u,divg_v,"
+         "sin_sg1,sin_sg2,sin_sg3,sin_sg4,sin_sg5,sin_sg6,sin_sg7,sin_sg8,sin_sg9,"
+         "cos_sg1,cos_sg2,cos_sg3,cos_sg4,cos_sg5,cos_sg6,cos_sg7,cos_sg8,cos_sg9";
+}
+
+int fv3lm_create(fv3lm_handle** out, const fv3lm_dims* dm, const fv3lm_options* opt, const double* const* metrics,
+                 double da_min, double da_min_c, const double* phis, const double* ak, const double* bk) {
+  if (!out || !dm || !opt || !metrics) return fail("fv3lm_create: null argument");
+#ifndef FV3LM_HOST_EMUL
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail("fv3lm_create: no HIP device visible (this library has no CPU fallback)");
+#endif
+  fv3lm_handle* h = new fv3lm_handle;
+  if (!h->d.init(dm->nx, dm->ny, dm->npz, dm->ntile, dm->nq, dm->dt, dm->n_split, dm->k_split, *opt, metrics, da_min,
+                 da_min_c, phis)) {
+    std::string e = h->d.err; delete h; return fail("fv3lm_create: " + e);
+  }
+  (void)ak; (void)bk;
+  *out = h;
+  return 0;
+}
+
+int fv3lm_destroy(fv3lm_handle* h) {
+  if (!h) return 0;
+  h->d.destroy(); delete h; return 0;
+}
+
+static bool find(fv3lm_handle* h, const char* name, Fld& f) {
+  auto it = h->d.F.find(name);
+  if (it == h->d.F.end()) { g_err = std::string("unknown field ") + name; return false; }
+  f = it->second; return true;
+}
+int fv3lm_field_levels(fv3lm_handle* h, const char* name) { Fld f; return find(h, name, f) ? f.nk : -1; }
+int fv3lm_field_put(fv3lm_handle* h, const char* name, int which, const double* host) {
+  Fld f; if (!find(h, name, f)) return 1;
+  h2d(h->d.ex, which ? f.p : f.t, host, (size_t)h->d.g.ntile * f.nk * h->d.g.plane * 8);
+  return 0;
+}
+int fv3lm_field_get(fv3lm_handle* h, const char* name, int which, double* host) {
+  Fld f; if (!find(h, name, f)) return 1;
+  d2h(h->d.ex, host, which ? f.p : f.t, (size_t)h->d.g.ntile * f.nk * h->d.g.plane * 8);
+  return 0;
+}
+int fv3lm_run_group(fv3lm_handle* h, const char* group, int mode) {
+  if (mode < 0 || mode > 2) return fail("bad mode");
+  h->d.run_group(h->d.acoustic, group, mode);
+  return 0;
+}
+int fv3lm_dyn_core(fv3lm_handle* h, int mode) {
+  if (mode < 0 || mode > 2) return fail("bad mode");
+  h->d.dyn_core(mode);
+  return 0;
+}
+int fv3lm_zero_work_adjoint(fv3lm_handle* h) { h->d.zero_work_adjoint(); return 0; }
+int fv3lm_sync(fv3lm_handle* h) { dev_sync(h->d.ex); return 0; }
+long fv3lm_launch_count(fv3lm_handle* h) { return h->d.ex.launches; }
+int fv3lm_level_params(fv3lm_handle* h, int k, int* ip, double* rp) {
+  if (k < 1 || k > h->d.g.npz) return fail("level out of range");
+  const LevelParams& l = h->d.lev_host[k - 1];
+  ip[0] = l.hord_mt; ip[1] = l.hord_vt; ip[2] = l.hord_tm; ip[3] = l.hord_dp; ip[4] = l.hord_tr;
+  ip[5] = l.nord; ip[6] = l.nord_v; ip[7] = l.nord_w; ip[8] = l.nord_t; ip[9] = l.nord_v_pert;
+  rp[0] = l.d2_divg; rp[1] = l.damp_vt; rp[2] = l.damp_w; rp[3] = l.damp_t; rp[4] = l.d_con; rp[5] = l.damp_vt_pert;
+  return 0;
+}
+#ifdef FV3LM_HOST_EMUL
+int fv3lm_emul_check_boxes(fv3lm_handle* h, int on) { h->d.ex.check_boxes = on != 0; return 0; }
+#endif
+
+}  // extern "C"

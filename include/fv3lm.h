@@ -1,0 +1,93 @@
+/* fv3lm.h — C-ABI of the MI355X-native FV3 tangent-linear / adjoint dynamical core.
+ *
+ * Drop-in boundary: the body of fv3jedi_lm_dynamics_type%step_tl / %step_ad between the
+ * traj/pert -> FV_Atm copies and the copy back (reference src/dynamics/fv3jedi_lm_dynamics_mod.F90:
+ * step_tl :347-456 calls FV_DYNAMICS_TLM at :421-438; step_ad :460-689 calls FV_DYNAMICS_FWD :507 and
+ * FV_DYNAMICS_BWD :615).  A Fortran host binds these entry points with ISO_C_BINDING
+ * (fortran/fv3lm_hip_mod.F90).
+ *
+ * Conventions: every pointer is a host pointer to fp64 data unless a function says "device".
+ * All functions return 0 on success, nonzero on failure; fv3lm_last_error() gives the message
+ * (the reference has no status returns — it calls mpp_error(FATAL)/exit(1),
+ * src/fv3jedi_lm_mod.F90:93 — the Fortran shim turns a nonzero status into that).
+ *
+ * Field layout ("padded plane"): a 3-D field is [ntile][nk][pj][pi] doubles, i fastest,
+ *   pi = nx + 2*ng + 1, pj = ny + 2*ng + 1, ng = 3 (TOOLS/fv_mp_nlm_mod.F90:67);
+ *   Fortran element (i,j,k), i in isd..ied+1, j in jsd..jed+1 (isd = 1-ng), sits at
+ *   ((k-1)*pj + (j-jsd))*pi + (i-isd).  This one index map holds the A-, C-, D- and corner-
+ *   staggered arrays of the reference (u(isd:ied,jsd:jed+1), v(isd:ied+1,jsd:jed), ...).
+ */
+#ifndef FV3LM_H
+#define FV3LM_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fv3lm_handle fv3lm_handle;
+
+/* fv_flags_type subset (NLM/fv_arrays_nlm.F90:236-506) and fv_flags_pert_type
+ * (TLM/fv_arrays_tlmadm.F90:37-92).  The trajectory-side values are those in force after
+ * run_setup_pert (TLM/fv_control_tlmadm.F90:219-252).  Two sets of physical constants are mixed on
+ * the path: the JEDI set (utils/fv3jedi_lm_const_mod.F90:17-41, passed at
+ * DYN/fv3jedi_lm_dynamics_mod.F90:423-424) and FMS constants_mod — both are runtime inputs. */
+typedef struct fv3lm_options {
+  int hord_mt, hord_vt, hord_tm, hord_dp, hord_tr;
+  int nord, do_vort_damp, n_sponge;
+  int hord_mt_pert, hord_vt_pert, hord_tm_pert, hord_dp_pert, hord_tr_pert;
+  int nord_pert, do_vort_damp_pert, n_sponge_pert, hord_ks_traj, hord_ks_pert;
+  int hord_mt_ks_traj, hord_vt_ks_traj, hord_tm_ks_traj, hord_dp_ks_traj, hord_tr_ks_traj;
+  int hord_mt_ks_pert, hord_vt_ks_pert, hord_tm_ks_pert, hord_dp_ks_pert, hord_tr_ks_pert;
+  int kord_tm, kord_mt, kord_wz, kord_tr;
+  int hydrostatic, pad_;
+  double dddmp, d2_bg, d4_bg, vtdm4, d2_bg_k1, d2_bg_k2, d_con, ke_bg;
+  double dddmp_pert, d2_bg_pert, d4_bg_pert, vtdm4_pert, d2_bg_k1_pert, d2_bg_k2_pert, d2_bg_ks_pert;
+  double akap, cp, zvir, grav_jedi;                          /* JEDI constants */
+  double cp_air, rdgas, rvgas, grav, radius, omega, hlv;     /* FMS constants_mod */
+  double ptop;
+} fv3lm_options;
+
+typedef struct fv3lm_dims {
+  int nx, ny, npz;      /* cells per tile edge (npx-1, npy-1), levels */
+  int ntile;            /* tiles resident on this GPU: 1 = doubly-periodic tile (interior-rank code path) */
+  int nq;               /* tracers (qv, ql, qi, o3: DYN/fv3jedi_lm_dynamics_mod.F90:158-167) */
+  int n_split, k_split; /* acoustic / remap sub-steps (fv_flags_type) */
+  int pad_;
+  double dt;            /* create(self,dt,...) src/fv3jedi_lm_mod.F90:44 */
+} fv3lm_dims;
+
+/* Number and order of the metric planes handed to fv3lm_create (fv_grid_type,
+ * NLM/fv_arrays_nlm.F90:115-234), each [ntile][pj][pi]:
+ *  area rarea rarea_c dx dy dxa dya dxc dyc rdx rdy rdxa rdya rdxc rdyc cosa sina rsina cosa_u cosa_v
+ *  cosa_s sina_u sina_v rsin_u rsin_v rsin2 f0 fC del6_u del6_v divg_u divg_v sin_sg(1..9) cos_sg(1..9) */
+#define FV3LM_NMETRIC 50
+const char* fv3lm_metric_names(void);
+
+/* Replaces fv3jedi_lm_dynamics_type%create (DYN/fv3jedi_lm_dynamics_mod.F90:69-264) for the device
+ * side: uploads metric terms once, resolves the per-level scheme table, allocates device state. */
+int fv3lm_create(fv3lm_handle** h, const fv3lm_dims* dims, const fv3lm_options* opt, const double* const* metrics,
+                 double da_min, double da_min_c, const double* phis, const double* ak, const double* bk);
+int fv3lm_destroy(fv3lm_handle* h);     /* %delete, DYN/fv3jedi_lm_dynamics_mod.F90:693-713 */
+const char* fv3lm_last_error(void);
+
+/* Device-resident named fields (padded-plane layout).  which: 0 = trajectory, 1 = perturbation /
+ * adjoint.  State fields: u v delp pt (+ q1.. for tracers), diagnostics pe peln pk pkz,
+ * accumulators mfx mfy cx cy; every work array of the step is also addressable (tests). */
+int fv3lm_field_put(fv3lm_handle* h, const char* name, int which, const double* host);
+int fv3lm_field_get(fv3lm_handle* h, const char* name, int which, double* host);
+int fv3lm_field_levels(fv3lm_handle* h, const char* name);
+
+/* Execution.  mode: 0 nonlinear, 1 tangent linear, 2 adjoint. */
+int fv3lm_run_group(fv3lm_handle* h, const char* group, int mode);  /* one kernel group of the acoustic step:
+     "c_sw" (C_SW_TLM sw_core_tlm.F90:87), "geopk_c"/"geopk_d" (GEOPK_TLM dyn_core_tlm.F90:4578),
+     "p_grad_c" (:3194), "d_sw" (D_SW_TLM sw_core_tlm.F90:1047), "one_grad_p" (:3867), "halo_*" */
+int fv3lm_dyn_core(fv3lm_handle* h, int mode);   /* DYN_CORE_TLM dyn_core_tlm.F90:93 / DYN_CORE_FWD+BWD dyn_core_adm.F90:115,1686 */
+int fv3lm_zero_work_adjoint(fv3lm_handle* h);
+int fv3lm_sync(fv3lm_handle* h);
+long fv3lm_launch_count(fv3lm_handle* h);
+int fv3lm_level_params(fv3lm_handle* h, int k, int* iparams10, double* rparams6);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,181 @@
+// TEST INFRASTRUCTURE — CPU oracle (see scalar.hpp).
+// Restatement of model_tlmadm/tp_core_tlm.F90: fv_tp_2d (:83-236 / _TLM :2123-2324), xppm
+// (_TLM :2328-2492), yppm (_TLM :2496-2669), deln_flux (:1918-2043 / _TLM :2673-2837),
+// copy_corners (:2046-2118).  Only the schemes the TL/AD code implements are restated:
+// iord/jord in {1, 2, 333} (tp_core_tlm.F90:2393,2431,2441,2467).
+#pragma once
+#include "arrays.hpp"
+
+namespace orc {
+
+static const double ppm_p1 = 7. / 12., ppm_p2 = -1. / 12.;   // tp_core_tlm.F90:57-58 region (p1,p2)
+static const double ppm_c1 = -2. / 14., ppm_c2 = 11. / 14., ppm_c3 = 5. / 14.;
+
+// xppm: 1-D flux in x along rows jfirst..jlast.  c and flux live on is..ie+1.
+// tp_core_tlm.F90:2328-2492.  Interior-rank version: is1=is-1, ie3=ie+2 (:2380-2386).
+template <class T>
+void xppm(Arr2<T>& flux, const Arr2<T>& q, const Arr2<T>& c, int iord, int is, int ie, int jfirst, int jlast,
+          const Bounds& bd, const Grid& g) {
+  assert(!bd.any_edge());
+  assert(iord == 1 || iord == 2 || iord == 333);
+  const int is1 = is - 1, ie3 = ie + 2;
+  std::vector<T> al(ie3 - is1 + 2);
+  auto AL = [&](int i) -> T& { return al[i - is1]; };
+  for (int j = jfirst; j <= jlast; ++j) {
+    for (int i = is1; i <= ie3; ++i)   // :2397-2399
+      AL(i) = ppm_p1 * (q(i - 1, j) + q(i, j)) + ppm_p2 * (q(i - 2, j) + q(i + 1, j));
+    if (iord == 1) {                   // :2431-2440
+      for (int i = is; i <= ie + 1; ++i) flux(i, j) = (val(c(i, j)) > 0.) ? q(i - 1, j) : q(i, j);
+    } else if (iord == 2) {            // :2441-2466
+      for (int i = is; i <= ie + 1; ++i) {
+        T xt = c(i, j);
+        if (val(xt) > 0.) {
+          T qtmp = q(i - 1, j);
+          flux(i, j) = qtmp + (1. - xt) * (AL(i) - qtmp - xt * (AL(i - 1) + AL(i) - (qtmp + qtmp)));
+        } else {
+          T qtmp = q(i, j);
+          flux(i, j) = qtmp + (1. + xt) * (AL(i) - qtmp + xt * (AL(i) + AL(i + 1) - (qtmp + qtmp)));
+        }
+      }
+    } else {                           // iord == 333, :2467-2487
+      for (int i = is; i <= ie + 1; ++i) {
+        T xt = c(i, j);
+        if (val(xt) > 0.)
+          flux(i, j) = (2.0 * q(i, j) + 5.0 * q(i - 1, j) - q(i - 2, j)) / 6.0 - 0.5 * xt * (q(i, j) - q(i - 1, j)) +
+                       xt * xt / 6.0 * (q(i, j) - 2.0 * q(i - 1, j) + q(i - 2, j));
+        else
+          flux(i, j) = (2.0 * q(i - 1, j) + 5.0 * q(i, j) - q(i + 1, j)) / 6.0 - 0.5 * xt * (q(i, j) - q(i - 1, j)) +
+                       xt * xt / 6.0 * (q(i + 1, j) - 2.0 * q(i, j) + q(i - 1, j));
+      }
+    }
+  }
+}
+
+// yppm: 1-D flux in y for columns ifirst..ilast; c and flux on js..je+1.  tp_core_tlm.F90:2496-2669.
+template <class T>
+void yppm(Arr2<T>& flux, const Arr2<T>& q, const Arr2<T>& c, int jord, int ifirst, int ilast, int js, int je,
+          const Bounds& bd, const Grid& g) {
+  assert(!bd.any_edge());
+  assert(jord == 1 || jord == 2 || jord == 333);
+  const int js1 = js - 1, je3 = je + 2;
+  if (jord == 1) {
+    for (int j = js; j <= je + 1; ++j)
+      for (int i = ifirst; i <= ilast; ++i) flux(i, j) = (val(c(i, j)) > 0.) ? q(i, j - 1) : q(i, j);
+    return;
+  }
+  Arr2<T> al(bd);
+  for (int j = js1; j <= je3; ++j)
+    for (int i = ifirst; i <= ilast; ++i)
+      al(i, j) = ppm_p1 * (q(i, j - 1) + q(i, j)) + ppm_p2 * (q(i, j - 2) + q(i, j + 1));
+  if (jord == 2) {
+    for (int j = js; j <= je + 1; ++j)
+      for (int i = ifirst; i <= ilast; ++i) {
+        T xt = c(i, j);
+        if (val(xt) > 0.) {
+          T qtmp = q(i, j - 1);
+          flux(i, j) = qtmp + (1. - xt) * (al(i, j) - qtmp - xt * (al(i, j - 1) + al(i, j) - (qtmp + qtmp)));
+        } else {
+          T qtmp = q(i, j);
+          flux(i, j) = qtmp + (1. + xt) * (al(i, j) - qtmp + xt * (al(i, j) + al(i, j + 1) - (qtmp + qtmp)));
+        }
+      }
+  } else {
+    for (int j = js; j <= je + 1; ++j)
+      for (int i = ifirst; i <= ilast; ++i) {
+        T xt = c(i, j);
+        if (val(xt) > 0.)
+          flux(i, j) = (2.0 * q(i, j) + 5.0 * q(i, j - 1) - q(i, j - 2)) / 6.0 - 0.5 * xt * (q(i, j) - q(i, j - 1)) +
+                       xt * xt / 6.0 * (q(i, j) - 2.0 * q(i, j - 1) + q(i, j - 2));
+        else
+          flux(i, j) = (2.0 * q(i, j - 1) + 5.0 * q(i, j) - q(i, j + 1)) / 6.0 - 0.5 * xt * (q(i, j) - q(i, j - 1)) +
+                       xt * xt / 6.0 * (q(i, j + 1) - 2.0 * q(i, j) + q(i, j - 1));
+      }
+  }
+}
+
+// deln_flux: del-(2*nord+2) damping fluxes added to fx,fy.  tp_core_tlm.F90:1918-2043.
+// mass==nullptr: d2 = damp*q, fluxes added unweighted; else mass-weighted with damp2=0.5*damp.
+template <class T>
+void deln_flux(int nord, const Bounds& bd, double damp, const Arr2<T>& q, Arr2<T>& fx, Arr2<T>& fy, const Grid& g,
+               const Arr2<T>* mass) {
+  assert(!bd.any_edge());  // copy_corners calls are no-ops away from cube corners
+  const int is = bd.is, ie = bd.ie, js = bd.js, je = bd.je;
+  Arr2<T> fx2(bd), fy2(bd), d2(bd);
+  const int i1 = is - 1 - nord, i2 = ie + 1 + nord, j1 = js - 1 - nord, j2 = je + 1 + nord;
+  for (int j = j1; j <= j2; ++j)
+    for (int i = i1; i <= i2; ++i) d2(i, j) = mass ? q(i, j) : damp * q(i, j);
+  for (int j = js - nord; j <= je + nord; ++j)
+    for (int i = is - nord; i <= ie + nord + 1; ++i) fx2(i, j) = g.del6_v(i, j) * (d2(i - 1, j) - d2(i, j));
+  for (int j = js - nord; j <= je + nord + 1; ++j)
+    for (int i = is - nord; i <= ie + nord; ++i) fy2(i, j) = g.del6_u(i, j) * (d2(i, j - 1) - d2(i, j));
+  for (int n = 1; n <= nord; ++n) {
+    const int nt = nord - n;
+    for (int j = js - nt - 1; j <= je + nt + 1; ++j)
+      for (int i = is - nt - 1; i <= ie + nt + 1; ++i)
+        d2(i, j) = (fx2(i, j) - fx2(i + 1, j) + fy2(i, j) - fy2(i, j + 1)) * g.rarea(i, j);
+    for (int j = js - nt; j <= je + nt; ++j)
+      for (int i = is - nt; i <= ie + nt + 1; ++i) fx2(i, j) = g.del6_v(i, j) * (d2(i, j) - d2(i - 1, j));
+    for (int j = js - nt; j <= je + nt + 1; ++j)
+      for (int i = is - nt; i <= ie + nt; ++i) fy2(i, j) = g.del6_u(i, j) * (d2(i, j) - d2(i, j - 1));
+  }
+  if (mass) {
+    const double damp2 = 0.5 * damp;
+    for (int j = js; j <= je; ++j)
+      for (int i = is; i <= ie + 1; ++i) fx(i, j) = fx(i, j) + damp2 * ((*mass)(i - 1, j) + (*mass)(i, j)) * fx2(i, j);
+    for (int j = js; j <= je + 1; ++j)
+      for (int i = is; i <= ie; ++i) fy(i, j) = fy(i, j) + damp2 * ((*mass)(i, j - 1) + (*mass)(i, j)) * fy2(i, j);
+  } else {
+    for (int j = js; j <= je; ++j)
+      for (int i = is; i <= ie + 1; ++i) fx(i, j) = fx(i, j) + fx2(i, j);
+    for (int j = js; j <= je + 1; ++j)
+      for (int i = is; i <= ie; ++i) fy(i, j) = fy(i, j) + fy2(i, j);
+  }
+}
+
+// fv_tp_2d: Lin–Rood 2-D flux-form transport operator.  tp_core_tlm.F90:83-236 (_TLM :2123-2324).
+// mfx/mfy non-null → "transport of pt and tracers" branch; mass+nord+damp_c → mass-weighted damping.
+// nord<0 means "nord/damp_c not present".
+template <class T>
+void fv_tp_2d(const Arr2<T>& q, const Arr2<T>& crx, const Arr2<T>& cry, int hord, Arr2<T>& fx, Arr2<T>& fy,
+              const Arr2<T>& xfx, const Arr2<T>& yfx, const Grid& g, const Bounds& bd, const Arr2<T>& ra_x,
+              const Arr2<T>& ra_y, const Arr2<T>* mfx, const Arr2<T>* mfy, const Arr2<T>* mass, int nord,
+              double damp_c) {
+  const int is = bd.is, ie = bd.ie, js = bd.js, je = bd.je, isd = bd.isd, ied = bd.ied, jsd = bd.jsd, jed = bd.jed;
+  const int ord_in = (hord == 10) ? 8 : hord, ord_ou = hord;
+  Arr2<T> q_i(bd), q_j(bd), fx2(bd), fy2(bd), fyy(bd);
+  // copy_corners(q,2) is a no-op on an interior rank (:2046-2118 only touches cube corners)
+  yppm(fy2, q, cry, ord_in, isd, ied, js, je, bd, g);
+  for (int j = js; j <= je + 1; ++j)
+    for (int i = isd; i <= ied; ++i) fyy(i, j) = yfx(i, j) * fy2(i, j);
+  for (int j = js; j <= je; ++j)
+    for (int i = isd; i <= ied; ++i) q_i(i, j) = (q(i, j) * g.area(i, j) + fyy(i, j) - fyy(i, j + 1)) / ra_y(i, j);
+  xppm(fx, q_i, crx, ord_ou, is, ie, js, je, bd, g);
+  xppm(fx2, q, crx, ord_in, is, ie, jsd, jed, bd, g);
+  for (int j = jsd; j <= jed; ++j) {
+    std::vector<T> fx1(ie + 2 - is + 1);
+    for (int i = is; i <= ie + 1; ++i) fx1[i - is] = xfx(i, j) * fx2(i, j);
+    for (int i = is; i <= ie; ++i) q_j(i, j) = (q(i, j) * g.area(i, j) + fx1[i - is] - fx1[i + 1 - is]) / ra_x(i, j);
+  }
+  yppm(fy, q_j, cry, ord_ou, is, ie, js, je, bd, g);
+  if (mfx && mfy) {
+    for (int j = js; j <= je; ++j)
+      for (int i = is; i <= ie + 1; ++i) fx(i, j) = 0.5 * (fx(i, j) + fx2(i, j)) * (*mfx)(i, j);
+    for (int j = js; j <= je + 1; ++j)
+      for (int i = is; i <= ie; ++i) fy(i, j) = 0.5 * (fy(i, j) + fy2(i, j)) * (*mfy)(i, j);
+    if (nord >= 0 && mass && damp_c > 1.e-4) {
+      double damp = std::pow(damp_c * g.da_min, nord + 1);
+      deln_flux(nord, bd, damp, q, fx, fy, g, mass);
+    }
+  } else {
+    for (int j = js; j <= je; ++j)
+      for (int i = is; i <= ie + 1; ++i) fx(i, j) = 0.5 * (fx(i, j) + fx2(i, j)) * xfx(i, j);
+    for (int j = js; j <= je + 1; ++j)
+      for (int i = is; i <= ie; ++i) fy(i, j) = 0.5 * (fy(i, j) + fy2(i, j)) * yfx(i, j);
+    if (nord >= 0 && damp_c > 1.e-4) {
+      double damp = std::pow(damp_c * g.da_min, nord + 1);
+      deln_flux<T>(nord, bd, damp, q, fx, fy, g, nullptr);
+    }
+  }
+}
+
+}  // namespace orc

@@ -1,0 +1,69 @@
+"""Shared case builder for the parity tests: one synthetic tile, the oracle and a product instance
+(HIP library on the GPU box, or the test-only host-emulation build of the same stage code)."""
+import os
+import subprocess
+import numpy as np
+import fv3_jedi_linearmodel_amd as fv3
+from fv3_jedi_linearmodel_amd._lib import Fv3LmLibrary, Dycore
+from fv3_jedi_linearmodel_amd import grid as G
+from oracle import Oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMUL_SO = os.path.join(ROOT, "tests", "_emul", "libfv3lm_emul.so")
+CSRC = os.path.join(ROOT, "fv3_jedi_linearmodel_amd", "csrc")
+
+
+def build_emul():
+    """g++ build of the product's stage code with -DFV3LM_HOST_EMUL (tests only)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "fv3lm.h")]
+    if os.path.exists(EMUL_SO) and all(os.path.getmtime(EMUL_SO) >= os.path.getmtime(s) for s in srcs):
+        return EMUL_SO
+    os.makedirs(os.path.dirname(EMUL_SO), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-DFV3LM_HOST_EMUL", "-shared", "-o", EMUL_SO,
+                           os.path.join(CSRC, "fv3lm_capi.cpp")])
+    return EMUL_SO
+
+
+class Case:
+    def __init__(self, nx=12, ny=12, npz=8, n_split=2, k_split=1, dt=1800.0, backend="emul", seed=20250114, **optkw):
+        self.nx, self.ny, self.npz = nx, ny, npz
+        self.opt = fv3.default_options(**optkw)
+        self.metrics, self.da_min, self.da_min_c = fv3.synthetic_tile_metrics(nx, ny)
+        self.traj, self.phis, self.ak, self.bk = G.synthetic_state(nx, ny, npz, self.opt, seed=seed)
+        self.pert = G.synthetic_pert(nx, ny, npz, seed=seed + 1)
+        for d in (self.traj, self.pert):
+            for k in d:
+                d[k] = G.halo_fill_periodic(d[k], nx, ny)
+        self.phis = G.halo_fill_periodic(self.phis, nx, ny)
+        self.dims = fv3.Dims(nx=nx, ny=ny, npz=npz, ntile=1, nq=0, n_split=n_split, k_split=k_split, dt=dt)
+        self.dt_ac = dt / n_split / k_split
+        self.oracle = Oracle(nx, ny, npz, 0, self.metrics, self.opt, self.da_min, self.da_min_c, self.phis, self.ak, self.bk)
+        if backend == "emul":
+            self.lib = Fv3LmLibrary(build_emul())
+            self.lib.L.fv3lm_emul_check_boxes.argtypes = [__import__("ctypes").c_void_p, __import__("ctypes").c_int]
+        else:
+            self.lib = fv3.load_hip_library()
+        self.dy = Dycore(self.lib, self.dims, self.opt, self.metrics, self.da_min, self.da_min_c, self.phis, self.ak, self.bk)
+        if backend == "emul":
+            self.lib.L.fv3lm_emul_check_boxes(self.dy.h, 1)
+
+    # helpers -------------------------------------------------------------------------------
+    def put_state(self, traj=None, pert=None):
+        traj = traj or self.traj
+        for n in ("u", "v", "delp", "pt"):
+            self.dy.put(n, traj[n], 0)
+            if pert is not None:
+                self.dy.put(n, pert[n], 1)
+
+    def rect(self, i0, i1, j0, j1):
+        """numpy slices of the padded plane for Fortran index ranges i0..i1, j0..j1."""
+        return (Ellipsis, slice(j0 + 2, j1 + 3), slice(i0 + 2, i1 + 3))
+
+    def rng_field(self, nk, seed, amp=1.0):
+        rng = np.random.default_rng(seed)
+        return amp * rng.standard_normal((1, nk, self.ny + 7, self.nx + 7))
+
+
+def relerr(a, b):
+    s = np.max(np.abs(b))
+    return float(np.max(np.abs(a - b)) / (s if s > 0 else 1.0))
