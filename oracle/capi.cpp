@@ -239,6 +239,18 @@ void orc_one_grad_p(void* hv, int mode, double dt, double** in_t, double** in_p,
   });
 }
 
+// compute_fv3_pressures (fv_pressure.F90:23-72 / _tlm :74-135 / _bwd :137-203).
+// in: delp (npz)   out: pe (npz+1), pk (npz+1), pkz (npz), peln (npz+1)
+void orc_fv_pressures(void* hv, int mode, double kappa, double ptop, double** in_t, double** in_p, double** out_t,
+                      double** out_p) {
+  OrcHandle* h = (OrcHandle*)hv; int npz = h->npz;
+  int nk[1] = {npz}, nko[4] = {npz + 1, npz + 1, npz, npz + 1};
+  auto in = mkio(1, in_t, in_p, nk); auto out = mkio(4, out_t, out_p, nko);
+  drive(mode, h->bd, in, out, [&](auto& x, auto& y) {
+    compute_fv3_pressures(h->bd, npz, kappa, ptop, x[0], y[0], y[1], y[2], y[3]);
+  });
+}
+
 // dyn_core (n_split acoustic steps).  in: u, v, pt, delp   out: u, v, pt, delp, mfx, mfy, cx, cy, pe, peln, pk, pkz
 void orc_dyn_core(void* hv, int mode, double bdt, int n_split, double** in_t, double** in_p, double** out_t,
                   double** out_p) {

@@ -25,7 +25,7 @@ def build_emul():
 
 
 class Case:
-    def __init__(self, nx=12, ny=12, npz=8, n_split=2, k_split=1, dt=1800.0, backend="emul", seed=20250114, **optkw):
+    def __init__(self, nx=12, ny=12, npz=8, n_split=2, k_split=1, dt=1800.0, backend="emul", seed=20250114, oracle=True, **optkw):
         self.nx, self.ny, self.npz = nx, ny, npz
         self.opt = fv3.default_options(**optkw)
         self.metrics, self.da_min, self.da_min_c = fv3.synthetic_tile_metrics(nx, ny)
@@ -37,7 +37,7 @@ class Case:
         self.phis = G.halo_fill_periodic(self.phis, nx, ny)
         self.dims = fv3.Dims(nx=nx, ny=ny, npz=npz, ntile=1, nq=0, n_split=n_split, k_split=k_split, dt=dt)
         self.dt_ac = dt / n_split / k_split
-        self.oracle = Oracle(nx, ny, npz, 0, self.metrics, self.opt, self.da_min, self.da_min_c, self.phis, self.ak, self.bk)
+        self.oracle = Oracle(nx, ny, npz, 0, self.metrics, self.opt, self.da_min, self.da_min_c, self.phis, self.ak, self.bk) if oracle else None
         if backend == "emul":
             self.lib = Fv3LmLibrary(build_emul())
             self.lib.L.fv3lm_emul_check_boxes.argtypes = [__import__("ctypes").c_void_p, __import__("ctypes").c_int]

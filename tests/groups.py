@@ -1,0 +1,192 @@
+"""Kernel-group tables shared by the emulation (CPU) and GPU parity tests: for each group of the
+acoustic step the product field names, the oracle entry point and the index ranges that carry
+defined data (Fortran index ranges of the reference routines, cited in oracle/*.hpp)."""
+import numpy as np
+from oracle import NL, TL, AD
+from common import relerr
+
+
+def rects(c):
+    nx, ny = c.nx, c.ny
+    isd, ied, jsd, jed = -2, nx + 3, -2, ny + 3
+    full = (isd, ied + 1, jsd, jed + 1)
+    return dict(
+        A=(1, nx, 1, ny), Ah=(0, nx + 1, 0, ny + 1), Ah2=(-1, nx + 2, -1, ny + 2),
+        U=(1, nx, 1, ny + 1), V=(1, nx + 1, 1, ny), B=(1, nx + 1, 1, ny + 1),
+        CX=(1, nx + 1, jsd, jed), CY=(isd, ied, 1, ny + 1), UTF=(0, nx + 2, 0, ny + 1), VTF=(0, nx + 1, 0, ny + 2),
+        full=full)
+
+
+# group -> (oracle method, scalar maker, [(oracle-in order) product field], [(product out field, rect key)])
+def table(c):
+    dt = c.dt_ac
+    return {
+        "c_sw": ("c_sw", lambda: (0.5 * dt,), ["delp", "pt", "u", "v"],
+                 [("delpc", "Ah"), ("ptc", "Ah"), ("uc1", "V"), ("vc1", "U"), ("ua", "Ah"), ("va", "Ah"), ("utf", "UTF"),
+                  ("vtf", "VTF"), ("divgd", "B")]),
+        "geopk_c": ("geopk", lambda: (1,), ["delpc", "ptc"],
+                    [("pe_c", "Ah"), ("peln_c", "A"), ("pkc", "Ah"), ("gz", "Ah"), (None, None)]),
+        "p_grad_c": ("p_grad_c", lambda: (0.5 * dt,), ["pkc", "gz", "uc1", "vc1"], [("uc", "V"), ("vc", "U")]),
+        "d_sw": ("d_sw", lambda: (dt,), ["delp", "pt", "u", "v", "uc", "vc", "ua", "va", "divgd", "mfx", "mfy", "cx", "cy"],
+                 [("delp_o", "A"), ("pt_o", "A"), ("u_m", "U"), ("v_m", "V"), ("mfx", "V"), ("mfy", "U"), ("cx", "CX"),
+                  ("cy", "CY"), ("crx", "CX"), ("cry", "CY"), ("xfx", "CX"), ("yfx", "CY")]),
+        "geopk_d": ("geopk", lambda: (0,), ["delp_o", "pt_o"],
+                    [("pe", "Ah"), ("peln", "A"), ("pk", "Ah2"), ("gzd", "Ah2"), ("pkz", "A")]),
+        "one_grad_p": ("one_grad_p", lambda: (dt,), ["u_m", "v_m", "pk", "gzd"], [("u_o", "U"), ("v_o", "V")]),
+    }
+
+
+def masked(c, arr, rkey):
+    out = np.zeros_like(arr)
+    r = c.rect(*rects(c)[rkey])
+    out[r] = arr[r]
+    return out
+
+
+def make_inputs(c, group, seed=7):
+    """Physically plausible inputs of a group = outputs of the preceding groups run by the oracle
+    (NL+TL), halo-filled where the reference would have exchanged them."""
+    from fv3_jedi_linearmodel_amd.grid import halo_fill_periodic as hf
+    nx, ny, dt = c.nx, c.ny, c.dt_ac
+    T = {n: c.traj[n][0] for n in ("delp", "pt", "u", "v")}
+    P = {n: c.pert[n][0] for n in ("delp", "pt", "u", "v")}
+    if group == "c_sw":
+        return T, P
+    ot, op = c.oracle.c_sw(TL, 0.5 * dt, [T[n] for n in ("delp", "pt", "u", "v")], [P[n] for n in ("delp", "pt", "u", "v")])
+    for n, a, b in zip(["delpc", "ptc", "uc1", "vc1", "ua", "va", "utf", "vtf", "divgd"], ot, op):
+        T[n], P[n] = a, b
+    T["divgd"], P["divgd"] = hf(T["divgd"], nx, ny), hf(P["divgd"], nx, ny)
+    if group == "geopk_c":
+        return T, P
+    ot, op = c.oracle.geopk(TL, 1, [T["delpc"], T["ptc"]], [P["delpc"], P["ptc"]])
+    T["pkc"], P["pkc"], T["gz"], P["gz"] = ot[2], op[2], ot[3], op[3]
+    if group == "p_grad_c":
+        return T, P
+    ot, op = c.oracle.p_grad_c(TL, 0.5 * dt, [T["pkc"], T["gz"], T["uc1"], T["vc1"]], [P["pkc"], P["gz"], P["uc1"], P["vc1"]])
+    T["uc"], P["uc"], T["vc"], P["vc"] = hf(ot[0], nx, ny), hf(op[0], nx, ny), hf(ot[1], nx, ny), hf(op[1], nx, ny)
+    rng = np.random.default_rng(seed)
+    for n in ("mfx", "mfy", "cx", "cy"):
+        T[n] = rng.standard_normal(T["u"].shape); P[n] = rng.standard_normal(T["u"].shape)
+    if group == "d_sw":
+        return T, P
+    names = ["delp", "pt", "u", "v", "uc", "vc", "ua", "va", "divgd", "mfx", "mfy", "cx", "cy"]
+    ot, op = c.oracle.d_sw(TL, dt, [T[n] for n in names], [P[n] for n in names])
+    for n, a, b in zip(["delp_o", "pt_o", "u_m", "v_m"], ot[:4], op[:4]):
+        T[n], P[n] = a, b
+    for n in ("delp_o", "pt_o"):
+        T[n], P[n] = hf(T[n], nx, ny), hf(P[n], nx, ny)
+    if group == "geopk_d":
+        return T, P
+    ot, op = c.oracle.geopk(TL, 0, [T["delp_o"], T["pt_o"]], [P["delp_o"], P["pt_o"]])
+    T["pk"], P["pk"], T["gzd"], P["gzd"] = ot[2], op[2], ot[3], op[3]
+    return T, P
+
+
+def check_group(c, group, mode, tol):
+    meth, scal, ins, outs = table(c)[group]
+    T, P = make_inputs(c, group)
+    fn = getattr(c.oracle, meth)
+    i_t = [T[n] for n in ins]; i_p = [P[n] for n in ins]
+    if mode == TL:
+        ot, op = fn(TL, *scal(), i_t, i_p)
+        for n in ins:
+            c.dy.put(n, T[n][None], 0); c.dy.put(n, P[n][None], 1)
+        c.dy.run_group(group, TL)
+        worst = 0.0
+        for (n, rk), a, b in zip(outs, ot, op):
+            if n is None:
+                continue
+            r = c.rect(*rects(c)[rk])
+            e1, e2 = relerr(c.dy.get(n, 0)[0][r], a[r]), relerr(c.dy.get(n, 1)[0][r], b[r])
+            assert e1 < tol, (group, n, "traj", e1)
+            assert e2 < tol, (group, n, "tl", e2)
+            worst = max(worst, e1, e2)
+        return worst
+    # adjoint: random output adjoints on the defined ranges
+    rng = np.random.default_rng(11)
+    nks = {n: c.dy.levels(n) for n, _ in outs if n}
+    seeds = []
+    for n, rk in outs:
+        if n is None:
+            seeds.append(np.zeros((c.npz, c.ny + 7, c.nx + 7)))
+        else:
+            seeds.append(masked(c, rng.standard_normal((nks[n], c.ny + 7, c.nx + 7)), rk))
+    _, iad = fn(AD, *scal(), i_t, None, seeds)
+    for n in ins:
+        c.dy.put(n, T[n][None], 0)
+    c.dy.run_group(group, NL)
+    c.dy.zero_work_adjoint()
+    for n in set(ins) | {o for o, _ in outs if o}:
+        c.dy.put(n, np.zeros(c.dy.shape(n)), 1)
+    for (n, rk), s in zip(outs, seeds):
+        if n:
+            c.dy.put(n, s[None], 1)
+    c.dy.run_group(group, AD)
+    worst = 0.0
+    for n, a in zip(ins, iad):
+        got = c.dy.get(n, 1)[0]
+        if n in [o for o, _ in outs]:      # accumulators: in-place, adjoint passes through
+            pass
+        e = relerr(got, a)
+        assert e < tol, (group, n, "ad", e)
+        worst = max(worst, e)
+    return worst
+
+
+DC_OUT = [("u", "full"), ("v", "full"), ("pt", "full"), ("delp", "full"), ("mfx", "V"), ("mfy", "U"), ("cx", "CX"),
+          ("cy", "CY"), ("pe", "Ah"), ("peln", "A"), ("pk", "A"), ("pkz", "A")]
+
+
+def check_dyn_core(c, mode, tol):
+    """n_split acoustic steps: product fv3lm_dyn_core vs oracle orc_dyn_core (DYN_CORE_TLM /
+    DYN_CORE_FWD+BWD)."""
+    ins = ["u", "v", "pt", "delp"]
+    i_t = [c.traj[n][0] for n in ins]; i_p = [c.pert[n][0] for n in ins]
+    bdt, ns = c.dims.dt / c.dims.k_split, c.dims.n_split
+    if mode == TL:
+        ot, op = c.oracle.dyn_core(TL, bdt, ns, i_t, i_p)
+        c.put_state(pert=c.pert)
+        c.dy.dyn_core(TL)
+        worst = 0.0
+        for (n, rk), a, b in zip(DC_OUT, ot, op):
+            r = c.rect(*rects(c)[rk])
+            e1, e2 = relerr(c.dy.get(n, 0)[0][r], a[r]), relerr(c.dy.get(n, 1)[0][r], b[r])
+            assert e1 < tol, (n, "traj", e1)
+            assert e2 < tol, (n, "tl", e2)
+            worst = max(worst, e1, e2)
+        return worst
+    rng = np.random.default_rng(5)
+    seeds = [masked(c, rng.standard_normal((c.dy.levels(n), c.ny + 7, c.nx + 7)), rk) for n, rk in DC_OUT]
+    _, iad = c.oracle.dyn_core(AD, bdt, ns, i_t, None, seeds)
+    c.put_state()
+    c.dy.dyn_core(NL)            # forward sweep: stores the per-step checkpoints
+    for (n, rk), s in zip(DC_OUT, seeds):
+        c.dy.put(n, s[None], 1)
+    c.dy.dyn_core(AD)
+    worst = 0.0
+    for n, a in zip(ins, iad):
+        e = relerr(c.dy.get(n, 1)[0], a)
+        assert e < tol, (n, "ad", e)
+        worst = max(worst, e)
+    return worst
+
+
+def dot_product_test(c, seed=3):
+    """<M dx, dy> = <dx, M^T dy> for the n_split-step dyn_core operator (the JEDI LinearModel test)."""
+    rng = np.random.default_rng(seed)
+    ins = ["u", "v", "pt", "delp"]
+    outs = [("u", "U"), ("v", "V"), ("pt", "A"), ("delp", "A")]
+    c.put_state(pert=c.pert)
+    c.dy.dyn_core(TL)
+    Mdx = {n: c.dy.get(n, 1)[0] for n, _ in outs}
+    dy = {n: masked(c, rng.standard_normal(Mdx[n].shape), rk) for n, rk in outs}
+    lhs = sum(float(np.sum(Mdx[n] * dy[n])) for n, _ in outs)
+    c.put_state()
+    c.dy.dyn_core(NL)
+    for n in ("mfx", "mfy", "cx", "cy", "pe", "peln", "pk", "pkz"):
+        c.dy.put(n, np.zeros(c.dy.shape(n)), 1)
+    for n, _ in outs:
+        c.dy.put(n, dy[n][None], 1)
+    c.dy.dyn_core(AD)
+    rhs = sum(float(np.sum(c.dy.get(n, 1)[0] * c.pert[n][0])) for n in ins)
+    return lhs, rhs

@@ -37,3 +37,34 @@ def test_c_sw_tl(case):
         r = c.rect(*rects[n])
         assert relerr(pt_[n][r], a[r]) < TOL, n
         assert relerr(pp_[n][r], b[r]) < TOL, n + "_tl"
+
+
+from groups import check_group
+
+GROUPS = ["c_sw", "geopk_c", "p_grad_c", "d_sw", "geopk_d", "one_grad_p"]
+
+
+@pytest.mark.parametrize("group", GROUPS)
+def test_group_tl(case, group):
+    check_group(case, group, TL, TOL)
+
+
+@pytest.mark.parametrize("group", GROUPS)
+def test_group_ad(case, group):
+    check_group(case, group, AD, 1e-11)
+
+
+from groups import check_dyn_core, dot_product_test
+
+
+def test_dyn_core_tl(case):
+    check_dyn_core(case, TL, 1e-10)      # full-step tolerance, BASELINE.md §6
+
+
+def test_dyn_core_ad(case):
+    check_dyn_core(case, AD, 1e-10)
+
+
+def test_dot_product(case):
+    lhs, rhs = dot_product_test(case)
+    assert abs(lhs - rhs) <= 1e-12 * abs(lhs), (lhs, rhs)
