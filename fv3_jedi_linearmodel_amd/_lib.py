@@ -39,6 +39,11 @@ class Fv3LmLibrary:
         L.fv3lm_launch_count.argtypes = [C.c_void_p]
         L.fv3lm_launch_count.restype = C.c_long
         L.fv3lm_level_params.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), _dp]
+        for fn in ("fv3lm_pressures", "fv3lm_tracer_2d", "fv3lm_fv_dynamics"):
+            getattr(L, fn).argtypes = [C.c_void_p, C.c_int]
+        L.fv3lm_remap.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        for fn in ("fv3lm_step_tl", "fv3lm_step_nl", "fv3lm_step_ad"):
+            getattr(L, fn).argtypes = [C.c_void_p]
 
     def err(self):
         return self.L.fv3lm_last_error().decode()
@@ -119,6 +124,34 @@ class Dycore:
     def dyn_core(self, mode):
         if self.lib.L.fv3lm_dyn_core(self.h, mode) != 0:
             raise Fv3LmError(self.lib.err())
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise Fv3LmError(self.lib.err())
+
+    def pressures(self, mode):
+        self._chk(self.lib.L.fv3lm_pressures(self.h, mode))
+
+    def tracer_2d(self, mode):
+        self._chk(self.lib.L.fv3lm_tracer_2d(self.h, mode))
+
+    def remap(self, mode, last_step):
+        self._chk(self.lib.L.fv3lm_remap(self.h, mode, int(last_step)))
+
+    def fv_dynamics(self, mode):
+        self._chk(self.lib.L.fv3lm_fv_dynamics(self.h, mode))
+
+    def step_tl(self):
+        """fv3jedi_lm_dynamics_type%step_tl (DYN/fv3jedi_lm_dynamics_mod.F90:347-456), device part."""
+        self._chk(self.lib.L.fv3lm_step_tl(self.h))
+
+    def step_nl(self):
+        self._chk(self.lib.L.fv3lm_step_nl(self.h))
+
+    def step_ad(self):
+        """%step_ad (DYN/fv3jedi_lm_dynamics_mod.F90:460-689): call after step_nl() (the FV_DYNAMICS_FWD
+        role: nonlinear sweep storing the stage checkpoints)."""
+        self._chk(self.lib.L.fv3lm_step_ad(self.h))
 
     def zero_work_adjoint(self):
         self.lib.L.fv3lm_zero_work_adjoint(self.h)

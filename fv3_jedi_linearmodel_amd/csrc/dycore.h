@@ -126,6 +126,7 @@ struct Dycore {
   std::map<std::string, Fld> F;       // field registry (debug/test access + driver)
   Program acoustic;                   // one acoustic step
   double* ckpt = nullptr;             // [n_split*k_split][4][field3]
+  int ck_base = 0;                    // first acoustic-step slot of the current k_split iteration
   size_t n3 = 0, n3p = 0;             // doubles per npz / npz+1 field
   std::string err;
 
@@ -251,7 +252,7 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int nq_, double bdt
   if (phis_host) h2d(ex, hs_dev, phis_host, np * 8);
   ctx.g = g; ctx.lev = lev_dev; ctx.nlev = npz;
   n3 = np * npz; n3p = np * (npz + 1);
-  state.init(n3 * (16 + 2 * (size_t)nq) + n3p * 4);
+  state.init(n3 * (20 + 3 * (size_t)nq) + n3p * 8);
   work.init(n3 * 110 + n3p * 14);
   build_acoustic();
   ckpt = (double*)dev_alloc((size_t)n_split * k_split * 4 * n3 * 8);
@@ -373,7 +374,7 @@ inline void Dycore::dyn_core(int mode) {
     for (const char* a : {"mfx", "mfy", "cx", "cy"}) { dev_zero(ex, f(a).t, b3); if (mode == MODE_TL) dev_zero(ex, f(a).p, b3); }
     for (int it = 0; it < n_split; ++it) {
       if (mode == MODE_NL)
-        for (int n = 0; n < 4; ++n) dev_copy(ex, ckpt + ((size_t)it * 4 + n) * n3, f(names[n]).t, b3);
+        for (int n = 0; n < 4; ++n) dev_copy(ex, ckpt + ((size_t)(ck_base + it) * 4 + n) * n3, f(names[n]).t, b3);
       run_group(acoustic, nullptr, mode);
       for (int n = 0; n < 4; ++n) {
         dev_copy(ex, f(names[n]).t, f(onames[n]).t, b3);
@@ -383,7 +384,7 @@ inline void Dycore::dyn_core(int mode) {
   } else {
     // incoming adjoint lives in the input-named buffers; move it to the *_o side of the last step
     for (int it = n_split - 1; it >= 0; --it) {
-      for (int n = 0; n < 4; ++n) dev_copy(ex, f(names[n]).t, ckpt + ((size_t)it * 4 + n) * n3, b3);
+      for (int n = 0; n < 4; ++n) dev_copy(ex, f(names[n]).t, ckpt + ((size_t)(ck_base + it) * 4 + n) * n3, b3);
       // recompute this step's nonlinear intermediates (flux capacitors left alone)
       run_group(acoustic, nullptr, MODE_NL, true);
       zero_work_adjoint();

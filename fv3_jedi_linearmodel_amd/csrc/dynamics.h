@@ -1,0 +1,268 @@
+// fv3lm-hip: fv_dynamics level — FV_DYNAMICS_TLM (fv_dynamics_tlm.F90:87-995) and
+// FV_DYNAMICS_FWD/BWD (fv_dynamics_adm.F90:110/874): pt conversion, the k_split loop
+// {halo, dyn_core, tracer_2d, Lagrangian-to-Eulerian remap}, and the step_tl / step_ad entry points
+// with the pressure diagnostics of fv_pressure.F90 on the device.
+#pragma once
+#include "dycore.h"
+#include "remap.h"
+
+namespace fv3 {
+
+// compute_fv3_pressures{,_tlm,_bwd} (model_tlmadm/fv_pressure.F90:23-203) on is..ie, js..je
+struct PressArgs { Geom g; Fld delp, pe, peln, pk, pkz; double kappa, ptop; };
+template <class T>
+HD void press_col(const PressArgs& a, int i, int j, int tile) {
+  const Geom& g = a.g; const int km = g.npz; typedef FIO<T> IO;
+  T pe = T(a.ptop), ln0 = dlog(pe), pk0 = dexp(a.kappa * ln0);
+  IO::st(a.pe, fidx(g, a.pe, tile, i, j, 1), pe); IO::st(a.peln, fidx(g, a.peln, tile, i, j, 1), ln0); IO::st(a.pk, fidx(g, a.pk, tile, i, j, 1), pk0);
+  for (int k = 1; k <= km; ++k) {
+    pe = pe + IO::ld(a.delp, fidx(g, a.delp, tile, i, j, k));
+    T ln1 = dlog(pe), pk1 = dexp(a.kappa * ln1);
+    const size_t m = fidx(g, a.pe, tile, i, j, k + 1);
+    IO::st(a.pe, m, pe); IO::st(a.peln, m, ln1); IO::st(a.pk, m, pk1);
+    IO::st(a.pkz, fidx(g, a.pkz, tile, i, j, k), (pk1 - pk0) / (a.kappa * (ln1 - ln0)));
+    ln0 = ln1; pk0 = pk1;
+  }
+}
+HD void press_col_ad(const PressArgs& a, int i, int j, int tile) {   // fv_pressure.F90:137-203
+  const Geom& g = a.g; const int km = g.npz;
+  for (int k = km; k >= 1; --k) {
+    const size_t n0 = fidx(g, a.pkz, tile, i, j, k), m0 = fidx(g, a.pe, tile, i, j, k), m1 = fidx(g, a.pe, tile, i, j, k + 1);
+    const double t1 = a.kappa * (a.peln.t[m1] - a.peln.t[m0]);
+    const double ad1 = a.pkz.p[n0] / t1, ad2 = -((a.pk.t[m1] - a.pk.t[m0]) * a.kappa * ad1 / t1);
+    a.pk.p[m1] += ad1; a.pk.p[m0] -= ad1; a.peln.p[m1] += ad2; a.peln.p[m0] -= ad2; a.pkz.p[n0] = 0.;
+  }
+  double carry = 0.;
+  for (int k = km + 1; k >= 1; --k) {
+    const size_t m = fidx(g, a.pe, tile, i, j, k);
+    const double ln_ad = a.peln.p[m] + a.pk.t[m] * a.kappa * a.pk.p[m];
+    const double pe_ad = a.pe.p[m] + ln_ad / a.pe.t[m] + carry;
+    a.pk.p[m] = 0.; a.peln.p[m] = 0.; a.pe.p[m] = 0.;
+    if (k >= 2) { a.delp.p[fidx(g, a.delp, tile, i, j, k - 1)] += pe_ad; carry = pe_ad; }
+  }
+}
+struct PressFn {
+  PressArgs a; int mode;
+  HD void operator()(int i, int j, int z) const {
+    if (mode == MODE_NL) press_col<double>(a, i, j, z);
+    else if (mode == MODE_TL) press_col<Dual>(a, i, j, z);
+    else press_col_ad(a, i, j, z);
+  }
+};
+
+// max Courant number per level (fv_tracer2d_tlm.F90:1248-1305); trajectory only.
+struct CmaxFn {
+  Geom g; Fld cx, cy; const double* sin5; double* out;   // out[ntile*npz]
+  HD void operator()(int, int, int z) const {              // one thread per (tile, level): tiny reduction
+    const int tile = z / g.npz, k = 1 + z % g.npz;
+    double cm = 0.;
+    for (int j = 1; j <= g.ny; ++j)
+      for (int i = 1; i <= g.nx; ++i) {
+        const size_t n = (size_t)z * g.plane + g.idx(i, j);
+        double ax = fabs(cx.t[n]), ay = fabs(cy.t[n]);
+        double c = ax > ay ? ax : ay;
+        if (!(k < g.npz / 6)) c += 1. - sin5[(size_t)tile * g.plane + g.idx(i, j)];
+        if (cm < c) cm = c;
+      }
+    out[z] = cm;
+  }
+};
+
+struct Dynamics : Dycore {
+  Arena tshared, twork;
+  Program tracer_pre, tracer_q, pt_in;
+  std::vector<Fld> q;
+  Fld dp1, qc, qc_o, pe2, pu_ad, pv_ad;
+  double *ak_dev = nullptr, *bk_dev = nullptr, *remap_ws = nullptr, *cmax_dev = nullptr;
+  double* ck_k = nullptr;      // per-k_split checkpoints
+  double* ck_0 = nullptr;      // initial T and pkz
+  size_t ck_k_stride = 0;
+  int nsplt_max = 1;
+  bool tracer_subcycle_error = false;
+
+  bool init2(const double* ak, const double* bk);
+  void destroy2();
+  void build_tracer();
+  RemapArgs remap_args(bool last_step);
+  void pressures(int mode);
+  void tracer_fwd(int mode);
+  void tracer_ad();
+  void fv_dynamics(int mode);
+  void step_tl() { pressures(MODE_TL); fv_dynamics(MODE_TL); }
+  void step_nl() { pressures(MODE_NL); fv_dynamics(MODE_NL); }
+  // after step_nl() has stored the checkpoints.  The backward sweep leaves the initial delp trajectory
+  // in place (first acoustic checkpoint), from which the initial pressures are recomputed.
+  void step_ad() { fv_dynamics(MODE_AD); pressures(MODE_NL); pressures(MODE_AD); }
+
+  double* ckq(int km, int n) { return ck_k + (size_t)km * ck_k_stride + (size_t)n * n3; }                       // q before tracer
+  double* ckm(int km, int n) { return ck_k + (size_t)km * ck_k_stride + (size_t)(nq + n) * n3; }                // mfx mfy cx cy
+  double* ckr3(int km, int n) { return ck_k + (size_t)km * ck_k_stride + (size_t)(nq + 4 + n) * n3; }           // pt u v q'[nq]
+  double* ckrp(int km, int n) { return ck_k + (size_t)km * ck_k_stride + (size_t)(2 * nq + 7) * n3 + (size_t)n * n3p; }  // pe peln pk
+};
+
+inline bool Dynamics::init2(const double* ak, const double* bk) {
+  const int npz = g.npz;
+  if (nq > 8) { err = "at most 8 tracers"; return false; }
+  ak_dev = (double*)dev_alloc((npz + 1) * 8); bk_dev = (double*)dev_alloc((npz + 1) * 8);
+  if (ak) h2d(ex, ak_dev, ak, (npz + 1) * 8);
+  if (bk) h2d(ex, bk_dev, bk, (npz + 1) * 8);
+  for (int n = 0; n < nq; ++n) { char nm[16]; std::snprintf(nm, sizeof nm, "q%d", n + 1); q.push_back(S(nm, npz)); }
+  dp1 = S("dp1", npz); qc = S("qc", npz); qc_o = S("qc_o", npz);
+  pe2 = S("pe2", npz + 1); pu_ad = S("pu_ad", npz + 1); pv_ad = S("pv_ad", npz + 1);
+  remap_ws = (double*)dev_alloc((size_t)REMAP_WS_SLOTS * (npz + 2) * g.ntile * g.plane * 8);
+  cmax_dev = (double*)dev_alloc((size_t)g.ntile * npz * 8);
+  tshared.init(n3 * 6); twork.init(n3 * 10);
+  build_tracer();
+  { DynPtIn s; s.in[0] = f("pt"); s.in[1] = nq > 0 ? q[0] : Fld{}; if (!s.in[1].t) s.in[1].nk = npz; s.in[2] = f("pkz"); s.out[0] = f("pt_o");
+    s.orect[0] = R(1, g.nx, 1, g.ny); s.k1 = npz; s.zvir = opt.zvir; s.has_q = nq > 0; add(pt_in, "pt_in", s); }
+  ck_k_stride = (size_t)(2 * nq + 7) * n3 + 3 * n3p;
+  ck_k = (double*)dev_alloc(ck_k_stride * k_split * 8);
+  ck_0 = (double*)dev_alloc(2 * n3 * 8);
+  return true;
+}
+inline void Dynamics::destroy2() {
+  dev_free(ak_dev); dev_free(bk_dev); dev_free(remap_ws); dev_free(cmax_dev); dev_free(ck_k); dev_free(ck_0);
+  tshared.destroy(); twork.destroy();
+}
+
+inline void Dynamics::build_tracer() {
+  const int is = 1, ie = g.nx, js = 1, je = g.ny, isd = g.isd(), ied = g.ied(), jsd = g.jsd(), jed = g.jed(), npz = g.npz;
+  auto TS = [&](const char* n) { Fld x = tshared.take((size_t)g.ntile * npz * g.plane, npz); F[n] = x; return x; };
+  Fld xfx = TS("tr_xfx"), yfx = TS("tr_yfx"), dp2 = TS("tr_dp2"), rax = TS("tr_rax"), ray = TS("tr_ray");
+  Fld cx = f("cx"), cy = f("cy"), mfx = f("mfx"), mfy = f("mfy");
+  { TrFlux s; s.in[0] = cx; s.in[1] = cy; s.out[0] = xfx; s.out[1] = yfx; s.orect[0] = R(is, ie + 1, jsd, jed); s.orect[1] = R(isd, ied, js, je + 1);
+    s.k1 = npz; add(tracer_pre, "tracer", s); }
+  { TrDp2Ra s; s.in[0] = dp1; s.in[1] = mfx; s.in[2] = mfy; s.in[3] = xfx; s.in[4] = yfx; s.out[0] = dp2; s.out[1] = rax; s.out[2] = ray;
+    s.orect[0] = R(is, ie, js, je); s.orect[1] = R(is, ie, jsd, jed); s.orect[2] = R(isd, ied, js, je); s.k1 = npz; add(tracer_pre, "tracer", s); }
+  // per-tracer program on the staging field qc -> qc_o, work arrays in twork
+  Arena save = work; work = twork;
+  Fld fx = W("tr_fx", npz), fy = W("tr_fy", npz);
+  build_tp(tracer_q, "tracer", "tpq", qc, cx, cy, xfx, yfx, rax, ray, mfx, mfy, Fld{}, HORD_TR, DAMP_NONE, false, fx, fy);
+  { TrUpdate s; s.in[0] = qc; s.in[1] = dp1; s.in[2] = dp2; s.in[3] = fx; s.in[4] = fy; s.out[0] = qc_o; s.orect[0] = R(is, ie, js, je); s.k1 = npz;
+    add(tracer_q, "tracer", s); }
+  twork = work; work = save;
+}
+
+inline RemapArgs Dynamics::remap_args(bool last_step) {
+  RemapArgs a; a.g = g; a.pe = f("pe"); a.peln = f("peln"); a.pk = f("pk"); a.pkz = f("pkz"); a.pt = f("pt"); a.delp = f("delp");
+  a.u = f("u"); a.v = f("v"); a.pe2 = pe2; a.nq = nq;
+  for (int n = 0; n < nq; ++n) a.q[n] = q[n];
+  a.ak = ak_dev; a.bk = bk_dev; a.akap = opt.akap; a.zvir = opt.zvir; a.ptop = opt.ptop; a.last_step = last_step;
+  a.ws = remap_ws; a.ws_stride = (size_t)g.ntile * g.plane; a.pu_ad = pu_ad; a.pv_ad = pv_ad;
+  return a;
+}
+
+inline void Dynamics::pressures(int mode) {
+  PressArgs a{g, f("delp"), f("pe"), f("peln"), f("pk"), f("pkz"), opt.akap, opt.ptop};
+  for_points(ex, Rect{1, g.nx, 1, g.ny}, g.ntile, PressFn{a, mode});
+}
+
+// tracer_2d forward (nonlinear or tangent); q halos must be valid
+inline void Dynamics::tracer_fwd(int mode) {
+  const size_t b3 = n3 * 8;
+  run_group(tracer_pre, nullptr, mode);
+  if (mode == MODE_NL || mode == MODE_TL) {   // nsplt from the trajectory's max Courant number
+    for_points(ex, Rect{1, 1, 1, 1}, g.ntile * g.npz, CmaxFn{g, f("cx"), f("cy"), ctx.m.sin_sg[5], cmax_dev});
+    std::vector<double> cm((size_t)g.ntile * g.npz);
+    d2h(ex, cm.data(), cmax_dev, cm.size() * 8);
+    double cg = 0.; for (double c : cm) if (!(c < cg)) cg = c;
+    const int nsplt = int(1. + cg);
+    if (nsplt > nsplt_max) nsplt_max = nsplt;
+    if (nsplt != 1) tracer_subcycle_error = true;   // sub-cycled tracer transport (nsplt > 1) not built yet
+  }
+  for (int n = 0; n < nq; ++n) {
+    dev_copy(ex, qc.t, q[n].t, b3);
+    if (mode == MODE_TL) dev_copy(ex, qc.p, q[n].p, b3);
+    run_group(tracer_q, nullptr, mode);
+    dev_copy(ex, q[n].t, qc_o.t, b3);
+    if (mode == MODE_TL) dev_copy(ex, q[n].p, qc_o.p, b3);
+  }
+}
+// adjoint: trajectory of dp1, mfx..cy and the pre-transport q[n] must be in place; q[n].p holds the
+// adjoint of the transported tracers on entry, of the inputs on exit; mfx..cy.p, dp1.p accumulate.
+inline void Dynamics::tracer_ad() {
+  const size_t b3 = n3 * 8;
+  run_group(tracer_pre, nullptr, MODE_NL);
+  dev_zero(ex, tshared.p, tshared.used * 8);
+  for (int n = nq - 1; n >= 0; --n) {
+    dev_copy(ex, qc.t, q[n].t, b3);
+    run_group(tracer_q, nullptr, MODE_NL);
+    dev_zero(ex, twork.p, twork.used * 8);
+    dev_copy(ex, qc_o.p, q[n].p, b3); dev_zero(ex, qc.p, b3);
+    run_group(tracer_q, nullptr, MODE_AD);
+    dev_copy(ex, q[n].p, qc.p, b3);
+  }
+  run_group(tracer_pre, nullptr, MODE_AD);
+}
+
+inline void Dynamics::fv_dynamics(int mode) {
+  const size_t b3 = n3 * 8, b3p = n3p * 8;
+  const char* st4[4] = {"u", "v", "delp", "pt"};
+  if (mode != MODE_AD) {
+    if (mode == MODE_NL) { dev_copy(ex, ck_0, f("pt").t, b3); dev_copy(ex, ck_0 + n3, f("pkz").t, b3); }
+    run_group(pt_in, nullptr, mode);
+    dev_copy(ex, f("pt").t, f("pt_o").t, b3);
+    if (mode == MODE_TL) dev_copy(ex, f("pt").p, f("pt_o").p, b3);
+    for (int km = 0; km < k_split; ++km) {
+      for (const char* n : st4) run_halo(ex, mode, g, f(n));
+      dev_copy(ex, dp1.t, f("delp").t, b3);
+      if (mode == MODE_TL) dev_copy(ex, dp1.p, f("delp").p, b3);
+      ck_base = km * n_split;
+      dyn_core(mode);
+      if (nq > 0) {
+        for (int n = 0; n < nq; ++n) run_halo(ex, mode, g, q[n]);
+        if (mode == MODE_NL) {
+          for (int n = 0; n < nq; ++n) dev_copy(ex, ckq(km, n), q[n].t, b3);
+          const char* mf[4] = {"mfx", "mfy", "cx", "cy"};
+          for (int n = 0; n < 4; ++n) dev_copy(ex, ckm(km, n), f(mf[n]).t, b3);
+        }
+        tracer_fwd(mode);
+      }
+      if (g.npz > 4) {
+        if (mode == MODE_NL) {
+          const char* r3[3] = {"pt", "u", "v"}; const char* rp[3] = {"pe", "peln", "pk"};
+          for (int n = 0; n < 3; ++n) dev_copy(ex, ckr3(km, n), f(r3[n]).t, b3);
+          for (int n = 0; n < nq; ++n) dev_copy(ex, ckr3(km, 3 + n), q[n].t, b3);
+          for (int n = 0; n < 3; ++n) dev_copy(ex, ckrp(km, n), f(rp[n]).t, b3p);
+        }
+        run_remap(ex, mode, remap_args(km == k_split - 1));
+      }
+    }
+    return;
+  }
+  // ------------------------------------------------------------------ adjoint sweep
+  // entry: u,v,pt,delp,q[n] .p = adjoint of the step outputs.  pe..pkz after the last remap are dead.
+  for (const char* n : {"pe", "peln", "pk"}) dev_zero(ex, f(n).p, b3p);
+  dev_zero(ex, f("pkz").p, b3);
+  for (int km = k_split - 1; km >= 0; --km) {
+    if (g.npz > 4) {
+      const char* r3[3] = {"pt", "u", "v"}; const char* rp[3] = {"pe", "peln", "pk"};
+      for (int n = 0; n < 3; ++n) dev_copy(ex, f(r3[n]).t, ckr3(km, n), b3);
+      for (int n = 0; n < nq; ++n) dev_copy(ex, q[n].t, ckr3(km, 3 + n), b3);
+      for (int n = 0; n < 3; ++n) dev_copy(ex, f(rp[n]).t, ckrp(km, n), b3p);
+      dev_zero(ex, f("pe").p, b3p);
+      run_remap(ex, MODE_AD, remap_args(km == k_split - 1));
+    }
+    const char* mf[4] = {"mfx", "mfy", "cx", "cy"};
+    for (int n = 0; n < 4; ++n) dev_zero(ex, f(mf[n]).p, b3);
+    dev_zero(ex, dp1.p, b3);
+    if (nq > 0) {
+      for (int n = 0; n < nq; ++n) dev_copy(ex, q[n].t, ckq(km, n), b3);
+      for (int n = 0; n < 4; ++n) dev_copy(ex, f(mf[n]).t, ckm(km, n), b3);
+      dev_copy(ex, dp1.t, ckpt + ((size_t)(km * n_split) * 4 + 2) * n3, b3);   // delp at the start of this k_split step
+      tracer_ad();
+      for (int n = 0; n < nq; ++n) run_halo(ex, MODE_AD, g, q[n]);
+    }
+    ck_base = km * n_split;
+    dyn_core(MODE_AD);
+    for_points(ex, Rect{g.isd(), g.ied() + 1, g.jsd(), g.jed() + 1}, g.ntile * g.npz, AccumFn{g, dp1, f("delp"), MODE_AD});   // delp.p += dp1.p
+    for (const char* n : st4) run_halo(ex, MODE_AD, g, f(n));
+  }
+  // pt_in: pt(theta_v) = T (1 + zvir qv) / pkz
+  dev_copy(ex, f("pt").t, ck_0, b3); dev_copy(ex, f("pkz").t, ck_0 + n3, b3);
+  if (nq > 0) dev_copy(ex, q[0].t, ckq(0, 0), b3);
+  dev_copy(ex, f("pt_o").p, f("pt").p, b3); dev_zero(ex, f("pt").p, b3);
+  run_group(pt_in, nullptr, MODE_AD);
+}
+
+}  // namespace fv3

@@ -2,12 +2,12 @@
 // Built with `hipcc -x hip --offload-arch=gfx950` into libfv3lm_hip.so (the product), and with
 // `g++ -DFV3LM_HOST_EMUL` into tests/_emul/libfv3lm_emul.so (test-only host emulation, never
 // loaded by the package).
-#include "dycore.h"
+#include "dynamics.h"
 #include <string>
 
 using namespace fv3;
 
-struct fv3lm_handle { Dycore d; };
+struct fv3lm_handle { Dynamics d; };
 
 static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return 1; }
@@ -35,14 +35,14 @@ int fv3lm_create(fv3lm_handle** out, const fv3lm_dims* dm, const fv3lm_options* 
                  da_min_c, phis)) {
     std::string e = h->d.err; delete h; return fail("fv3lm_create: " + e);
   }
-  (void)ak; (void)bk;
+  if (!h->d.init2(ak, bk)) { std::string e = h->d.err; delete h; return fail("fv3lm_create: " + e); }
   *out = h;
   return 0;
 }
 
 int fv3lm_destroy(fv3lm_handle* h) {
   if (!h) return 0;
-  h->d.destroy(); delete h; return 0;
+  h->d.destroy2(); h->d.destroy(); delete h; return 0;
 }
 
 static bool find(fv3lm_handle* h, const char* name, Fld& f) {
@@ -71,6 +71,19 @@ int fv3lm_dyn_core(fv3lm_handle* h, int mode) {
   h->d.dyn_core(mode);
   return 0;
 }
+int fv3lm_pressures(fv3lm_handle* h, int mode) { h->d.pressures(mode); return 0; }
+int fv3lm_tracer_2d(fv3lm_handle* h, int mode) {
+  if (mode == MODE_AD) h->d.tracer_ad(); else h->d.tracer_fwd(mode);
+  return h->d.tracer_subcycle_error ? fail("tracer_2d: max Courant number >= 1 needs sub-cycling (nsplt > 1), not built yet") : 0;
+}
+int fv3lm_remap(fv3lm_handle* h, int mode, int last_step) { run_remap(h->d.ex, mode, h->d.remap_args(last_step != 0)); return 0; }
+int fv3lm_fv_dynamics(fv3lm_handle* h, int mode) {
+  h->d.fv_dynamics(mode);
+  return h->d.tracer_subcycle_error ? fail("tracer_2d: max Courant number >= 1 needs sub-cycling (nsplt > 1), not built yet") : 0;
+}
+int fv3lm_step_tl(fv3lm_handle* h) { h->d.step_tl(); return h->d.tracer_subcycle_error ? fail("tracer sub-cycling not built") : 0; }
+int fv3lm_step_nl(fv3lm_handle* h) { h->d.step_nl(); return h->d.tracer_subcycle_error ? fail("tracer sub-cycling not built") : 0; }
+int fv3lm_step_ad(fv3lm_handle* h) { h->d.step_ad(); return 0; }
 int fv3lm_zero_work_adjoint(fv3lm_handle* h) { h->d.zero_work_adjoint(); return 0; }
 int fv3lm_sync(fv3lm_handle* h) { dev_sync(h->d.ex); return 0; }
 long fv3lm_launch_count(fv3lm_handle* h) { return h->d.ex.launches; }

@@ -1,0 +1,535 @@
+// fv3lm-hip: Lagrangian-to-Eulerian vertical remap (LAGRANGIAN_TO_EULERIAN_TLM / _FWD+_BWD,
+// fv_mapz_tlm.F90:69-1360, fv_mapz_adm.F90:91/1614) as column kernels: one thread per column,
+// i fastest so every level access of a wave is one contiguous row piece.  Hydrostatic,
+// remap_option = 0 (T in log p), |kord| > 16: the "perfectly linear" profile, the only one the TL/AD
+// reference implements (fv_mapz_tlm.F90:8653-8666).
+//   forward (nonlinear / tangent):  templated on the scalar (double / Dual)
+//   adjoint: hand-written reverse of the same statements (tridiagonal edge-value solve reversed,
+//            the monotone layer search replayed on the trajectory), no tape.
+// Per-thread work vectors live in a global workspace laid out [slot][k][column] (coalesced), not in
+// private memory.
+#pragma once
+#include "column.h"
+
+namespace fv3 {
+
+// workspace view of one column: element (slot, k), k = 0..kw-1
+struct ColWs {
+  double* base; size_t stride; int kw;   // stride = number of columns in the launch
+  HD double& at(int slot, int k) const { return base[((size_t)slot * kw + k) * stride]; }
+};
+template <class T> struct WsIO;
+template <> struct WsIO<double> {
+  static constexpr int W = 1;
+  HD static double get(const ColWs& w, int s, int k) { return w.at(s, k); }
+  HD static void set(const ColWs& w, int s, int k, double x) { w.at(s, k) = x; }
+};
+template <> struct WsIO<Dual> {
+  static constexpr int W = 2;
+  HD static Dual get(const ColWs& w, int s, int k) { return Dual(w.at(2 * s, k), w.at(2 * s + 1, k)); }
+  HD static void set(const ColWs& w, int s, int k, const Dual& x) { w.at(2 * s, k) = x.v; w.at(2 * s + 1, k) = x.d; }
+};
+
+constexpr double R3 = 1. / 3., R23 = 2. / 3.;
+
+// ---------------------------------------------------------------- forward column map
+// cs_profile (|kord|>16, iv != -2; fv_mapz_tlm.F90:8592-8666) + map1_ppm/map_scalar/map1_q2 loop
+// (:7980-8045).  pe1, q1, pe2: functors k -> T (1-based); out(k, value).  Workspace slots used
+// (in units of T): SG = gam, SE = edge values qe.
+template <class T, class FP1, class FQ1, class FP2, class FOut>
+HD void map_col(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const FOut& out, const ColWs& ws, int SG, int SE) {
+  typedef WsIO<T> W;
+  // edge values by the tridiagonal solve
+  T dpa = pe1(2) - pe1(1), dpb = pe1(3) - pe1(2);
+  T grat = dpb / dpa;
+  T bet = grat * (grat + 0.5);
+  T qf = ((grat + grat) * (grat + 1.) * q1(1) + q1(2)) / bet;
+  T gam = (1. + grat * (grat + 1.5)) / bet;
+  W::set(ws, SE, 1, qf); W::set(ws, SG, 1, gam);
+  T d4 = grat, a_prev = q1(1), dp_prev = dpa;
+  for (int k = 2; k <= km; ++k) {
+    T dpk = pe1(k + 1) - pe1(k);
+    T ak_ = q1(k);
+    d4 = dp_prev / dpk;
+    bet = 2. + d4 + d4 - gam;
+    qf = (3. * (a_prev + d4 * ak_) - qf) / bet;
+    gam = d4 / bet;
+    W::set(ws, SE, k, qf); W::set(ws, SG, k, gam);
+    a_prev = ak_; dp_prev = dpk;
+  }
+  T a_bot = 1. + d4 * (d4 + 1.5);
+  T qe = (2. * d4 * (d4 + 1.) * q1(km) + q1(km - 1) - a_bot * qf) / (d4 * (d4 + 0.5) - a_bot * gam);
+  W::set(ws, SE, km + 1, qe);
+  for (int k = km; k >= 1; --k) {
+    qe = W::get(ws, SE, k) - W::get(ws, SG, k) * qe;
+    W::set(ws, SE, k, qe);
+  }
+  // conservative mapping
+  int k0 = 1;
+  T qsum = T(0.);
+  for (int k = 1; k <= km; ++k) {
+    const T p2t = pe2(k), p2b = pe2(k + 1);
+    int l; bool found = false;
+    for (l = k0; l <= km; ++l)
+      if (val(p2t) >= val(pe1(l)) && val(p2t) <= val(pe1(l + 1))) { found = true; break; }
+    if (found) {
+      const T p1l = pe1(l), p1r = pe1(l + 1), dpl = p1r - p1l;
+      const T a1 = q1(l), a2 = W::get(ws, SE, l), a3 = W::get(ws, SE, l + 1), a4 = 3. * (2. * a1 - (a2 + a3));
+      const T pl = (p2t - p1l) / dpl;
+      if (val(p2b) <= val(p1r)) {
+        const T pr = (p2b - p1l) / dpl;
+        out(k, a2 + 0.5 * (a4 + a3 - a2) * (pr + pl) - a4 * R3 * (pr * (pr + pl) + pl * pl));
+        k0 = l;
+        continue;
+      }
+      qsum = (p1r - p2t) * (a2 + 0.5 * (a4 + a3 - a2) * (1. + pl) - a4 * (R3 * (1. + pl * (1. + pl))));
+      int m; bool bottom = false;
+      for (m = l + 1; m <= km; ++m) {
+        if (val(p2b) > val(pe1(m + 1))) qsum = qsum + (pe1(m + 1) - pe1(m)) * q1(m);
+        else { bottom = true; break; }
+      }
+      if (bottom) {
+        const T p1m = pe1(m), dpm = pe1(m + 1) - p1m;
+        const T b1 = q1(m), b2 = W::get(ws, SE, m), b3 = W::get(ws, SE, m + 1), b4 = 3. * (2. * b1 - (b2 + b3));
+        const T dp = p2b - p1m, esl = dp / dpm;
+        qsum = qsum + dp * (b2 + 0.5 * esl * (b3 - b2 + b4 * (1. - R23 * esl)));
+        k0 = m;
+      }
+    }
+    out(k, qsum / (p2b - p2t));
+  }
+}
+
+// ---------------------------------------------------------------- adjoint column map
+// Trajectory functors pe1, q1, pe2 (double); q2_ad(k) functor; accumulates into workspace slots
+// SP1 (pe1_ad), SQ1 (q1_ad), SP2 (pe2_ad), which the caller has zeroed or pre-loaded.  Scratch
+// slots: SG gam, SB bet, SF qf (pre back-substitution), SE qe, SD d4, SDP dp1_ad, SGA gam_ad,
+// SFA qf_ad, SEA qe_ad, SDA d4_ad.
+struct MapAdSlots { int SP1, SQ1, SP2, SG, SB, SF, SE, SD, SDP, SGA, SFA, SEA, SDA; };
+template <class FP1, class FQ1, class FP2, class FAd>
+HD void map_col_ad(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const FAd& q2_ad, const ColWs& ws,
+                   const MapAdSlots& S) {
+  // ---- forward replay with storage
+  const double dp1_1 = pe1(2) - pe1(1), dp1_2 = pe1(3) - pe1(2);
+  const double grat = dp1_2 / dp1_1, bet1 = grat * (grat + 0.5);
+  {
+    double qf = ((grat + grat) * (grat + 1.) * q1(1) + q1(2)) / bet1, gam = (1. + grat * (grat + 1.5)) / bet1;
+    ws.at(S.SF, 1) = qf; ws.at(S.SG, 1) = gam; ws.at(S.SB, 1) = bet1; ws.at(S.SD, 1) = grat;
+    double d4 = grat, a_prev = q1(1), dp_prev = dp1_1;
+    for (int k = 2; k <= km; ++k) {
+      const double dpk = pe1(k + 1) - pe1(k), ak_ = q1(k);
+      d4 = dp_prev / dpk;
+      const double bet = 2. + d4 + d4 - gam;
+      qf = (3. * (a_prev + d4 * ak_) - qf) / bet;
+      gam = d4 / bet;
+      ws.at(S.SF, k) = qf; ws.at(S.SG, k) = gam; ws.at(S.SB, k) = bet; ws.at(S.SD, k) = d4;
+      a_prev = ak_; dp_prev = dpk;
+    }
+    const double a_bot = 1. + d4 * (d4 + 1.5), den = d4 * (d4 + 0.5) - a_bot * gam;
+    double qe = (2. * d4 * (d4 + 1.) * q1(km) + q1(km - 1) - a_bot * qf) / den;
+    ws.at(S.SF, km + 1) = qe; ws.at(S.SE, km + 1) = qe;
+    for (int k = km; k >= 1; --k) { qe = ws.at(S.SF, k) - ws.at(S.SG, k) * qe; ws.at(S.SE, k) = qe; }
+  }
+  for (int k = 0; k <= km + 1; ++k) { ws.at(S.SDP, k) = 0.; ws.at(S.SGA, k) = 0.; ws.at(S.SFA, k) = 0.; ws.at(S.SEA, k) = 0.; ws.at(S.SDA, k) = 0.; }
+  // ---- reverse of the mapping loop (targets are independent; the search is replayed in order)
+  auto addq = [&](int l, double a1_ad, double a2_ad, double a3_ad, double a4_ad) {   // a4 = 3(2 a1 - a2 - a3)
+    ws.at(S.SQ1, l) += a1_ad + 6. * a4_ad;
+    ws.at(S.SEA, l) += a2_ad - 3. * a4_ad;
+    ws.at(S.SEA, l + 1) += a3_ad - 3. * a4_ad;
+  };
+  int k0 = 1;
+  for (int k = 1; k <= km; ++k) {
+    const double g = q2_ad(k);
+    const double p2t = pe2(k), p2b = pe2(k + 1);
+    int l; bool found = false;
+    for (l = k0; l <= km; ++l)
+      if (p2t >= pe1(l) && p2t <= pe1(l + 1)) { found = true; break; }
+    if (!found) continue;   // (stale-qsum path of the reference: never taken for ordered pressures)
+    const double p1l = pe1(l), p1r = pe1(l + 1), dpl = p1r - p1l;
+    const double a1 = q1(l), a2 = ws.at(S.SE, l), a3 = ws.at(S.SE, l + 1), a4 = 3. * (2. * a1 - (a2 + a3)), Sm = a4 + a3 - a2;
+    const double pl = (p2t - p1l) / dpl;
+    double pl_ad = 0.;
+    if (p2b <= p1r) {
+      const double pr = (p2b - p1l) / dpl, s = pr + pl, w = pr * s + pl * pl;
+      addq(l, 0., (1. - 0.5 * s) * g, 0.5 * s * g, (0.5 * s - R3 * w) * g);
+      const double pr_ad = (0.5 * Sm - a4 * R3 * (2. * pr + pl)) * g;
+      pl_ad = (0.5 * Sm - a4 * R3 * (pr + 2. * pl)) * g;
+      ws.at(S.SP2, k + 1) += pr_ad / dpl; ws.at(S.SP1, l) -= pr_ad / dpl; ws.at(S.SDP, l) -= pr * pr_ad / dpl;
+      k0 = l;
+    } else {
+      const double D = p2b - p2t;
+      const double E = a2 + 0.5 * Sm * (1. + pl) - a4 * (R3 * (1. + pl * (1. + pl)));
+      double qsum = (p1r - p2t) * E;
+      int m; bool bottom = false;
+      for (m = l + 1; m <= km; ++m) {
+        if (p2b > pe1(m + 1)) qsum += (pe1(m + 1) - pe1(m)) * q1(m);
+        else { bottom = true; break; }
+      }
+      const int mend = m;   // first layer not fully inside
+      double dp = 0., esl = 0., Fm = 0., b1 = 0., b2 = 0., b3 = 0., b4 = 0., dpm = 1.;
+      if (bottom) {
+        const double p1m = pe1(m); dpm = pe1(m + 1) - p1m;
+        b1 = q1(m); b2 = ws.at(S.SE, m); b3 = ws.at(S.SE, m + 1); b4 = 3. * (2. * b1 - (b2 + b3));
+        dp = p2b - p1m; esl = dp / dpm;
+        Fm = b2 + 0.5 * esl * (b3 - b2 + b4 * (1. - R23 * esl));
+        qsum += dp * Fm;
+      }
+      const double q2v = qsum / D, qs_ad = g / D, D_ad = -q2v * g / D;
+      ws.at(S.SP2, k + 1) += D_ad; ws.at(S.SP2, k) -= D_ad;
+      const double W_ad = E * qs_ad, E_ad = (p1r - p2t) * qs_ad;
+      ws.at(S.SP1, l + 1) += W_ad; ws.at(S.SP2, k) -= W_ad;
+      addq(l, 0., (1. - 0.5 * (1. + pl)) * E_ad, 0.5 * (1. + pl) * E_ad, (0.5 * (1. + pl) - R3 * (1. + pl * (1. + pl))) * E_ad);
+      pl_ad = (0.5 * Sm - a4 * R3 * (1. + 2. * pl)) * E_ad;
+      for (int mm = l + 1; mm < mend; ++mm) { ws.at(S.SDP, mm) += q1(mm) * qs_ad; ws.at(S.SQ1, mm) += (pe1(mm + 1) - pe1(mm)) * qs_ad; }
+      if (bottom) {
+        double dp_ad = Fm * qs_ad;
+        const double F_ad = dp * qs_ad;
+        addq(m, 0., (1. - 0.5 * esl) * F_ad, 0.5 * esl * F_ad, 0.5 * esl * (1. - R23 * esl) * F_ad);
+        const double esl_ad = (0.5 * (b3 - b2 + b4 * (1. - R23 * esl)) - 0.5 * esl * b4 * R23) * F_ad;
+        dp_ad += esl_ad / dpm; ws.at(S.SDP, m) -= esl * esl_ad / dpm;
+        ws.at(S.SP2, k + 1) += dp_ad; ws.at(S.SP1, m) -= dp_ad;
+        k0 = m;
+      }
+    }
+    ws.at(S.SP2, k) += pl_ad / dpl; ws.at(S.SP1, l) -= pl_ad / dpl; ws.at(S.SDP, l) -= pl * pl_ad / dpl;
+  }
+  // ---- reverse of the back substitution  qe(k) = qf(k) - gam(k) qe(k+1), k = km..1
+  for (int k = 1; k <= km; ++k) {
+    const double e = ws.at(S.SEA, k);
+    ws.at(S.SFA, k) += e;
+    ws.at(S.SGA, k) -= ws.at(S.SE, k + 1) * e;
+    ws.at(S.SEA, k + 1) -= ws.at(S.SG, k) * e;
+  }
+  ws.at(S.SFA, km + 1) += ws.at(S.SEA, km + 1);
+  // ---- bottom edge value
+  {
+    const double d = ws.at(S.SD, km), gamk = ws.at(S.SG, km), qfk = ws.at(S.SF, km);
+    const double a_bot = 1. + d * (d + 1.5), den = d * (d + 0.5) - a_bot * gamk;
+    const double fa = ws.at(S.SFA, km + 1);
+    const double numb_ad = fa / den, den_ad = -ws.at(S.SF, km + 1) * fa / den;
+    double d_ad = 2. * (2. * d + 1.) * q1(km) * numb_ad + (2. * d + 0.5) * den_ad;
+    ws.at(S.SQ1, km) += 2. * d * (d + 1.) * numb_ad; ws.at(S.SQ1, km - 1) += numb_ad;
+    double abot_ad = -qfk * numb_ad - gamk * den_ad;
+    ws.at(S.SFA, km) -= a_bot * numb_ad;
+    ws.at(S.SGA, km) -= a_bot * den_ad;
+    d_ad += (2. * d + 1.5) * abot_ad;
+    ws.at(S.SDA, km) += d_ad;
+  }
+  // ---- reverse of the forward elimination, k = km..2
+  for (int k = km; k >= 2; --k) {
+    const double bet = ws.at(S.SB, k), gam = ws.at(S.SG, k), qf = ws.at(S.SF, k), d4 = ws.at(S.SD, k);
+    const double ga = ws.at(S.SGA, k);
+    double d4_ad = ws.at(S.SDA, k) + ga / bet;
+    double bet_ad = -gam * ga / bet;
+    const double t = ws.at(S.SFA, k) / bet;
+    ws.at(S.SQ1, k - 1) += 3. * t; ws.at(S.SQ1, k) += 3. * d4 * t;
+    d4_ad += 3. * q1(k) * t;
+    ws.at(S.SFA, k - 1) -= t;
+    bet_ad -= qf * t;
+    d4_ad += 2. * bet_ad; ws.at(S.SGA, k - 1) -= bet_ad;
+    const double dpk = pe1(k + 1) - pe1(k);
+    ws.at(S.SDP, k - 1) += d4_ad / dpk; ws.at(S.SDP, k) -= d4 * d4_ad / dpk;
+  }
+  {
+    const double gam1 = ws.at(S.SG, 1), qf1 = ws.at(S.SF, 1);
+    const double ga = ws.at(S.SGA, 1);
+    double grat_ad = (2. * grat + 1.5) / bet1 * ga;
+    double bet_ad = -gam1 * ga / bet1;
+    const double t = ws.at(S.SFA, 1) / bet1;
+    bet_ad -= qf1 * t;
+    grat_ad += 2. * (2. * grat + 1.) * q1(1) * t;
+    ws.at(S.SQ1, 1) += 2. * grat * (grat + 1.) * t; ws.at(S.SQ1, 2) += t;
+    grat_ad += (2. * grat + 0.5) * bet_ad;
+    ws.at(S.SDP, 2) += grat_ad / dp1_1; ws.at(S.SDP, 1) -= grat * grat_ad / dp1_1;
+  }
+  for (int k = 1; k <= km; ++k) { const double a = ws.at(S.SDP, k); ws.at(S.SP1, k + 1) += a; ws.at(S.SP1, k) -= a; }
+}
+
+// ---------------------------------------------------------------- kernels
+struct RemapArgs {
+  Geom g;
+  Fld pe, peln, pk, pkz, pt, delp, u, v;   // state (in place)
+  Fld pe2;                                 // new interface pressures (work, npz+1)
+  Fld q[8]; int nq;
+  const double *ak, *bk;                   // device [npz+1]
+  double akap, zvir, ptop; int last_step;
+  double* ws; size_t ws_stride;            // column workspace
+  Fld pu_ad, pv_ad;                        // adjoint hand-over of the u/v maps to pe (npz+1 levels + ps slot)
+};
+HD size_t fidx(const Geom& g, const Fld& f, int tile, int i, int j, int k) { return ((size_t)(tile * f.nk + k - 1)) * g.plane + g.idx(i, j); }
+
+// scalars: T (log p), tracers, delp, pk, peln, pkz, final pt (fv_mapz_tlm.F90:1586-1835, :2203-2250)
+template <class T>
+HD void remap_scalars_col(const RemapArgs& a, int i, int j, int tile, size_t col) {
+  const Geom& g = a.g; const int km = g.npz;
+  const ColWs ws{a.ws + col, a.ws_stride, km + 2};
+  typedef FIO<T> IO; typedef WsIO<T> W;
+  const int SG = 0, SE = 1, SO = 2;
+  auto pe1 = [&](int k) { return IO::ld(a.pe, fidx(g, a.pe, tile, i, j, k)); };
+  auto pn1 = [&](int k) { return IO::ld(a.peln, fidx(g, a.peln, tile, i, j, k)); };
+  auto pk1 = [&](int k) { return IO::ld(a.pk, fidx(g, a.pk, tile, i, j, k)); };
+  const T ps = pe1(km + 1);
+  auto pe2 = [&](int k) -> T { return k == 1 ? T(a.ptop) : (k == km + 1 ? ps : a.ak[k - 1] + a.bk[k - 1] * ps); };
+  auto pn2 = [&](int k) -> T { return (k == 1 || k == km + 1) ? pn1(k) : dlog(pe2(k)); };
+  auto tv = [&](int k) -> T { return IO::ld(a.pt, fidx(g, a.pt, tile, i, j, k)) * (pk1(k + 1) - pk1(k)) / (a.akap * (pn1(k + 1) - pn1(k))); };
+  auto outw = [&](int k, const T& x) { W::set(ws, SO, k, x); };
+  map_col<T>(km, pn1, tv, pn2, outw, ws, SG, SE);
+  for (int k = 1; k <= km; ++k) IO::st(a.pt, fidx(g, a.pt, tile, i, j, k), W::get(ws, SO, k));   // T_v on the new levels
+  for (int n = 0; n < a.nq; ++n) {
+    const Fld& qf = a.q[n];
+    auto q1 = [&](int k) { return IO::ld(qf, fidx(g, qf, tile, i, j, k)); };
+    map_col<T>(km, pe1, q1, pe2, outw, ws, SG, SE);
+    for (int k = 1; k <= km; ++k) IO::st(qf, fidx(g, qf, tile, i, j, k), W::get(ws, SO, k));
+  }
+  // new pressures; pk/peln end levels keep their values (:1650-1661)
+  T pk_hi = pk1(1), pn_hi = pn1(1), pe_hi = pe2(1);
+  IO::st(a.pe2, fidx(g, a.pe2, tile, i, j, 1), pe_hi);
+  for (int k = 1; k <= km; ++k) {
+    const T pe_lo = pe2(k + 1);
+    T pn_lo, pk_lo;
+    if (k == km) { pn_lo = pn1(km + 1); pk_lo = pk1(km + 1); } else { pn_lo = dlog(pe_lo); pk_lo = dexp(a.akap * pn_lo); }
+    const T pkz = (pk_lo - pk_hi) / (a.akap * (pn_lo - pn_hi));
+    const size_t n0 = fidx(g, a.pt, tile, i, j, k);
+    IO::st(a.delp, n0, pe_lo - pe_hi);
+    IO::st(a.pkz, n0, pkz);
+    const T t2 = IO::ld(a.pt, n0);
+    if (a.last_step) IO::st(a.pt, n0, t2 / (1. + a.zvir * (a.nq > 0 ? IO::ld(a.q[0], n0) : T(0.))));
+    else IO::st(a.pt, n0, t2 / pkz);
+    if (k > 1) { IO::st(a.peln, fidx(g, a.peln, tile, i, j, k), pn_hi); IO::st(a.pk, fidx(g, a.pk, tile, i, j, k), pk_hi); }
+    IO::st(a.pe2, fidx(g, a.pe2, tile, i, j, k + 1), pe_lo);
+    pe_hi = pe_lo; pn_hi = pn_lo; pk_hi = pk_lo;
+  }
+}
+
+// u (dir=0, points i=1..nx, j=1..ny+1) and v (dir=1, i=1..nx+1, j=1..ny) on pressures averaged across the
+// edge (fv_mapz_tlm.F90:1884-1934)
+template <class T>
+HD void remap_wind_col(const RemapArgs& a, int dir, int i, int j, int tile, size_t col) {
+  const Geom& g = a.g; const int km = g.npz;
+  const ColWs ws{a.ws + col, a.ws_stride, km + 2};
+  typedef FIO<T> IO; typedef WsIO<T> W;
+  const int SG = 0, SE = 1, SO = 2;
+  const int im = dir == 0 ? i : i - 1, jm = dir == 0 ? j - 1 : j;
+  const Fld& wf = dir == 0 ? a.u : a.v;
+  auto pe0 = [&](int k) -> T {
+    if (k == 1) return IO::ld(a.pe, fidx(g, a.pe, tile, i, j, 1));
+    return 0.5 * (IO::ld(a.pe, fidx(g, a.pe, tile, im, jm, k)) + IO::ld(a.pe, fidx(g, a.pe, tile, i, j, k)));
+  };
+  const T pss = IO::ld(a.pe, fidx(g, a.pe, tile, im, jm, km + 1)) + IO::ld(a.pe, fidx(g, a.pe, tile, i, j, km + 1));
+  auto pe3 = [&](int k) -> T { return (dir == 1 && k == 1) ? T(a.ak[0]) : a.ak[k - 1] + (0.5 * a.bk[k - 1]) * pss; };
+  auto q1 = [&](int k) { return IO::ld(wf, fidx(g, wf, tile, i, j, k)); };
+  auto outw = [&](int k, const T& x) { W::set(ws, SO, k, x); };
+  map_col<T>(km, pe0, q1, pe3, outw, ws, SG, SE);
+  for (int k = 1; k <= km; ++k) IO::st(wf, fidx(g, wf, tile, i, j, k), W::get(ws, SO, k));
+}
+
+// adjoint of remap_wind_col: consumes wf.p (adjoint of the mapped wind), writes the adjoint of the
+// input wind back into wf.p and hands the pressure adjoints to pu_ad / pv_ad (npz+1 levels of
+// d/d pe0(k); level slot km+2 -> here stored at k = km+2 as the adjoint of the surface-pressure sum).
+HD void remap_wind_col_ad(const RemapArgs& a, int dir, int i, int j, int tile, size_t col) {
+  const Geom& g = a.g; const int km = g.npz;
+  const ColWs ws{a.ws + col, a.ws_stride, km + 2};
+  const int im = dir == 0 ? i : i - 1, jm = dir == 0 ? j - 1 : j;
+  const Fld& wf = dir == 0 ? a.u : a.v;
+  const Fld& ho = dir == 0 ? a.pu_ad : a.pv_ad;
+  auto pe0 = [&](int k) -> double {
+    if (k == 1) return a.pe.t[fidx(g, a.pe, tile, i, j, 1)];
+    return 0.5 * (a.pe.t[fidx(g, a.pe, tile, im, jm, k)] + a.pe.t[fidx(g, a.pe, tile, i, j, k)]);
+  };
+  const double pss = a.pe.t[fidx(g, a.pe, tile, im, jm, km + 1)] + a.pe.t[fidx(g, a.pe, tile, i, j, km + 1)];
+  auto pe3 = [&](int k) -> double { return (dir == 1 && k == 1) ? a.ak[0] : a.ak[k - 1] + (0.5 * a.bk[k - 1]) * pss; };
+  auto q1 = [&](int k) { return wf.t[fidx(g, wf, tile, i, j, k)]; };
+  auto q2ad = [&](int k) { return wf.p[fidx(g, wf, tile, i, j, k)]; };
+  const MapAdSlots S{0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12};
+  for (int k = 0; k <= km + 1; ++k) { ws.at(S.SP1, k) = 0.; ws.at(S.SQ1, k) = 0.; ws.at(S.SP2, k) = 0.; }
+  map_col_ad(km, pe0, q1, pe3, q2ad, ws, S);
+  double pss_ad = 0.;
+  for (int k = 1; k <= km + 1; ++k) if (!(dir == 1 && k == 1)) pss_ad += 0.5 * a.bk[k - 1] * ws.at(S.SP2, k);
+  for (int k = 1; k <= km; ++k) wf.p[fidx(g, wf, tile, i, j, k)] = ws.at(S.SQ1, k);
+  // hand-over: level k (1..km+1) = d/d pe0(k); the ps-sum adjoint is folded into level km+1 of both neighbours
+  for (int k = 1; k <= km + 1; ++k) ho.p[fidx(g, ho, tile, i, j, k)] = ws.at(S.SP1, k);
+  ho.t[fidx(g, ho, tile, i, j, 1)] = pss_ad;   // stored in the (otherwise unused) trajectory side, level 1
+}
+
+// gather of the wind-map pressure adjoints into pe.p on is-1..ie+1, js-1..je+1
+HD void remap_pe_gather_ad(const RemapArgs& a, int i, int j, int tile) {
+  const Geom& g = a.g; const int km = g.npz;
+  const bool u0 = (i >= 1 && i <= g.nx && j >= 1 && j <= g.ny + 1), u1 = (i >= 1 && i <= g.nx && j + 1 >= 1 && j + 1 <= g.ny + 1);
+  const bool v0 = (i >= 1 && i <= g.nx + 1 && j >= 1 && j <= g.ny), v1 = (i + 1 >= 1 && i + 1 <= g.nx + 1 && j >= 1 && j <= g.ny);
+  for (int k = 1; k <= km + 1; ++k) {
+    double acc = 0.;
+    // u point (i,j) uses pe(i,j-1) and pe(i,j); u point (i,j+1) uses pe(i,j) and pe(i,j+1)
+    if (k == 1) {
+      if (u0) acc += a.pu_ad.p[fidx(g, a.pu_ad, tile, i, j, 1)];
+      if (v0) acc += a.pv_ad.p[fidx(g, a.pv_ad, tile, i, j, 1)];
+    } else {
+      if (u0) acc += 0.5 * a.pu_ad.p[fidx(g, a.pu_ad, tile, i, j, k)];
+      if (u1) acc += 0.5 * a.pu_ad.p[fidx(g, a.pu_ad, tile, i, j + 1, k)];
+      if (v0) acc += 0.5 * a.pv_ad.p[fidx(g, a.pv_ad, tile, i, j, k)];
+      if (v1) acc += 0.5 * a.pv_ad.p[fidx(g, a.pv_ad, tile, i + 1, j, k)];
+    }
+    if (k == km + 1) {
+      if (u0) acc += a.pu_ad.t[fidx(g, a.pu_ad, tile, i, j, 1)];
+      if (u1) acc += a.pu_ad.t[fidx(g, a.pu_ad, tile, i, j + 1, 1)];
+      if (v0) acc += a.pv_ad.t[fidx(g, a.pv_ad, tile, i, j, 1)];
+      if (v1) acc += a.pv_ad.t[fidx(g, a.pv_ad, tile, i + 1, j, 1)];
+    }
+    a.pe.p[fidx(g, a.pe, tile, i, j, k)] += acc;
+  }
+}
+
+// adjoint of remap_scalars_col.  Trajectory inputs (pre-remap pe, peln, pk, pt, q) must be in place.
+// Incoming adjoints: pt.p, q[n].p, delp.p, pk.p, peln.p, pkz.p (of the remapped fields); outgoing:
+// pt.p, q[n].p (of the inputs), pk.p, peln.p replaced, pe.p accumulated, delp.p = pkz.p = 0.
+HD void remap_scalars_col_ad(const RemapArgs& a, int i, int j, int tile, size_t col) {
+  const Geom& g = a.g; const int km = g.npz;
+  const ColWs ws{a.ws + col, a.ws_stride, km + 2};
+  const MapAdSlots S{0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12};
+  const int SPE1 = 13, SPN1 = 14, SPK1 = 15, SPE2 = 16, SPN2 = 17, SPK2 = 18, ST2 = 19, SQ2 = 20, SV = 21;
+  auto pe1 = [&](int k) { return a.pe.t[fidx(g, a.pe, tile, i, j, k)]; };
+  auto pn1 = [&](int k) { return a.peln.t[fidx(g, a.peln, tile, i, j, k)]; };
+  auto pk1 = [&](int k) { return a.pk.t[fidx(g, a.pk, tile, i, j, k)]; };
+  const double ps = pe1(km + 1);
+  auto pe2 = [&](int k) -> double { return k == 1 ? a.ptop : (k == km + 1 ? ps : a.ak[k - 1] + a.bk[k - 1] * ps); };
+  auto pn2 = [&](int k) -> double { return (k == 1 || k == km + 1) ? pn1(k) : log(pe2(k)); };
+  auto pk2 = [&](int k) -> double { return (k == 1 || k == km + 1) ? pk1(k) : exp(a.akap * pn2(k)); };
+  auto ptin = [&](int k) { return a.pt.t[fidx(g, a.pt, tile, i, j, k)]; };
+  auto tv = [&](int k) -> double { return ptin(k) * (pk1(k + 1) - pk1(k)) / (a.akap * (pn1(k + 1) - pn1(k))); };
+  for (int k = 0; k <= km + 1; ++k)
+    for (int s : {SPE1, SPN1, SPK1, SPE2, SPN2, SPK2}) ws.at(s, k) = 0.;
+  // trajectory of the remapped T_v and q_v (needed by the final conversion)
+  {
+    auto outT = [&](int k, double x) { ws.at(ST2, k) = x; };
+    map_col<double>(km, pn1, tv, pn2, outT, ws, 0, 1);
+    if (a.nq > 0 && a.last_step) {
+      auto q1 = [&](int k) { return a.q[0].t[fidx(g, a.q[0], tile, i, j, k)]; };
+      auto outQ = [&](int k, double x) { ws.at(SQ2, k) = x; };
+      map_col<double>(km, pe1, q1, pe2, outQ, ws, 0, 1);
+    }
+  }
+  // final conversion, pkz, pk/peln outputs, delp
+  for (int k = 1; k <= km; ++k) {
+    const size_t n0 = fidx(g, a.pt, tile, i, j, k);
+    const double pk_hi = pk2(k), pk_lo = pk2(k + 1), pn_hi = pn2(k), pn_lo = pn2(k + 1);
+    const double den = a.akap * (pn_lo - pn_hi), pkz = (pk_lo - pk_hi) / den;
+    const double pt_ad = a.pt.p[n0], t2 = ws.at(ST2, k);
+    double pkz_ad = a.pkz.p[n0], t2_ad;
+    if (a.last_step) {
+      const double qv = a.nq > 0 ? ws.at(SQ2, k) : 0., f = 1. + a.zvir * qv;
+      t2_ad = pt_ad / f;
+      if (a.nq > 0) a.q[0].p[fidx(g, a.q[0], tile, i, j, k)] += -(t2 / f) * a.zvir * pt_ad / f;
+    } else {
+      t2_ad = pt_ad / pkz;
+      pkz_ad += -(t2 / pkz) * pt_ad / pkz;
+    }
+    ws.at(SV, k) = t2_ad;
+    const double za = pkz_ad / den;
+    ws.at(SPK2, k + 1) += za; ws.at(SPK2, k) -= za;
+    const double zb = -pkz * a.akap * za;
+    ws.at(SPN2, k + 1) += zb; ws.at(SPN2, k) -= zb;
+    const double dpa = a.delp.p[n0];
+    ws.at(SPE2, k + 1) += dpa; ws.at(SPE2, k) -= dpa;
+    a.delp.p[n0] = 0.; a.pkz.p[n0] = 0.;
+  }
+  for (int k = 2; k <= km; ++k) {   // pk_out(k) = pk2(k), peln_out(k) = pn2(k) for interior interfaces
+    ws.at(SPK2, k) += a.pk.p[fidx(g, a.pk, tile, i, j, k)];
+    ws.at(SPN2, k) += a.peln.p[fidx(g, a.peln, tile, i, j, k)];
+  }
+  // T map (coordinates pn1 -> pn2)
+  {
+    for (int k = 0; k <= km + 1; ++k) { ws.at(S.SP1, k) = 0.; ws.at(S.SQ1, k) = 0.; ws.at(S.SP2, k) = 0.; }
+    auto q2ad = [&](int k) { return ws.at(SV, k); };
+    map_col_ad(km, pn1, tv, pn2, q2ad, ws, S);
+    for (int k = 1; k <= km + 1; ++k) { ws.at(SPN1, k) += ws.at(S.SP1, k); ws.at(SPN2, k) += ws.at(S.SP2, k); }
+    for (int k = 1; k <= km; ++k) {   // T_v(k) = pt * dpk / (akap * dln)
+      const double tv_ad = ws.at(S.SQ1, k), dpk = pk1(k + 1) - pk1(k), den = a.akap * (pn1(k + 1) - pn1(k)), pt0 = ptin(k);
+      a.pt.p[fidx(g, a.pt, tile, i, j, k)] = tv_ad * dpk / den;
+      const double za = pt0 * tv_ad / den;
+      ws.at(SPK1, k + 1) += za; ws.at(SPK1, k) -= za;
+      const double zb = -(pt0 * dpk / den) * a.akap * tv_ad / den;
+      ws.at(SPN1, k + 1) += zb; ws.at(SPN1, k) -= zb;
+    }
+  }
+  // tracer maps (coordinates pe1 -> pe2)
+  for (int n = 0; n < a.nq; ++n) {
+    const Fld& qf = a.q[n];
+    for (int k = 0; k <= km + 1; ++k) { ws.at(S.SP1, k) = 0.; ws.at(S.SQ1, k) = 0.; ws.at(S.SP2, k) = 0.; }
+    auto q1 = [&](int k) { return qf.t[fidx(g, qf, tile, i, j, k)]; };
+    auto q2ad = [&](int k) { return qf.p[fidx(g, qf, tile, i, j, k)]; };
+    map_col_ad(km, pe1, q1, pe2, q2ad, ws, S);
+    for (int k = 1; k <= km; ++k) qf.p[fidx(g, qf, tile, i, j, k)] = ws.at(S.SQ1, k);
+    for (int k = 1; k <= km + 1; ++k) { ws.at(SPE1, k) += ws.at(S.SP1, k); ws.at(SPE2, k) += ws.at(S.SP2, k); }
+  }
+  // pk2 = exp(akap pn2), pn2 = log pe2 on interior interfaces; end levels pass through to pk1/pn1
+  for (int k = 2; k <= km; ++k) {
+    const double pn_ad = ws.at(SPN2, k) + a.akap * pk2(k) * ws.at(SPK2, k);
+    ws.at(SPE2, k) += pn_ad / pe2(k);
+  }
+  for (int k : {1, km + 1}) {   // end interfaces pass through: pk_out = pk1, peln_out = pn1
+    ws.at(SPN1, k) += ws.at(SPN2, k) + a.peln.p[fidx(g, a.peln, tile, i, j, k)];
+    ws.at(SPK1, k) += ws.at(SPK2, k) + a.pk.p[fidx(g, a.pk, tile, i, j, k)];
+  }
+  double ps_ad = ws.at(SPE2, km + 1);
+  for (int k = 2; k <= km; ++k) ps_ad += a.bk[k - 1] * ws.at(SPE2, k);
+  ws.at(SPE1, km + 1) += ps_ad;
+  // write back: pk.p / peln.p replaced by the input adjoints, pe.p accumulated
+  for (int k = 1; k <= km + 1; ++k) {
+    a.pk.p[fidx(g, a.pk, tile, i, j, k)] = ws.at(SPK1, k);
+    a.peln.p[fidx(g, a.peln, tile, i, j, k)] = ws.at(SPN1, k);
+    a.pe.p[fidx(g, a.pe, tile, i, j, k)] += ws.at(SPE1, k);
+  }
+}
+
+struct RemapScalFn {
+  RemapArgs a; int mode;
+  HD void operator()(int i, int j, int z) const {
+    const size_t col = (size_t)z * a.g.plane + a.g.idx(i, j);
+    if (mode == MODE_NL) remap_scalars_col<double>(a, i, j, z, col);
+    else if (mode == MODE_TL) remap_scalars_col<Dual>(a, i, j, z, col);
+    else remap_scalars_col_ad(a, i, j, z, col);
+  }
+};
+struct RemapWindFn {
+  RemapArgs a; int mode, dir;
+  HD void operator()(int i, int j, int z) const {
+    const size_t col = (size_t)z * a.g.plane + a.g.idx(i, j);
+    if (mode == MODE_NL) remap_wind_col<double>(a, dir, i, j, z, col);
+    else if (mode == MODE_TL) remap_wind_col<Dual>(a, dir, i, j, z, col);
+    else remap_wind_col_ad(a, dir, i, j, z, col);
+  }
+};
+struct RemapGatherFn {
+  RemapArgs a;
+  HD void operator()(int i, int j, int z) const { remap_pe_gather_ad(a, i, j, z); }
+};
+// pe(k) <- pe2(k), k = 2..km, on the compute domain (fv_mapz_tlm.F90:1944-1950)
+struct RemapPeFn {
+  RemapArgs a; int mode;
+  HD void operator()(int i, int j, int z) const {
+    for (int k = 2; k <= a.g.npz; ++k) {
+      const size_t n = fidx(a.g, a.pe, z, i, j, k);
+      a.pe.t[n] = a.pe2.t[n];
+      if (mode == MODE_TL) a.pe.p[n] = a.pe2.p[n];
+    }
+  }
+};
+
+// Workspace: 22 slots of (npz+2) doubles per column, columns = ntile*plane.
+constexpr int REMAP_WS_SLOTS = 22;
+inline void run_remap(Exec& ex, int mode, const RemapArgs& a) {
+  const Geom& g = a.g;
+  const Rect A{1, g.nx, 1, g.ny}, U{1, g.nx, 1, g.ny + 1}, V{1, g.nx + 1, 1, g.ny}, H{0, g.nx + 1, 0, g.ny + 1};
+  if (mode != MODE_AD) {
+    for_points(ex, A, g.ntile, RemapScalFn{a, mode});
+    for_points(ex, U, g.ntile, RemapWindFn{a, mode, 0});
+    for_points(ex, V, g.ntile, RemapWindFn{a, mode, 1});
+    for_points(ex, A, g.ntile, RemapPeFn{a, mode});
+  } else {
+    for_points(ex, V, g.ntile, RemapWindFn{a, mode, 1});
+    for_points(ex, U, g.ntile, RemapWindFn{a, mode, 0});
+    for_points(ex, H, g.ntile, RemapGatherFn{a});
+    for_points(ex, A, g.ntile, RemapScalFn{a, mode});
+  }
+}
+
+}  // namespace fv3

@@ -573,6 +573,61 @@ struct DswUpdateUV {
   }
 };
 
+// ===================================================================== tracer_2d (fv_tracer2d_tlm.F90:1148-1446)
+// accumulated Courant numbers -> area fluxes (:1226-1247)
+struct TrFlux {
+  STAGE_COMMON("TrFlux", 2, 2)   // in: cx cy   out: xfx yfx
+  HD static Box box(int) { return Box{0, 0, 0, 0, 0, 0}; }
+  template <class T, class A>
+  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+    o[0] = o[1] = T(0.);
+    if (orect[0].has(i, j)) {
+      T cx = a.template in<0>(i, j);
+      o[0] = (val(cx) > 0.) ? cx * MET(dxa, i - 1, j) * MET(dy, i, j) * SSG(3, i - 1, j) : cx * MET(dxa, i, j) * MET(dy, i, j) * SSG(1, i, j);
+    }
+    if (orect[1].has(i, j)) {
+      T cy = a.template in<1>(i, j);
+      o[1] = (val(cy) > 0.) ? cy * MET(dya, i, j - 1) * MET(dx, i, j) * SSG(4, i, j - 1) : cy * MET(dya, i, j) * MET(dx, i, j) * SSG(2, i, j);
+    }
+  }
+};
+// dp2 and the flux-form areas (:1375-1392)
+struct TrDp2Ra {
+  STAGE_COMMON("TrDp2Ra", 5, 3)   // in: dp1 mfx mfy xfx yfx   out: dp2 ra_x ra_y
+  HD static Box box(int M) { return M == 0 ? Box{0, 0, 0, 0, 0, 0} : (M == 1 || M == 3) ? Box{0, 1, 0, 0, 0, 0} : Box{0, 0, 0, 1, 0, 0}; }
+  template <class T, class A>
+  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+    o[0] = o[1] = o[2] = T(0.);
+    const double ar = MET(area, i, j);
+    if (orect[0].has(i, j))
+      o[0] = a.template in<0>(i, j) + (a.template in<1>(i, j) - a.template in<1>(i + 1, j) + (a.template in<2>(i, j) - a.template in<2>(i, j + 1))) * MET(rarea, i, j);
+    if (orect[1].has(i, j)) o[1] = ar + (a.template in<3>(i, j) - a.template in<3>(i + 1, j));
+    if (orect[2].has(i, j)) o[2] = ar + (a.template in<4>(i, j) - a.template in<4>(i, j + 1));
+  }
+};
+// q update (:1423-1430)
+struct TrUpdate {
+  STAGE_COMMON("TrUpdate", 5, 1)   // in: q dp1 dp2 fx fy   out: q_o
+  HD static Box box(int M) { return M == 3 ? Box{0, 1, 0, 0, 0, 0} : M == 4 ? Box{0, 0, 0, 1, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
+  template <class T, class A>
+  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+    o[0] = (a.template in<0>(i, j) * a.template in<1>(i, j) +
+            (a.template in<3>(i, j) - a.template in<3>(i + 1, j) + (a.template in<4>(i, j) - a.template in<4>(i, j + 1))) * MET(rarea, i, j)) /
+           a.template in<2>(i, j);
+  }
+};
+// pt <-> virtual potential temperature at the ends of fv_dynamics (fv_dynamics_tlm.F90:1395-1403)
+struct DynPtIn {
+  STAGE_COMMON("DynPtIn", 3, 1)   // in: pt(T) qv pkz   out: pt(theta_v)
+  double zvir; int has_q;
+  HD static Box box(int) { return Box{0, 0, 0, 0, 0, 0}; }
+  template <class T, class A>
+  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+    T d = has_q ? zvir * a.template in<1>(i, j) : T(0.);
+    o[0] = a.template in<0>(i, j) * (1. + d) / a.template in<2>(i, j);
+  }
+};
+
 // one_grad_p wind update from corner pk, gz (dyn_core_tlm.F90:4128-4157); level 1 of pk is the
 // constant top value (:4068-4072).
 struct OneGradP {

@@ -267,4 +267,55 @@ void orc_dyn_core(void* hv, int mode, double bdt, int n_split, double** in_t, do
   });
 }
 
+// tracer_2d.  in: dp1, mfx, mfy, cx, cy, q[nq]   out: q[nq]
+void orc_tracer_2d(void* hv, int mode, int nq, double** in_t, double** in_p, double** out_t, double** out_p) {
+  OrcHandle* h = (OrcHandle*)hv; int npz = h->npz;
+  std::vector<int> nk(5 + nq, npz), nko(nq, npz);
+  auto in = mkio(5 + nq, in_t, in_p, nk.data()); auto out = mkio(nq, out_t, out_p, nko.data());
+  drive(mode, h->bd, in, out, [&](auto& x, auto& y) {
+    using T = typename std::decay<decltype(x[0].p[0].d[0])>::type;
+    std::vector<Arr3<T>> q(nq);
+    for (int n = 0; n < nq; ++n) q[n] = x[5 + n];
+    tracer_2d(q, x[0], x[1], x[2], x[3], x[4], npz, h->o.hord_tr, h->g, h->bd);
+    for (int n = 0; n < nq; ++n) y[n] = q[n];
+  });
+}
+
+// Lagrangian_to_Eulerian.  in: pe, peln, pk (npz+1), pt, delp, u, v, q[nq]
+//                          out: pe, peln, pk (npz+1), pkz, pt, delp, u, v, q[nq]
+void orc_remap(void* hv, int mode, int nq, int last_step, double** in_t, double** in_p, double** out_t, double** out_p) {
+  OrcHandle* h = (OrcHandle*)hv; int npz = h->npz;
+  std::vector<int> nk(7 + nq, npz), nko(8 + nq, npz);
+  nk[0] = nk[1] = nk[2] = npz + 1; nko[0] = nko[1] = nko[2] = npz + 1;
+  auto in = mkio(7 + nq, in_t, in_p, nk.data()); auto out = mkio(8 + nq, out_t, out_p, nko.data());
+  drive(mode, h->bd, in, out, [&](auto& x, auto& y) {
+    using T = typename std::decay<decltype(x[0].p[0].d[0])>::type;
+    DynState<T> s; s.init(h->bd, npz, nq);
+    s.pe = x[0]; s.peln = x[1]; s.pk = x[2]; s.pt = x[3]; s.delp = x[4]; s.u = x[5]; s.v = x[6];
+    for (int n = 0; n < nq; ++n) s.q[n] = x[7 + n];
+    lagrangian_to_eulerian(last_step != 0, s, npz, h->c.akap, h->c.zvir, h->ptop, h->ak, h->bk, h->bd);
+    y[0] = s.pe; y[1] = s.peln; y[2] = s.pk; y[3] = s.pkz; y[4] = s.pt; y[5] = s.delp; y[6] = s.u; y[7] = s.v;
+    for (int n = 0; n < nq; ++n) y[8 + n] = s.q[n];
+  });
+}
+
+// fv_dynamics (k_split x (dyn_core, tracer_2d, remap)).  in: u, v, pt(=T), delp, pe, peln, pk (npz+1), pkz, q[nq]
+//                                                       out: u, v, pt(=T), delp, q[nq]
+void orc_fv_dynamics(void* hv, int mode, int nq, double bdt, int n_split, int k_split, double** in_t, double** in_p,
+                     double** out_t, double** out_p) {
+  OrcHandle* h = (OrcHandle*)hv; int npz = h->npz;
+  std::vector<int> nk(8 + nq, npz), nko(4 + nq, npz);
+  nk[4] = nk[5] = nk[6] = npz + 1;
+  auto in = mkio(8 + nq, in_t, in_p, nk.data()); auto out = mkio(4 + nq, out_t, out_p, nko.data());
+  drive(mode, h->bd, in, out, [&](auto& x, auto& y) {
+    using T = typename std::decay<decltype(x[0].p[0].d[0])>::type;
+    DynState<T> s; s.init(h->bd, npz, nq);
+    s.u = x[0]; s.v = x[1]; s.pt = x[2]; s.delp = x[3]; s.pe = x[4]; s.peln = x[5]; s.pk = x[6]; s.pkz = x[7];
+    for (int n = 0; n < nq; ++n) s.q[n] = x[8 + n];
+    fv_dynamics(s, h->phis, npz, bdt, n_split, k_split, h->o, h->c, h->ptop, h->ak, h->bk, h->g, h->bd);
+    y[0] = s.u; y[1] = s.v; y[2] = s.pt; y[3] = s.delp;
+    for (int n = 0; n < nq; ++n) y[4 + n] = s.q[n];
+  });
+}
+
 }  // extern "C"

@@ -1,7 +1,245 @@
-// TEST INFRASTRUCTURE — CPU oracle (see scalar.hpp).  fv_dynamics / tracer_2d / fv_mapz restatement.
+// TEST INFRASTRUCTURE — CPU oracle (see scalar.hpp).
+// Restatement of
+//   fv_tracer2d_tlm.F90  TRACER_2D (:1148-1446 / _TLM :757-1147), q_split=0, trdm=0
+//   fv_mapz_tlm.F90      LAGRANGIAN_TO_EULERIAN (:1361-2286 / _TLM :69-1360), hydrostatic,
+//                        remap_option=0 (T in log p), consv=0, no sat_adj, do_omega diagnostics
+//                        not restated; map_scalar (_TLM :7765), map1_ppm (_TLM :7909), map1_q2
+//                        (_TLM :8222), scalar_profile/cs_profile with |kord|>16 — the only profile
+//                        the TL/AD reference implements (_TLM :8356-8667)
+//   fv_dynamics_tlm.F90  FV_DYNAMICS (:999-1745 / _TLM :87-995), hydrostatic, adiabatic=.false.,
+//                        consv_te=0, tau=0, nwat<=1 (no fill2d), omega diagnostics not restated.
 #pragma once
 #include "dyn_core.hpp"
 
 namespace orc {
 struct RemapOpts { int kord_tm = -17, kord_mt = 17, kord_wz = 17, kord_tr = 17; };
+
+// scalar_profile / cs_profile, iv != -2, |kord| > 16 (fv_mapz_tlm.F90:8424-8509 == :8592-8666)
+template <class T>
+void cs_profile_linear(std::vector<T>& a1, std::vector<T>& a2, std::vector<T>& a3, std::vector<T>& a4,
+                       const std::vector<T>& delp, int km) {
+  std::vector<T> q(km + 2), gam(km + 1);
+  T grat = delp[2] / delp[1];
+  T bet = grat * (grat + 0.5);
+  q[1] = ((grat + grat) * (grat + 1.) * a1[1] + a1[2]) / bet;
+  gam[1] = (1. + grat * (grat + 1.5)) / bet;
+  T d4 = grat;
+  for (int k = 2; k <= km; ++k) {
+    d4 = delp[k - 1] / delp[k];
+    bet = 2. + d4 + d4 - gam[k - 1];
+    q[k] = (3. * (a1[k - 1] + d4 * a1[k]) - q[k - 1]) / bet;
+    gam[k] = d4 / bet;
+  }
+  T a_bot = 1. + d4 * (d4 + 1.5);
+  q[km + 1] = (2. * d4 * (d4 + 1.) * a1[km] + a1[km - 1] - a_bot * q[km]) / (d4 * (d4 + 0.5) - a_bot * gam[km]);
+  for (int k = km; k >= 1; --k) q[k] = q[k] - gam[k] * q[k + 1];
+  for (int k = 1; k <= km; ++k) {
+    a2[k] = q[k];
+    a3[k] = q[k + 1];
+    a4[k] = 3. * (2. * a1[k] - (a2[k] + a3[k]));
+  }
+}
+
+// One column of map_scalar / map1_ppm / map1_q2 (fv_mapz_tlm.F90:7812-7905): q1 on pe1 (km layers)
+// -> q2 on pe2 (kn layers).  1-based vectors.
+template <class T>
+void map_col(int km, const std::vector<T>& pe1, const std::vector<T>& q1, int kn, const std::vector<T>& pe2,
+             std::vector<T>& q2) {
+  const double r3 = 1. / 3., r23 = 2. / 3.;
+  std::vector<T> dp1(km + 1), a1(km + 1), a2(km + 1), a3(km + 1), a4(km + 1);
+  for (int k = 1; k <= km; ++k) { dp1[k] = pe1[k + 1] - pe1[k]; a1[k] = q1[k]; }
+  cs_profile_linear(a1, a2, a3, a4, dp1, km);
+  int k0 = 1;
+  T qsum = T(0.);
+  for (int k = 1; k <= kn; ++k) {
+    int l; bool found = false;
+    for (l = k0; l <= km; ++l)
+      if (val(pe2[k]) >= val(pe1[l]) && val(pe2[k]) <= val(pe1[l + 1])) { found = true; break; }
+    if (found) {
+      T pl = (pe2[k] - pe1[l]) / dp1[l];
+      if (val(pe2[k + 1]) <= val(pe1[l + 1])) {
+        T pr = (pe2[k + 1] - pe1[l]) / dp1[l];
+        q2[k] = a2[l] + 0.5 * (a4[l] + a3[l] - a2[l]) * (pr + pl) - a4[l] * r3 * (pr * (pr + pl) + pl * pl);
+        k0 = l;
+        continue;
+      }
+      qsum = (pe1[l + 1] - pe2[k]) * (a2[l] + 0.5 * (a4[l] + a3[l] - a2[l]) * (1. + pl) - a4[l] * (r3 * (1. + pl * (1. + pl))));
+      int m; bool bottom = false;
+      for (m = l + 1; m <= km; ++m) {
+        if (val(pe2[k + 1]) > val(pe1[m + 1])) qsum = qsum + dp1[m] * a1[m];
+        else { bottom = true; break; }
+      }
+      if (bottom) {
+        T dp = pe2[k + 1] - pe1[m];
+        T esl = dp / dp1[m];
+        qsum = qsum + dp * (a2[m] + 0.5 * esl * (a3[m] - a2[m] + a4[m] * (1. - r23 * esl)));
+        k0 = m;
+      }
+    }
+    q2[k] = qsum / (pe2[k + 1] - pe2[k]);
+  }
+}
+
+// tracer_2d, fv_tracer2d_tlm.F90:1148-1446 (q_split = 0, nord_tr/trdm = 0).  dp1 = delp before dyn_core.
+template <class T>
+void tracer_2d(std::vector<Arr3<T>>& q, Arr3<T>& dp1, Arr3<T>& mfx, Arr3<T>& mfy, Arr3<T>& cx, Arr3<T>& cy, int npz,
+               int hord, const Grid& g, const Bounds& bd) {
+  const int is = bd.is, ie = bd.ie, js = bd.js, je = bd.je, isd = bd.isd, ied = bd.ied, jsd = bd.jsd, jed = bd.jed;
+  const int nq = (int)q.size();
+  Arr3<T> xfx(bd, npz), yfx(bd, npz);
+  std::vector<double> cmax(npz + 1, 0.);
+  std::vector<int> ksplt(npz + 1, 1);
+  for (int k = 1; k <= npz; ++k) {
+    for (int j = jsd; j <= jed; ++j)
+      for (int i = is; i <= ie + 1; ++i) {
+        if (val(cx(i, j, k)) > 0.) xfx(i, j, k) = cx(i, j, k) * g.dxa(i - 1, j) * g.dy(i, j) * g.sin_sg[3](i - 1, j);
+        else                       xfx(i, j, k) = cx(i, j, k) * g.dxa(i, j) * g.dy(i, j) * g.sin_sg[1](i, j);
+      }
+    for (int j = js; j <= je + 1; ++j)
+      for (int i = isd; i <= ied; ++i) {
+        if (val(cy(i, j, k)) > 0.) yfx(i, j, k) = cy(i, j, k) * g.dya(i, j - 1) * g.dx(i, j) * g.sin_sg[4](i, j - 1);
+        else                       yfx(i, j, k) = cy(i, j, k) * g.dya(i, j) * g.dx(i, j) * g.sin_sg[2](i, j);
+      }
+    cmax[k] = 0.;
+    for (int j = js; j <= je; ++j)
+      for (int i = is; i <= ie; ++i) {
+        double ax = std::fabs(val(cx(i, j, k))), ay = std::fabs(val(cy(i, j, k)));
+        double c = (k < npz / 6) ? std::max(ax, ay) : std::max(ax, ay) + 1. - g.sin_sg[5](i, j);
+        if (cmax[k] < c) cmax[k] = c;
+      }
+  }
+  double c_global = cmax[1];
+  for (int k = 2; k <= npz; ++k) if (!(cmax[k] < c_global)) c_global = cmax[k];
+  const int nsplt = int(1. + c_global);
+  if (nsplt != 1)
+    for (int k = 1; k <= npz; ++k) {
+      ksplt[k] = int(1. + cmax[k]);
+      const double frac = 1. / double(ksplt[k]);
+      for (int j = jsd; j <= jed; ++j)
+        for (int i = is; i <= ie + 1; ++i) { cx(i, j, k) = cx(i, j, k) * frac; xfx(i, j, k) = xfx(i, j, k) * frac; }
+      for (int j = js; j <= je; ++j)
+        for (int i = is; i <= ie + 1; ++i) mfx(i, j, k) = mfx(i, j, k) * frac;
+      for (int j = js; j <= je + 1; ++j)
+        for (int i = isd; i <= ied; ++i) { cy(i, j, k) = cy(i, j, k) * frac; yfx(i, j, k) = yfx(i, j, k) * frac; }
+      for (int j = js; j <= je + 1; ++j)
+        for (int i = is; i <= ie; ++i) mfy(i, j, k) = mfy(i, j, k) * frac;
+    }
+  Arr2<T> dp2(bd), ra_x(bd), ra_y(bd), fx(bd), fy(bd);
+  for (int it = 1; it <= nsplt; ++it) {
+    for (int k = 1; k <= npz; ++k) {
+      if (it > ksplt[k]) continue;
+      for (int j = js; j <= je; ++j)
+        for (int i = is; i <= ie; ++i)
+          dp2(i, j) = dp1(i, j, k) + (mfx(i, j, k) - mfx(i + 1, j, k) + (mfy(i, j, k) - mfy(i, j + 1, k))) * g.rarea(i, j);
+      for (int j = jsd; j <= jed; ++j)
+        for (int i = is; i <= ie; ++i) ra_x(i, j) = g.area(i, j) + (xfx(i, j, k) - xfx(i + 1, j, k));
+      for (int j = js; j <= je; ++j)
+        for (int i = isd; i <= ied; ++i) ra_y(i, j) = g.area(i, j) + (yfx(i, j, k) - yfx(i, j + 1, k));
+      for (int iq = 0; iq < nq; ++iq) {
+        fv_tp_2d<T>(q[iq].plane(k), cx.plane(k), cy.plane(k), hord, fx, fy, xfx.plane(k), yfx.plane(k), g, bd, ra_x, ra_y,
+                    &mfx.plane(k), &mfy.plane(k), nullptr, -1, 0.0);
+        for (int j = js; j <= je; ++j)
+          for (int i = is; i <= ie; ++i)
+            q[iq](i, j, k) = (q[iq](i, j, k) * dp1(i, j, k) + (fx(i, j) - fx(i + 1, j) + (fy(i, j) - fy(i, j + 1))) * g.rarea(i, j)) / dp2(i, j);
+      }
+      if (it != nsplt)
+        for (int j = js; j <= je; ++j)
+          for (int i = is; i <= ie; ++i) dp1(i, j, k) = dp2(i, j);
+    }
+    if (it != nsplt) for (auto& qq : q) halo_periodic(qq, bd);
+  }
+}
+
+// Lagrangian_to_Eulerian, hydrostatic, remap_t (fv_mapz_tlm.F90:1586-1951, :2203-2250).
+// pe must be valid on is-1..ie+1, js-1..je+1 (old Lagrangian pressures); sphum = tracer 0.
+template <class T>
+void lagrangian_to_eulerian(bool last_step, DynState<T>& s, int km, double akap, double zvir, double ptop,
+                            const std::vector<double>& ak, const std::vector<double>& bk, const Bounds& bd) {
+  const int is = bd.is, ie = bd.ie, js = bd.js, je = bd.je;
+  const int nq = (int)s.q.size();
+  Arr3<T> pe2s(bd, km + 1);
+  std::vector<T> pe1(km + 2), pe2(km + 2), pn1(km + 2), pn2(km + 2), pk2(km + 2), q1(km + 1), q2(km + 1), pe0(km + 2), pe3(km + 2);
+  for (int j = js; j <= je + 1; ++j) {
+    if (j != je + 1)
+      for (int i = is; i <= ie; ++i) {
+        for (int k = 1; k <= km + 1; ++k) { pe1[k] = s.pe(i, j, k); pn1[k] = s.peln(i, j, k); }
+        pe2[1] = T(ptop); pe2[km + 1] = s.pe(i, j, km + 1);
+        for (int k = 1; k <= km; ++k)    // virtual pt -> virtual T (:1600-1606)
+          s.pt(i, j, k) = s.pt(i, j, k) * (s.pk(i, j, k + 1) - s.pk(i, j, k)) / (akap * (pn1[k + 1] - pn1[k]));
+        for (int k = 2; k <= km; ++k) pe2[k] = ak[k - 1] + bk[k - 1] * s.pe(i, j, km + 1);
+        for (int k = 1; k <= km; ++k) s.delp(i, j, k) = pe2[k + 1] - pe2[k];
+        pn2[1] = pn1[1]; pn2[km + 1] = pn1[km + 1]; pk2[1] = s.pk(i, j, 1); pk2[km + 1] = s.pk(i, j, km + 1);
+        for (int k = 2; k <= km; ++k) { pn2[k] = log(pe2[k]); pk2[k] = exp(akap * pn2[k]); }
+        for (int k = 1; k <= km; ++k) q1[k] = s.pt(i, j, k);
+        map_col(km, pn1, q1, km, pn2, q2);       // map_scalar in log p (:1676-1688)
+        for (int k = 1; k <= km; ++k) s.pt(i, j, k) = q2[k];
+        for (int iq = 0; iq < nq; ++iq) {        // map1_q2 (:1746-1763)
+          for (int k = 1; k <= km; ++k) q1[k] = s.q[iq](i, j, k);
+          map_col(km, pe1, q1, km, pe2, q2);
+          for (int k = 1; k <= km; ++k) s.q[iq](i, j, k) = q2[k];
+        }
+        for (int k = 1; k <= km + 1; ++k) { s.pk(i, j, k) = pk2[k]; s.peln(i, j, k) = pn2[k]; pe2s(i, j, k) = pe2[k]; }
+        for (int k = 1; k <= km; ++k) s.pkz(i, j, k) = (pk2[k + 1] - pk2[k]) / (akap * (pn2[k + 1] - pn2[k]));
+      }
+    // map u (:1884-1909)
+    for (int i = is; i <= ie; ++i) {
+      pe0[1] = s.pe(i, j, 1);
+      for (int k = 2; k <= km + 1; ++k) pe0[k] = 0.5 * (s.pe(i, j - 1, k) + s.pe(i, j, k));
+      for (int k = 1; k <= km + 1; ++k) pe3[k] = ak[k - 1] + (0.5 * bk[k - 1]) * (s.pe(i, j - 1, km + 1) + s.pe(i, j, km + 1));
+      for (int k = 1; k <= km; ++k) q1[k] = s.u(i, j, k);
+      map_col(km, pe0, q1, km, pe3, q2);
+      for (int k = 1; k <= km; ++k) s.u(i, j, k) = q2[k];
+    }
+    if (j < je + 1)     // map v (:1913-1934)
+      for (int i = is; i <= ie + 1; ++i) {
+        pe3[1] = T(ak[0]);
+        pe0[1] = s.pe(i, j, 1);
+        for (int k = 2; k <= km + 1; ++k) {
+          pe0[k] = 0.5 * (s.pe(i - 1, j, k) + s.pe(i, j, k));
+          pe3[k] = ak[k - 1] + (0.5 * bk[k - 1]) * (s.pe(i - 1, j, km + 1) + s.pe(i, j, km + 1));
+        }
+        for (int k = 1; k <= km; ++k) q1[k] = s.v(i, j, k);
+        map_col(km, pe0, q1, km, pe3, q2);
+        for (int k = 1; k <= km; ++k) s.v(i, j, k) = q2[k];
+      }
+  }
+  for (int k = 2; k <= km; ++k)      // :1944-1950
+    for (int j = js; j <= je; ++j)
+      for (int i = is; i <= ie; ++i) s.pe(i, j, k) = pe2s(i, j, k);
+  for (int k = 1; k <= km; ++k)      // :2203-2250 (dtmp = 0)
+    for (int j = js; j <= je; ++j)
+      for (int i = is; i <= ie; ++i) {
+        if (last_step) s.pt(i, j, k) = s.pt(i, j, k) / (1. + zvir * (nq > 0 ? s.q[0](i, j, k) : T(0.)));
+        else           s.pt(i, j, k) = s.pt(i, j, k) / s.pkz(i, j, k);
+      }
+}
+
+// fv_dynamics, hydrostatic (fv_dynamics_tlm.F90:1255-1262, :1395-1403, :1430-1680).  On entry pt is
+// temperature, pe/pk/peln/pkz consistent with delp (compute_fv3_pressures); on exit pt is temperature.
+template <class T>
+void fv_dynamics(DynState<T>& s, const Arr2<double>& phis, int npz, double bdt, int n_split, int k_split,
+                 const DampOpts& o, const Consts& c, double ptop, const std::vector<double>& ak,
+                 const std::vector<double>& bk, const Grid& g, const Bounds& bd) {
+  const int nq = (int)s.q.size();
+  Arr3<T> dp1(bd, npz);
+  for (int k = 1; k <= npz; ++k)
+    for (int j = bd.js; j <= bd.je; ++j)
+      for (int i = bd.is; i <= bd.ie; ++i) {
+        T d = (nq > 0) ? c.zvir * s.q[0](i, j, k) : T(0.);
+        s.pt(i, j, k) = s.pt(i, j, k) * (1. + d) / s.pkz(i, j, k);
+      }
+  const double mdt = bdt / double(k_split);
+  for (int n_map = 1; n_map <= k_split; ++n_map) {
+    halo_periodic(s.delp, bd); halo_periodic(s.pt, bd); halo_periodic(s.u, bd); halo_periodic(s.v, bd);
+    for (int k = 1; k <= npz; ++k) dp1.plane(k) = s.delp.plane(k);
+    const bool last_step = (n_map == k_split);
+    dyn_core(s, phis, npz, mdt, n_split, o, c, ptop, g, bd);
+    if (nq > 0) {
+      for (auto& qq : s.q) halo_periodic(qq, bd);     // dyn_core_tlm.F90:2452-2454 halo of q
+      tracer_2d(s.q, dp1, s.mfx, s.mfy, s.cx, s.cy, npz, o.hord_tr, g, bd);
+    }
+    if (npz > 4) lagrangian_to_eulerian(last_step, s, npz, c.akap, c.zvir, ptop, ak, bk, bd);
+  }
+}
+
 }  // namespace orc

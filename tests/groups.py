@@ -190,3 +190,182 @@ def dot_product_test(c, seed=3):
     c.dy.dyn_core(AD)
     rhs = sum(float(np.sum(c.dy.get(n, 1)[0] * c.pert[n][0])) for n in ins)
     return lhs, rhs
+
+
+# ------------------------------------------------------------------------------ fv_dynamics level
+def np_pressures(c, delp):
+    """compute_fv3_pressures (fv_pressure.F90:23-72) in numpy on the padded plane (all points)."""
+    k = c.opt.akap
+    pe = np.concatenate([np.full_like(delp[:1], c.opt.ptop), c.opt.ptop + np.cumsum(delp, axis=0)], axis=0)
+    peln = np.log(pe); pk = np.exp(k * peln)
+    pkz = (pk[1:] - pk[:-1]) / (k * (peln[1:] - peln[:-1]))
+    return pe, peln, pk, pkz
+
+
+def _dyn_outputs(c):
+    """oracle dyn_core (TL) from the case state: realistic mfx.., pe.., state after the acoustic steps."""
+    ins = ["u", "v", "pt", "delp"]
+    ot, op = c.oracle.dyn_core(TL, c.dims.dt / c.dims.k_split, c.dims.n_split, [c.traj[n][0] for n in ins], [c.pert[n][0] for n in ins])
+    names = ["u", "v", "pt", "delp", "mfx", "mfy", "cx", "cy", "pe", "peln", "pk", "pkz"]
+    return dict(zip(names, ot)), dict(zip(names, op))
+
+
+def check_tracer(c, mode, tol):
+    T, P = _dyn_outputs(c)
+    nq = c.nq
+    ins_n = ["dp1", "mfx", "mfy", "cx", "cy"] + ["q%d" % (n + 1) for n in range(nq)]
+    T["dp1"], P["dp1"] = c.traj["delp"][0], c.pert["delp"][0]
+    for n in range(nq):
+        T["q%d" % (n + 1)], P["q%d" % (n + 1)] = c.qtraj[n][0], c.qpert[n][0]
+    i_t = [T[n] for n in ins_n]; i_p = [P[n] for n in ins_n]
+    A = c.rect(*rects(c)["A"])
+    for n in ins_n:
+        c.dy.put(n, T[n][None], 0)
+    if mode == TL:
+        ot, op = c.oracle.tracer_2d(TL, nq, i_t, i_p)
+        for n in ins_n:
+            c.dy.put(n, P[n][None], 1)
+        c.dy.tracer_2d(TL)
+        for n in range(nq):
+            nm = "q%d" % (n + 1)
+            assert relerr(c.dy.get(nm, 0)[0][A], ot[n][A]) < tol, (nm, "traj")
+            assert relerr(c.dy.get(nm, 1)[0][A], op[n][A]) < tol, (nm, "tl")
+        return
+    rng = np.random.default_rng(21)
+    seeds = [masked(c, rng.standard_normal(T["dp1"].shape), "A") for _ in range(nq)]
+    _, iad = c.oracle.tracer_2d(AD, nq, i_t, None, seeds)
+    for n in ins_n:
+        c.dy.put(n, np.zeros(c.dy.shape(n)), 1)
+    for n in range(nq):
+        c.dy.put("q%d" % (n + 1), seeds[n][None], 1)
+    c.dy.tracer_2d(AD)
+    for n, a in zip(ins_n, iad):
+        e = relerr(c.dy.get(n, 1)[0], a)
+        assert e < tol, (n, "ad", e)
+
+
+def check_remap(c, mode, last_step, tol):
+    T, P = _dyn_outputs(c)
+    nq = c.nq
+    ins_n = ["pe", "peln", "pk", "pt", "delp", "u", "v"] + ["q%d" % (n + 1) for n in range(nq)]
+    for n in range(nq):
+        T["q%d" % (n + 1)], P["q%d" % (n + 1)] = c.qtraj[n][0], c.qpert[n][0]
+    # the oracle's pe is defined on 0..nx+1, peln/pk on the compute domain: zero the rest on both sides
+    for d in (T, P):
+        d["pe"] = masked(c, d["pe"], "Ah"); d["peln"] = masked(c, d["peln"], "A"); d["pk"] = masked(c, d["pk"], "A")
+    T["pe"] = np.where(T["pe"] == 0, 1.0, T["pe"]); T["peln"] = np.where(T["peln"] == 0, 1.0, T["peln"])
+    i_t = [T[n] for n in ins_n]; i_p = [P[n] for n in ins_n]
+    outs = [("pe", "A"), ("peln", "A"), ("pk", "A"), ("pkz", "A"), ("pt", "A"), ("delp", "A"), ("u", "U"), ("v", "V")] + \
+           [("q%d" % (n + 1), "A") for n in range(nq)]
+    for n in ins_n:
+        c.dy.put(n, T[n][None], 0)
+    if mode == TL:
+        ot, op = c.oracle.remap(TL, nq, last_step, i_t, i_p)
+        for n in ins_n:
+            c.dy.put(n, P[n][None], 1)
+        c.dy.remap(TL, last_step)
+        for (n, rk), a, b in zip(outs, ot, op):
+            r = c.rect(*rects(c)[rk])
+            e1, e2 = relerr(c.dy.get(n, 0)[0][r], a[r]), relerr(c.dy.get(n, 1)[0][r], b[r])
+            assert e1 < tol, (n, "traj", e1)
+            assert e2 < tol, (n, "tl", e2)
+        return
+    rng = np.random.default_rng(31)
+    seeds = []
+    for n, rk in outs:
+        s = masked(c, rng.standard_normal((c.dy.levels(n), c.ny + 7, c.nx + 7)), rk)
+        if n == "pe":
+            s[:] = 0.0       # pe after the remap is dead in fv_dynamics (overwritten by the next geopk)
+        seeds.append(s)
+    _, iad = c.oracle.remap(AD, nq, last_step, i_t, None, seeds)
+    for n in set(ins_n) | {o for o, _ in outs}:
+        c.dy.put(n, np.zeros(c.dy.shape(n)), 1)
+    for (n, rk), s in zip(outs, seeds):
+        c.dy.put(n, s[None], 1)
+    c.dy.remap(AD, last_step)
+    for n, a in zip(ins_n, iad):
+        e = relerr(c.dy.get(n, 1)[0], a)
+        assert e < tol, (n, "ad", e)
+
+
+def step_state(c):
+    """Temperature-based state as the L2 driver hands it over (pt = T), plus numpy pressures."""
+    pe, peln, pk, pkz = np_pressures(c, c.traj["delp"][0])
+    qv = c.qtraj[0][0] if c.nq else 0.0
+    Tt = c.traj["pt"][0] * pkz / (1.0 + c.opt.zvir * qv)
+    T = dict(u=c.traj["u"][0], v=c.traj["v"][0], pt=Tt, delp=c.traj["delp"][0], pe=pe, peln=peln, pk=pk, pkz=pkz)
+    P = dict(u=c.pert["u"][0], v=c.pert["v"][0], pt=20.0 * c.pert["pt"][0], delp=c.pert["delp"][0])
+    # TL of the pressures by finite... no: exact linearisation in numpy
+    k = c.opt.akap
+    pe_p = np.concatenate([np.zeros_like(P["delp"][:1]), np.cumsum(P["delp"], axis=0)], axis=0)
+    peln_p = pe_p / pe; pk_p = k * peln_p * pk
+    den = k * (peln[1:] - peln[:-1])
+    pkz_p = ((pk_p[1:] - pk_p[:-1]) * den - (pk[1:] - pk[:-1]) * k * (peln_p[1:] - peln_p[:-1])) / den ** 2
+    P.update(pe=pe_p, peln=peln_p, pk=pk_p, pkz=pkz_p)
+    for n in range(c.nq):
+        T["q%d" % (n + 1)], P["q%d" % (n + 1)] = c.qtraj[n][0], c.qpert[n][0]
+    return T, P
+
+
+def check_fv_dynamics(c, mode, tol):
+    T, P = step_state(c)
+    nq = c.nq
+    ins_n = ["u", "v", "pt", "delp", "pe", "peln", "pk", "pkz"] + ["q%d" % (n + 1) for n in range(nq)]
+    outs = [("u", "U"), ("v", "V"), ("pt", "A"), ("delp", "A")] + [("q%d" % (n + 1), "A") for n in range(nq)]
+    i_t = [T[n] for n in ins_n]; i_p = [P[n] for n in ins_n]
+    for n in ins_n:
+        c.dy.put(n, T[n][None], 0)
+    if mode == TL:
+        ot, op = c.oracle.fv_dynamics(TL, nq, c.dims.dt, c.dims.n_split, c.dims.k_split, i_t, i_p)
+        for n in ins_n:
+            c.dy.put(n, P[n][None], 1)
+        c.dy.fv_dynamics(TL)
+        worst = 0.0
+        for (n, rk), a, b in zip(outs, ot, op):
+            r = c.rect(*rects(c)[rk])
+            e1, e2 = relerr(c.dy.get(n, 0)[0][r], a[r]), relerr(c.dy.get(n, 1)[0][r], b[r])
+            assert e1 < tol, (n, "traj", e1)
+            assert e2 < tol, (n, "tl", e2)
+            worst = max(worst, e1, e2)
+        return worst
+    rng = np.random.default_rng(41)
+    seeds = [masked(c, rng.standard_normal(T["u"].shape), rk) for n, rk in outs]
+    _, iad = c.oracle.fv_dynamics(AD, nq, c.dims.dt, c.dims.n_split, c.dims.k_split, i_t, None, seeds)
+    c.dy.fv_dynamics(NL)
+    for n in ins_n:
+        c.dy.put(n, np.zeros(c.dy.shape(n)), 1)
+    for (n, rk), s in zip(outs, seeds):
+        c.dy.put(n, s[None], 1)
+    c.dy.fv_dynamics(AD)
+    worst = 0.0
+    for n, a in zip(ins_n, iad):
+        if n in ("pe", "peln", "pk"):
+            continue        # not used by the first dyn_core (geopk recomputes them): adjoint 0 on both sides
+        e = relerr(c.dy.get(n, 1)[0], a)
+        assert e < tol, (n, "ad", e)
+        worst = max(worst, e)
+    return worst
+
+
+def dot_product_step(c, seed=13):
+    """<M dx, dy> = <dx, M^T dy> for the complete dynamics step (step_tl / step_ad), the test the JEDI
+    LinearModel applies downstream.  x = (u, v, T, delp, q) on the compute domain."""
+    T, P = step_state(c)
+    names = ["u", "v", "pt", "delp"] + ["q%d" % (n + 1) for n in range(c.nq)]
+    rk = {"u": "U", "v": "V"}
+    rng = np.random.default_rng(seed)
+    dx = {n: masked(c, P[n], rk.get(n, "A")) for n in names}
+    for n in names:
+        c.dy.put(n, T[n][None], 0); c.dy.put(n, dx[n][None], 1)
+    c.dy.step_tl()
+    Mdx = {n: c.dy.get(n, 1)[0] for n in names}
+    dy = {n: masked(c, rng.standard_normal(Mdx[n].shape) * (1.0 / max(1e-30, np.abs(Mdx[n]).max())), rk.get(n, "A")) for n in names}
+    lhs = sum(float(np.sum(masked(c, Mdx[n], rk.get(n, "A")) * dy[n])) for n in names)
+    for n in names:
+        c.dy.put(n, T[n][None], 0)
+    c.dy.step_nl()
+    for n in names:
+        c.dy.put(n, dy[n][None], 1)
+    c.dy.step_ad()
+    rhs = sum(float(np.sum(c.dy.get(n, 1)[0] * dx[n])) for n in names)
+    return lhs, rhs

@@ -101,3 +101,15 @@ class Oracle:
     def fv_tp_2d(self, mode, hord, nord, damp_c, use_mf, use_mass, ins, ins_p=None, outs_p=None):
         return self._call("orc_fv_tp_2d", mode, [C.c_int(hord), C.c_int(nord), C.c_double(damp_c), C.c_int(use_mf),
                                                  C.c_int(use_mass)], ins, ins_p, [1, 1], outs_p)
+
+    def tracer_2d(self, mode, nq, ins, ins_p=None, outs_p=None):
+        return self._call("orc_tracer_2d", mode, [C.c_int(nq)], ins, ins_p, [self.npz] * nq, outs_p)
+
+    def remap(self, mode, nq, last_step, ins, ins_p=None, outs_p=None):
+        n = self.npz
+        return self._call("orc_remap", mode, [C.c_int(nq), C.c_int(int(last_step))], ins, ins_p,
+                          [n + 1, n + 1, n + 1] + [n] * (5 + nq), outs_p)
+
+    def fv_dynamics(self, mode, nq, bdt, n_split, k_split, ins, ins_p=None, outs_p=None):
+        return self._call("orc_fv_dynamics", mode, [C.c_int(nq), C.c_double(bdt), C.c_int(n_split), C.c_int(k_split)],
+                          ins, ins_p, [self.npz] * (4 + nq), outs_p)

@@ -68,3 +68,32 @@ def test_dyn_core_ad(case):
 def test_dot_product(case):
     lhs, rhs = dot_product_test(case)
     assert abs(lhs - rhs) <= 1e-12 * abs(lhs), (lhs, rhs)
+
+
+from groups import check_tracer, check_remap, check_fv_dynamics, dot_product_step
+
+
+@pytest.fixture(scope="module")
+def case_q():
+    return Case(nx=12, ny=10, npz=10, n_split=2, k_split=2, dt=1800.0, backend="emul", nq=3)
+
+
+@pytest.mark.parametrize("mode", [TL, AD])
+def test_tracer_2d(case_q, mode):
+    check_tracer(case_q, mode, 1e-11)
+
+
+@pytest.mark.parametrize("mode", [TL, AD])
+@pytest.mark.parametrize("last", [0, 1])
+def test_remap(case_q, mode, last):
+    check_remap(case_q, mode, last, 1e-11)
+
+
+@pytest.mark.parametrize("mode", [TL, AD])
+def test_fv_dynamics(case_q, mode):
+    check_fv_dynamics(case_q, mode, 1e-10)
+
+
+def test_dot_product_step(case_q):
+    lhs, rhs = dot_product_step(case_q)
+    assert abs(lhs - rhs) <= 1e-12 * abs(lhs), (lhs, rhs)

@@ -57,3 +57,44 @@ def test_dot_product_c48l72():
     c = Case(nx=48, ny=48, npz=72, n_split=6, dt=900.0, backend="hip", oracle=False)
     lhs, rhs = dot_product_test(c)
     assert abs(lhs - rhs) <= 1e-12 * abs(lhs), (lhs, rhs)
+
+
+@pytest.fixture(scope="module")
+def case_q():
+    from common import Case
+    return Case(nx=12, ny=10, npz=10, n_split=2, k_split=2, dt=1800.0, backend="hip", nq=3)
+
+
+@pytest.mark.parametrize("mode", [TL, AD])
+def test_tracer_2d(case_q, mode):
+    from groups import check_tracer
+    check_tracer(case_q, mode, 1e-11)
+
+
+@pytest.mark.parametrize("mode", [TL, AD])
+@pytest.mark.parametrize("last", [0, 1])
+def test_remap(case_q, mode, last):
+    from groups import check_remap
+    check_remap(case_q, mode, last, 1e-11)
+
+
+@pytest.mark.parametrize("mode", [TL, AD])
+def test_fv_dynamics(case_q, mode):
+    from groups import check_fv_dynamics
+    check_fv_dynamics(case_q, mode, 1e-10)
+
+
+def test_dot_product_step(case_q):
+    from groups import dot_product_step
+    lhs, rhs = dot_product_step(case_q)
+    assert abs(lhs - rhs) <= 1e-12 * abs(lhs), (lhs, rhs)
+
+
+def test_dot_product_step_c48l72():
+    """BASELINE config 2 (C48 L72 hydrostatic, 4 tracers, k_split 1, n_split 6, dt 900 s): the TL/AD
+    dot-product identity of the whole step at full size — a size-independent invariant."""
+    from common import Case
+    from groups import dot_product_step
+    c = Case(nx=48, ny=48, npz=72, n_split=6, k_split=1, dt=900.0, backend="hip", oracle=False, nq=4)
+    lhs, rhs = dot_product_step(c)
+    assert abs(lhs - rhs) <= 1e-12 * abs(lhs), (lhs, rhs)
