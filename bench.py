@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""bench.py — column-updates/s per TL+AD dynamics step (BASELINE.json metric) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over the resident synthetic state: one step_tl (tangent linear)
+plus one step_ad (nonlinear forward sweep with stage checkpoints + backward sweep), i.e. what the
+reference's %step_tl and %step_ad do for the dynamics (DYN/fv3jedi_lm_dynamics_mod.F90:347,460).
+Workload at N=1: one C192 L127 hydrostatic face (36,864 columns), k_split=2, n_split=6, dt=450 s,
+4 tracers, doubly-periodic tile (the 6-face cube exchange is not built yet — DESIGN.md §8); with N
+ranks every rank owns one such tile (weak scaling, no data-path collective).
+Extra objects on the JSON line: "roofline" (dominant kernel, HIP events on the library's own stream),
+"contract" (whole step against BASELINE.md §3's algorithmic bytes) and "cpu_baseline" (the oracle
+port timed on one host core on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
+
+
+def algorithmic_bytes(cells, k_split, n_split, nq):
+    """BASELINE.md §3 contract: B_TL = cells*k_split*(n_split*880 + (4nq+10)*8 + ((3+nq)*4+12)*8); B_TL+AD = 2.75 B_TL."""
+    b_tl = cells * k_split * (n_split * 880.0 + (4 * nq + 10) * 8.0 + ((3 + nq) * 4 + 12) * 8.0)
+    return 2.75 * b_tl
+
+
+def cpu_baseline(args, opt):
+    """Oracle port (oracle/liboracle.so, one host core) on a bounded sample of the same workload:
+    a 10x10-column tile with the same npz / k_split / n_split / nq."""
+    import numpy as np
+    from common import Case
+    from groups import step_state
+    from oracle import NL, TL, AD
+    nx = 10
+    c = Case(nx=nx, ny=nx, npz=args.npz, n_split=args.n_split, k_split=args.k_split, dt=args.dt, backend="none", nq=args.nq)
+    T, P = step_state(c)
+    ins_n = ["u", "v", "pt", "delp", "pe", "peln", "pk", "pkz"] + ["q%d" % (n + 1) for n in range(c.nq)]
+    i_t = [T[n] for n in ins_n]; i_p = [P[n] for n in ins_n]
+    t0 = time.time()
+    c.oracle.fv_dynamics(TL, c.nq, args.dt, args.n_split, args.k_split, i_t, i_p)
+    t_tl = time.time() - t0
+    seeds = [np.ones_like(T["u"]) for _ in range(4 + c.nq)]
+    t0 = time.time()
+    c.oracle.fv_dynamics(AD, c.nq, args.dt, args.n_split, args.k_split, i_t, None, seeds)   # taped forward + reverse
+    t_ad = time.time() - t0
+    return {"value": nx * nx / (t_tl + t_ad), "unit": "column-updates/s", "cores": 1, "kind": "port",
+            "sample": "oracle C++ port, %dx%d-column periodic tile, L%d, k_split=%d n_split=%d nq=%d: TL (dual numbers) %.2f s + "
+                      "AD (taped forward + reverse sweep) %.2f s" % (nx, nx, args.npz, args.k_split, args.n_split, args.nq, t_tl, t_ad)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nx", type=int, default=192)
+    ap.add_argument("--npz", type=int, default=127)
+    ap.add_argument("--k_split", type=int, default=2)
+    ap.add_argument("--n_split", type=int, default=6)
+    ap.add_argument("--dt", type=float, default=450.0)
+    ap.add_argument("--nq", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-out", default="")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    import ctypes as C
+    import fv3_jedi_linearmodel_amd as fv3
+    from common import Case
+    from groups import step_state
+    lib = fv3.load_hip_library()
+    lib.L.fv3lm_set_device(C.c_int(local))
+    c = Case(nx=args.nx, ny=args.nx, npz=args.npz, n_split=args.n_split, k_split=args.k_split, dt=args.dt, backend="hip",
+             oracle=False, nq=args.nq, seed=20250114 + rank)
+    T, P = step_state(c)
+    names = ["u", "v", "pt", "delp"] + ["q%d" % (n + 1) for n in range(c.nq)]
+    for n in names:
+        c.dy.put(n, T[n][None], 0); c.dy.put(n, P[n][None], 1)
+    c.dy.state_save()
+
+    def one_step():
+        c.dy.state_restore(); c.dy.step_tl()
+        c.dy.state_restore(); c.dy.step_nl(); c.dy.step_ad()
+
+    def barrier():
+        c.dy.sync()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        c.dy.sync()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    cols_rank = args.nx * args.nx
+    value = world * cols_rank / (elapsed / args.steps)
+
+    # roofline leg: per-kernel HIP-event durations on the library's stream over one more step
+    c.dy.profile_begin()
+    one_step()
+    prof = c.dy.profile_end()
+    if rank == 0:
+        dom = max(prof.items(), key=lambda kv: kv[1][1])
+        cnt, ms, by = dom[1]
+        achieved = (by / cnt) / (ms / cnt * 1e-3) / 1e9 if ms > 0 and by > 0 else 0.0
+        cells = cols_rank * args.npz
+        b_step = algorithmic_bytes(cells, args.k_split, args.n_split, args.nq)
+        contract_gbps = b_step / (ms_per_step * 1e-3) / 1e9
+        out = {
+            "metric": "column-updates/s per TL+AD dyn step", "value": value, "unit": "column-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C%dL%d hydrostatic TL+AD, 1 doubly-periodic tile (one cube face, %d columns) per GPU, "
+                                   "k_split=%d n_split=%d dt=%gs nq=%d, hord=2 (1 in the sponge), kord=17, nord=1"
+                                   % (args.nx, args.npz, cols_rank, args.k_split, args.n_split, args.dt, args.nq),
+                       "columns_per_gpu": cols_rank, "launches_per_step": sum(v[0] for v in prof.values())},
+            "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "launches_per_step": cnt, "avg_launch_ms": ms / cnt, "algorithmic_bytes_per_launch": by / cnt,
+                         "share_of_step_time": ms / sum(v[1] for v in prof.values())},
+            "contract": {"algorithmic_bytes_per_step": b_step, "achieved_GBps": contract_gbps, "frac": contract_gbps / HBM_PEAK_GBPS,
+                         "note": "whole TL+AD step against BASELINE.md §3 (2.75 x B_TL)"},
+        }
+        if args.profile_out:
+            with open(args.profile_out, "w") as f:
+                f.write("# per-kernel HIP-event profile of one TL+AD step (bench.py roofline leg)\n")
+                f.write("# kernel launches total_ms avg_ms algorithmic_GB achieved_GBps\n")
+                for k, (n_, m_, b_) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+                    f.write("%-22s %5d %10.3f %8.4f %9.3f %9.1f\n" % (k, n_, m_, m_ / n_, b_ / 1e9, (b_ / 1e9) / (m_ * 1e-3) if m_ > 0 else 0))
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, c.opt)
+            except Exception as e:   # the baseline leg must never hide the measurement
+                out["cpu_baseline"] = {"value": None, "unit": "column-updates/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

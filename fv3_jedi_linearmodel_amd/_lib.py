@@ -153,6 +153,29 @@ class Dycore:
         role: nonlinear sweep storing the stage checkpoints)."""
         self._chk(self.lib.L.fv3lm_step_ad(self.h))
 
+    def state_save(self):
+        self.lib.L.fv3lm_state_save.argtypes = [C.c_void_p]
+        self._chk(self.lib.L.fv3lm_state_save(self.h))
+
+    def state_restore(self):
+        self.lib.L.fv3lm_state_restore.argtypes = [C.c_void_p]
+        self._chk(self.lib.L.fv3lm_state_restore(self.h))
+
+    def profile_begin(self):
+        self.lib.L.fv3lm_profile_begin.argtypes = [C.c_void_p]
+        self.lib.L.fv3lm_profile_begin(self.h)
+
+    def profile_end(self):
+        """-> {kernel: (launches, total_ms, algorithmic_bytes)} measured with HIP events on the library stream."""
+        self.lib.L.fv3lm_profile_end.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        buf = C.create_string_buffer(1 << 16)
+        self.lib.L.fv3lm_profile_end(self.h, buf, len(buf))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            n, cnt, ms, by = line.split()
+            out[n] = (int(float(cnt)), float(ms), float(by))
+        return out
+
     def zero_work_adjoint(self):
         self.lib.L.fv3lm_zero_work_adjoint(self.h)
 

@@ -89,7 +89,12 @@ struct GeopkFn {
     else geopk_col_ad(a, i, j, z);
   }
 };
-inline void run_geopk(Exec& ex, int mode, const GeopkArgs& a) { for_points(ex, a.R, a.g.ntile, GeopkFn{a, mode}); }
+inline void run_geopk(Exec& ex, int mode, const GeopkArgs& a) {
+  // algorithmic bytes: delp, pt in; pe, peln, pk, gz (+pkz) out; x2 for TL; adjoint reads/updates the same set
+  const double cells = double(a.R.i1 - a.R.i0 + 1) * (a.R.j1 - a.R.j0 + 1) * a.g.ntile * a.g.npz;
+  const double per = (a.cg ? 6. : 7.) * (mode == MODE_NL ? 1. : mode == MODE_TL ? 2. : 3.);
+  for_points(ex, a.R, a.g.ntile, GeopkFn{a, mode}, mode == MODE_AD ? "geopk.ad" : mode == MODE_TL ? "geopk.tl" : "geopk.nl", 8. * per * cells);
+}
 
 // ---------------------------------------------------------------- doubly-periodic halo fill
 // Every point of the padded plane outside 1..nx x 1..ny takes the value of its periodic image
@@ -134,10 +139,10 @@ inline void run_halo(Exec& ex, int mode, const Geom& g, const Fld& f) {
   const Rect full{g.isd(), g.ied() + 1, g.jsd(), g.jed() + 1}, inner{1, g.nx, 1, g.ny};
   const int nz = g.ntile * f.nk;
   if (mode == MODE_AD) {
-    for_points(ex, inner, nz, HaloAdGatherFn{g, f});
-    for_points(ex, full, nz, HaloAdZeroFn{g, f});
+    for_points(ex, inner, nz, HaloAdGatherFn{g, f}, "halo.ad");
+    for_points(ex, full, nz, HaloAdZeroFn{g, f}, "halo.ad");
   } else {
-    for_points(ex, full, nz, HaloFn{g, f, mode});
+    for_points(ex, full, nz, HaloFn{g, f, mode}, "halo");
   }
 }
 
@@ -152,7 +157,7 @@ struct AccumFn {
   }
 };
 inline void run_accum(Exec& ex, int mode, const Geom& g, const Fld& acc, const Fld& x, const Rect& R) {
-  for_points(ex, R, g.ntile * acc.nk, AccumFn{g, acc, x, mode});
+  for_points(ex, R, g.ntile * acc.nk, AccumFn{g, acc, x, mode}, "accum");
 }
 
 // ---------------------------------------------------------------- plane copy of the interior+everything (state hand-over)
@@ -166,7 +171,7 @@ struct CopyFn {
 };
 inline void run_copy(Exec& ex, const Geom& g, const Fld& dst, const Fld& src, int what) {
   const Rect full{g.isd(), g.ied() + 1, g.jsd(), g.jed() + 1};
-  for_points(ex, full, g.ntile * dst.nk, CopyFn{g, dst, src, what});
+  for_points(ex, full, g.ntile * dst.nk, CopyFn{g, dst, src, what}, "copy");
 }
 
 }  // namespace fv3

@@ -52,19 +52,23 @@ struct PressFn {
 
 // max Courant number per level (fv_tracer2d_tlm.F90:1248-1305); trajectory only.
 struct CmaxFn {
-  Geom g; Fld cx, cy; const double* sin5; double* out;   // out[ntile*npz]
-  HD void operator()(int, int, int z) const {              // one thread per (tile, level): tiny reduction
+  Geom g; Fld cx, cy; const double* sin5; double* out;   // out[ntile*npz], zeroed before the launch
+  HD void operator()(int i, int, int z) const {            // one thread per (i, tile, level): column over j, coalesced in i
     const int tile = z / g.npz, k = 1 + z % g.npz;
     double cm = 0.;
-    for (int j = 1; j <= g.ny; ++j)
-      for (int i = 1; i <= g.nx; ++i) {
-        const size_t n = (size_t)z * g.plane + g.idx(i, j);
-        double ax = fabs(cx.t[n]), ay = fabs(cy.t[n]);
-        double c = ax > ay ? ax : ay;
-        if (!(k < g.npz / 6)) c += 1. - sin5[(size_t)tile * g.plane + g.idx(i, j)];
-        if (cm < c) cm = c;
-      }
-    out[z] = cm;
+    for (int j = 1; j <= g.ny; ++j) {
+      const size_t n = (size_t)z * g.plane + g.idx(i, j);
+      double ax = fabs(cx.t[n]), ay = fabs(cy.t[n]);
+      double c = ax > ay ? ax : ay;
+      if (!(k < g.npz / 6)) c += 1. - sin5[(size_t)tile * g.plane + g.idx(i, j)];
+      if (cm < c) cm = c;
+    }
+#ifdef FV3LM_HOST_EMUL
+    if (out[z] < cm) out[z] = cm;
+#else
+    // non-negative doubles order like their bit patterns
+    atomicMax(reinterpret_cast<unsigned long long*>(&out[z]), (unsigned long long)__double_as_longlong(cm));
+#endif
   }
 };
 
@@ -79,6 +83,7 @@ struct Dynamics : Dycore {
   size_t ck_k_stride = 0;
   int nsplt_max = 1;
   bool tracer_subcycle_error = false;
+  std::vector<double*> snap;   // device snapshot of the prognostic state (fv3lm_state_save)
 
   bool init2(const double* ak, const double* bk);
   void destroy2();
@@ -123,6 +128,7 @@ inline bool Dynamics::init2(const double* ak, const double* bk) {
 inline void Dynamics::destroy2() {
   dev_free(ak_dev); dev_free(bk_dev); dev_free(remap_ws); dev_free(cmax_dev); dev_free(ck_k); dev_free(ck_0);
   tshared.destroy(); twork.destroy();
+  for (double* p : snap) dev_free(p);
 }
 
 inline void Dynamics::build_tracer() {
@@ -154,7 +160,7 @@ inline RemapArgs Dynamics::remap_args(bool last_step) {
 
 inline void Dynamics::pressures(int mode) {
   PressArgs a{g, f("delp"), f("pe"), f("peln"), f("pk"), f("pkz"), opt.akap, opt.ptop};
-  for_points(ex, Rect{1, g.nx, 1, g.ny}, g.ntile, PressFn{a, mode});
+  for_points(ex, Rect{1, g.nx, 1, g.ny}, g.ntile, PressFn{a, mode}, "pressures");
 }
 
 // tracer_2d forward (nonlinear or tangent); q halos must be valid
@@ -162,7 +168,8 @@ inline void Dynamics::tracer_fwd(int mode) {
   const size_t b3 = n3 * 8;
   run_group(tracer_pre, nullptr, mode);
   if (mode == MODE_NL || mode == MODE_TL) {   // nsplt from the trajectory's max Courant number
-    for_points(ex, Rect{1, 1, 1, 1}, g.ntile * g.npz, CmaxFn{g, f("cx"), f("cy"), ctx.m.sin_sg[5], cmax_dev});
+    dev_zero(ex, cmax_dev, (size_t)g.ntile * g.npz * 8);
+    for_points(ex, Rect{1, g.nx, 1, 1}, g.ntile * g.npz, CmaxFn{g, f("cx"), f("cy"), ctx.m.sin_sg[5], cmax_dev}, "tracer_cmax");
     std::vector<double> cm((size_t)g.ntile * g.npz);
     d2h(ex, cm.data(), cmax_dev, cm.size() * 8);
     double cg = 0.; for (double c : cm) if (!(c < cg)) cg = c;
@@ -255,7 +262,7 @@ inline void Dynamics::fv_dynamics(int mode) {
     }
     ck_base = km * n_split;
     dyn_core(MODE_AD);
-    for_points(ex, Rect{g.isd(), g.ied() + 1, g.jsd(), g.jed() + 1}, g.ntile * g.npz, AccumFn{g, dp1, f("delp"), MODE_AD});   // delp.p += dp1.p
+    for_points(ex, Rect{g.isd(), g.ied() + 1, g.jsd(), g.jed() + 1}, g.ntile * g.npz, AccumFn{g, dp1, f("delp"), MODE_AD}, "accum");   // delp.p += dp1.p
     for (const char* n : st4) run_halo(ex, MODE_AD, g, f(n));
   }
   // pt_in: pt(theta_v) = T (1 + zvir qv) / pkz

@@ -7,15 +7,41 @@
 // one level stay together in an XCD's L2 while the stencil rows are re-read.
 #pragma once
 #include "core.h"
+#include <string>
+#include <vector>
 
 namespace fv3 {
 
+// Per-kernel measurement: HIP events recorded on the library's own stream around every launch while
+// profiling is on (bench.py's roofline leg), aggregated by kernel name together with the algorithmic
+// bytes of each launch (compulsory reads+writes of the launch's fields).
+struct ProfRec { std::string name; double bytes; 
+#ifndef FV3LM_HOST_EMUL
+  hipEvent_t e0, e1;
+#endif
+};
 struct Exec {
 #ifndef FV3LM_HOST_EMUL
   hipStream_t stream = nullptr;
 #endif
   bool check_boxes = false;   // host emulation only: verify declared stencil boxes
   long launches = 0;
+  bool profiling = false;
+  std::vector<ProfRec> recs;
+  void mark_begin(const char* name, const char* suffix, double bytes) {
+    if (!profiling) return;
+    ProfRec r; r.name = std::string(name) + suffix; r.bytes = bytes;
+#ifndef FV3LM_HOST_EMUL
+    (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1); (void)hipEventRecord(r.e0, stream);
+#endif
+    recs.push_back(r);
+  }
+  void mark_end() {
+    if (!profiling) return;
+#ifndef FV3LM_HOST_EMUL
+    (void)hipEventRecord(recs.back().e1, stream);
+#endif
+  }
 };
 
 HD Rect rect_union(const Rect* r, int n) {
@@ -110,6 +136,19 @@ inline Rect ad_input_rect(const S& s, const Ctx& c, const Rect& R) {
   return q;
 }
 
+enum Mode { MODE_NL = 0, MODE_TL = 1, MODE_AD = 2 };
+// Algorithmic bytes of one stage launch: every active input read once, every output written once
+// (trajectory; + perturbation in TL; adjoint: trajectory inputs + output adjoints read, input adjoints
+// read-modify-written), 8 B each, over the launch's cells.
+template <class S>
+inline double stage_bytes(const S& s, const Ctx& c, const Rect& R, int mode) {
+  const double cells = double(R.i1 - R.i0 + 1) * double(R.j1 - R.j0 + 1) * c.g.ntile * (s.k1 - s.k0 + 1);
+  int nin = 0;
+  for (int m = 0; m < S::NIN; ++m) if (s.in[m].t) nin++;
+  const double per = mode == MODE_NL ? nin + S::NOUT : mode == MODE_TL ? 2. * (nin + S::NOUT) : (nin + S::NOUT + 2. * nin);
+  return 8. * per * cells;
+}
+
 #ifndef FV3LM_HOST_EMUL
 // ---- HIP kernels ---------------------------------------------------------------------------
 constexpr int BX = 64, BY = 4;
@@ -134,13 +173,17 @@ inline dim3 grid_for(const Rect& R, int nz) {
 template <class S>
 void run_nl(Exec& ex, const S& s, const Ctx& c) {
   Rect R = rect_union(s.orect, S::NOUT);
+  ex.mark_begin(S::name(), ".nl", stage_bytes(s, c, R, MODE_NL));
   hipLaunchKernelGGL(k_stage_nl<S>, grid_for(R, c.g.ntile * (s.k1 - s.k0 + 1)), dim3(BX, BY), 0, ex.stream, s, c, R);
+  ex.mark_end();
   ex.launches++;
 }
 template <class S>
 void run_tl(Exec& ex, const S& s, const Ctx& c) {
   Rect R = rect_union(s.orect, S::NOUT);
+  ex.mark_begin(S::name(), ".tl", stage_bytes(s, c, R, MODE_TL));
   hipLaunchKernelGGL(k_stage_tl<S>, grid_for(R, c.g.ntile * (s.k1 - s.k0 + 1)), dim3(BX, BY), 0, ex.stream, s, c, R);
+  ex.mark_end();
   ex.launches++;
 }
 template <class S>
@@ -149,7 +192,9 @@ void run_ad(Exec& ex, const S& s, const Ctx& c) {
   Rect Q = ad_input_rect(s, c, R);
   int nkmax = 0;
   for (int m = 0; m < S::NIN; ++m) if (s.in[m].nk > nkmax) nkmax = s.in[m].nk;
+  ex.mark_begin(S::name(), ".ad", stage_bytes(s, c, R, MODE_AD));
   hipLaunchKernelGGL(k_stage_ad<S>, grid_for(Q, c.g.ntile * nkmax), dim3(BX, BY), 0, ex.stream, s, c, R, Q, nkmax);
+  ex.mark_end();
   ex.launches++;
 }
 // generic per-point functor launch: f(i, j, z)
@@ -159,9 +204,11 @@ __global__ void __launch_bounds__(BX* BY) k_points(F f, Rect R) {
   if (i <= R.i1 && j <= R.j1) f(i, j, (int)blockIdx.z);
 }
 template <class F>
-void for_points(Exec& ex, const Rect& R, int nz, const F& f) {
+void for_points(Exec& ex, const Rect& R, int nz, const F& f, const char* tag = "points", double bytes = 0.) {
   if (nz <= 0) return;
+  ex.mark_begin(tag, "", bytes);
   hipLaunchKernelGGL(k_points<F>, grid_for(R, nz), dim3(BX, BY), 0, ex.stream, f, R);
+  ex.mark_end();
   ex.launches++;
 }
 #else
@@ -202,7 +249,7 @@ void run_ad(Exec& ex, const S& s, const Ctx& c) {
   ex.launches++;
 }
 template <class F>
-void for_points(Exec& ex, const Rect& R, int nz, const F& f) {
+void for_points(Exec& ex, const Rect& R, int nz, const F& f, const char* tag = "points", double bytes = 0.) {
   for (int z = 0; z < nz; ++z)
     for (int j = R.j0; j <= R.j1; ++j)
       for (int i = R.i0; i <= R.i1; ++i) f(i, j, z);
@@ -210,7 +257,6 @@ void for_points(Exec& ex, const Rect& R, int nz, const F& f) {
 }
 #endif
 
-enum Mode { MODE_NL = 0, MODE_TL = 1, MODE_AD = 2 };
 template <class S>
 void run(Exec& ex, int mode, const S& s, const Ctx& c) {
   if (mode == MODE_NL) run_nl(ex, s, c);

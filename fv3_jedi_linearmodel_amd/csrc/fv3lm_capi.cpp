@@ -3,6 +3,7 @@
 // `g++ -DFV3LM_HOST_EMUL` into tests/_emul/libfv3lm_emul.so (test-only host emulation, never
 // loaded by the package).
 #include "dynamics.h"
+#include <array>
 #include <string>
 
 using namespace fv3;
@@ -94,6 +95,47 @@ int fv3lm_level_params(fv3lm_handle* h, int k, int* ip, double* rp) {
   ip[5] = l.nord; ip[6] = l.nord_v; ip[7] = l.nord_w; ip[8] = l.nord_t; ip[9] = l.nord_v_pert;
   rp[0] = l.d2_divg; rp[1] = l.damp_vt; rp[2] = l.damp_w; rp[3] = l.damp_t; rp[4] = l.d_con; rp[5] = l.damp_vt_pert;
   return 0;
+}
+// Device selection for one-process-per-GPU launches (call before fv3lm_create).
+int fv3lm_set_device(int dev) {
+#ifndef FV3LM_HOST_EMUL
+  if (hipSetDevice(dev) != hipSuccess) return fail("hipSetDevice failed");
+#endif
+  (void)dev; return 0;
+}
+// Device-side snapshot / restore of the prognostic state (trajectory and perturbation of u v pt delp q*).
+int fv3lm_state_save(fv3lm_handle* h) {
+  Dynamics& d = h->d; std::vector<Fld> fs{d.f("u"), d.f("v"), d.f("pt"), d.f("delp")};
+  for (auto& q : d.q) fs.push_back(q);
+  if (d.snap.size() != fs.size() * 2) { for (double* p : d.snap) dev_free(p); d.snap.clear(); for (size_t n = 0; n < fs.size() * 2; ++n) d.snap.push_back((double*)dev_alloc(d.n3 * 8)); }
+  for (size_t n = 0; n < fs.size(); ++n) { dev_copy(d.ex, d.snap[2 * n], fs[n].t, d.n3 * 8); dev_copy(d.ex, d.snap[2 * n + 1], fs[n].p, d.n3 * 8); }
+  return 0;
+}
+int fv3lm_state_restore(fv3lm_handle* h) {
+  Dynamics& d = h->d; std::vector<Fld> fs{d.f("u"), d.f("v"), d.f("pt"), d.f("delp")};
+  for (auto& q : d.q) fs.push_back(q);
+  if (d.snap.size() != fs.size() * 2) return fail("fv3lm_state_restore: no snapshot");
+  for (size_t n = 0; n < fs.size(); ++n) { dev_copy(d.ex, fs[n].t, d.snap[2 * n], d.n3 * 8); dev_copy(d.ex, fs[n].p, d.snap[2 * n + 1], d.n3 * 8); }
+  return 0;
+}
+// Per-kernel HIP-event profile of everything launched between begin and end (bench.py roofline leg).
+// end() writes lines "name count total_ms total_algorithmic_bytes" into buf and returns the length needed.
+int fv3lm_profile_begin(fv3lm_handle* h) { h->d.ex.recs.clear(); h->d.ex.profiling = true; return 0; }
+int fv3lm_profile_end(fv3lm_handle* h, char* buf, int buflen) {
+  Exec& ex = h->d.ex; ex.profiling = false; dev_sync(ex);
+  std::map<std::string, std::array<double, 3>> agg;
+  for (ProfRec& r : ex.recs) {
+    float ms = 0.f;
+#ifndef FV3LM_HOST_EMUL
+    (void)hipEventElapsedTime(&ms, r.e0, r.e1); (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+#endif
+    auto& a = agg[r.name]; a[0] += 1.; a[1] += ms; a[2] += r.bytes;
+  }
+  ex.recs.clear();
+  std::string out;
+  for (auto& kv : agg) { char line[256]; std::snprintf(line, sizeof line, "%s %.0f %.6f %.0f\n", kv.first.c_str(), kv.second[0], kv.second[1], kv.second[2]); out += line; }
+  if (buf && buflen > 0) { std::strncpy(buf, out.c_str(), buflen - 1); buf[buflen - 1] = 0; }
+  return (int)out.size() + 1;
 }
 #ifdef FV3LM_HOST_EMUL
 int fv3lm_emul_check_boxes(fv3lm_handle* h, int on) { h->d.ex.check_boxes = on != 0; return 0; }

@@ -520,15 +520,18 @@ inline void run_remap(Exec& ex, int mode, const RemapArgs& a) {
   const Geom& g = a.g;
   const Rect A{1, g.nx, 1, g.ny}, U{1, g.nx, 1, g.ny + 1}, V{1, g.nx + 1, 1, g.ny}, H{0, g.nx + 1, 0, g.ny + 1};
   if (mode != MODE_AD) {
-    for_points(ex, A, g.ntile, RemapScalFn{a, mode});
-    for_points(ex, U, g.ntile, RemapWindFn{a, mode, 0});
-    for_points(ex, V, g.ntile, RemapWindFn{a, mode, 1});
-    for_points(ex, A, g.ntile, RemapPeFn{a, mode});
+    const double cells = double(g.nx) * g.ny * g.ntile * g.npz, w = mode == MODE_TL ? 2. : 1.;
+    // algorithmic bytes: scalars read pe,peln,pk,pt,q[nq]; write pt,q[nq],delp,pk,peln,pkz,pe2; winds read pe x2, u|v; write u|v
+    for_points(ex, A, g.ntile, RemapScalFn{a, mode}, mode == MODE_TL ? "remap_scalars.tl" : "remap_scalars.nl", 8. * w * (10. + 2. * a.nq) * cells);
+    for_points(ex, U, g.ntile, RemapWindFn{a, mode, 0}, mode == MODE_TL ? "remap_wind.tl" : "remap_wind.nl", 8. * w * 4. * cells);
+    for_points(ex, V, g.ntile, RemapWindFn{a, mode, 1}, mode == MODE_TL ? "remap_wind.tl" : "remap_wind.nl", 8. * w * 4. * cells);
+    for_points(ex, A, g.ntile, RemapPeFn{a, mode}, "remap_pe");
   } else {
-    for_points(ex, V, g.ntile, RemapWindFn{a, mode, 1});
-    for_points(ex, U, g.ntile, RemapWindFn{a, mode, 0});
-    for_points(ex, H, g.ntile, RemapGatherFn{a});
-    for_points(ex, A, g.ntile, RemapScalFn{a, mode});
+    const double cells = double(g.nx) * g.ny * g.ntile * g.npz;
+    for_points(ex, V, g.ntile, RemapWindFn{a, mode, 1}, "remap_wind.ad", 8. * 7. * cells);
+    for_points(ex, U, g.ntile, RemapWindFn{a, mode, 0}, "remap_wind.ad", 8. * 7. * cells);
+    for_points(ex, H, g.ntile, RemapGatherFn{a}, "remap_gather.ad", 8. * 4. * cells);
+    for_points(ex, A, g.ntile, RemapScalFn{a, mode}, "remap_scalars.ad", 8. * (16. + 3. * a.nq) * cells);
   }
 }
 

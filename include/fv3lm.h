@@ -82,6 +82,29 @@ int fv3lm_run_group(fv3lm_handle* h, const char* group, int mode);  /* one kerne
      "c_sw" (C_SW_TLM sw_core_tlm.F90:87), "geopk_c"/"geopk_d" (GEOPK_TLM dyn_core_tlm.F90:4578),
      "p_grad_c" (:3194), "d_sw" (D_SW_TLM sw_core_tlm.F90:1047), "one_grad_p" (:3867), "halo_*" */
 int fv3lm_dyn_core(fv3lm_handle* h, int mode);   /* DYN_CORE_TLM dyn_core_tlm.F90:93 / DYN_CORE_FWD+BWD dyn_core_adm.F90:115,1686 */
+/* The operator itself.  State fields u v pt(=temperature) delp q1..qn are device-resident (fv3lm_field_put /
+ * _get; compute domain is..ie x js..je, D-grid winds incl. the far edge row/column).
+ *  fv3lm_step_tl : replaces compute_fv3_pressures_tlm + FV_DYNAMICS_TLM in %step_tl
+ *                  (DYN/fv3jedi_lm_dynamics_mod.F90:404-438).  In: trajectory (which=0) and perturbation
+ *                  (which=1) at t; out: both advanced to t+dt.
+ *  fv3lm_step_nl : nonlinear sweep that also stores the stage checkpoints (FV_DYNAMICS_FWD role, :507).
+ *  fv3lm_step_ad : FV_DYNAMICS_BWD + compute_fv3_pressures_bwd (:615-638); call after fv3lm_step_nl on the
+ *                  same trajectory.  In: adjoint of the state at t+dt (which=1); out: adjoint at t. */
+int fv3lm_step_tl(fv3lm_handle* h);
+int fv3lm_step_nl(fv3lm_handle* h);
+int fv3lm_step_ad(fv3lm_handle* h);
+/* Sub-operators, same mode argument (tests and kernel-level benchmarks): */
+int fv3lm_pressures(fv3lm_handle* h, int mode);                 /* compute_fv3_pressures{,_tlm,_bwd} TLM/fv_pressure.F90 */
+int fv3lm_tracer_2d(fv3lm_handle* h, int mode);                 /* TRACER_2D_TLM fv_tracer2d_tlm.F90:757 / _FWD+_BWD */
+int fv3lm_remap(fv3lm_handle* h, int mode, int last_step);      /* LAGRANGIAN_TO_EULERIAN_TLM fv_mapz_tlm.F90:69 / _FWD+_BWD */
+int fv3lm_fv_dynamics(fv3lm_handle* h, int mode);               /* FV_DYNAMICS_TLM fv_dynamics_tlm.F90:87 / _FWD+_BWD */
+/* Per-kernel HIP-event profile of everything launched between begin and end, on the library's stream:
+ * lines "kernel count total_ms algorithmic_bytes".  Returns the buffer length needed. */
+int fv3lm_profile_begin(fv3lm_handle* h);
+int fv3lm_profile_end(fv3lm_handle* h, char* buf, int buflen);
+int fv3lm_set_device(int dev);                 /* one process per GPU: select the device before fv3lm_create */
+int fv3lm_state_save(fv3lm_handle* h);         /* device-side snapshot of u v pt delp q* (traj + pert) */
+int fv3lm_state_restore(fv3lm_handle* h);
 int fv3lm_zero_work_adjoint(fv3lm_handle* h);
 int fv3lm_sync(fv3lm_handle* h);
 long fv3lm_launch_count(fv3lm_handle* h);

@@ -44,6 +44,9 @@ class Case:
         self.qtraj = [G.halo_fill_periodic(np.abs(1e-3 * (n + 1) + _smooth_field(rng, shp, nx, ny, 3e-4)), nx, ny) for n in range(nq)]
         self.qpert = [G.halo_fill_periodic(_smooth_field(rng, shp, nx, ny, 1e-4), nx, ny) for n in range(nq)]
         self.oracle = Oracle(nx, ny, npz, nq, self.metrics, self.opt, self.da_min, self.da_min_c, self.phis, self.ak, self.bk) if oracle else None
+        if backend == "none":        # oracle only (bench.py's cpu_baseline leg)
+            self.lib = self.dy = None
+            return
         if backend == "emul":
             self.lib = Fv3LmLibrary(build_emul())
             self.lib.L.fv3lm_emul_check_boxes.argtypes = [__import__("ctypes").c_void_p, __import__("ctypes").c_int]
