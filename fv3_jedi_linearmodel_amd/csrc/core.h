@@ -126,6 +126,7 @@ struct Ctx {
 template <class S>
 struct AccNL {
   const S& s; const Ctx& c; int tile, k;
+  static constexpr unsigned want = ~0u;
   template <int M> HD double in(int i, int j, int dk = 0) const {
     const Fld& f = s.in[M];
     return f.t[(size_t)(tile * f.nk + k - 1 + dk) * c.g.plane + c.g.idx(i, j)];
@@ -134,6 +135,7 @@ struct AccNL {
 template <class S>
 struct AccTL {
   const S& s; const Ctx& c; int tile, k;
+  static constexpr unsigned want = ~0u;
   template <int M> HD Dual in(int i, int j, int dk = 0) const {
     const Fld& f = s.in[M];
     size_t n = (size_t)(tile * f.nk + k - 1 + dk) * c.g.plane + c.g.idx(i, j);
@@ -143,6 +145,7 @@ struct AccTL {
 template <class S, int MS>
 struct AccAD {
   const S& s; const Ctx& c; int tile, k; int si, sj, sk;   // seed point (absolute i, j, level)
+  unsigned want;                                             // outputs that depend on input MS (bit n = output n)
   template <int M> HD Dual in(int i, int j, int dk = 0) const {
     const Fld& f = s.in[M];
     double t = f.t[(size_t)(tile * f.nk + k - 1 + dk) * c.g.plane + c.g.idx(i, j)];
@@ -154,9 +157,11 @@ struct AccAD {
 template <class S>
 struct AccChk {
   const S& s; const Ctx& c; int tile, k; int ei, ej;   // evaluation point
+  static constexpr unsigned want = ~0u;
   template <int M> Dual in(int i, int j, int dk = 0) const {
     Box b = S::box(M);
-    if (i - ei < b.di0 || i - ei > b.di1 || j - ej < b.dj0 || j - ej > b.dj1 || dk < b.dk0 || dk > b.dk1) {
+    if (i - ei < b.di0 || i - ei > b.di1 || j - ej < b.dj0 || j - ej > b.dj1 || dk < b.dk0 || dk > b.dk1 ||
+        !S::uses(M, i - ei, j - ej, dk)) {
       std::fprintf(stderr, "stage %s: input %d accessed at offset (%d,%d,%d) outside declared box\n", S::name(), M,
                    i - ei, j - ej, dk);
       std::abort();

@@ -90,17 +90,18 @@ HD void body_ad_one(const S& s, const Ctx& c, const Rect& R, int i, int j, int z
   for (int dk = b.dk0; dk <= b.dk1; ++dk) {
     const int k = kk - dk;
     if (k < s.k0 || k > s.k1) continue;
-    AccAD<S, M> a{s, c, tile, k, i, j, kk};
+    AccAD<S, M> a{s, c, tile, k, i, j, kk, S::wants(M)};
     for (int dj = b.dj0; dj <= b.dj1; ++dj) {
       const int oj = j - dj;
       if (oj < R.j0 || oj > R.j1) continue;
       for (int di = b.di0; di <= b.di1; ++di) {
         const int oi = i - di;
         if (oi < R.i0 || oi > R.i1) continue;
+        if (!S::uses(M, di, dj, dk)) continue;
         Dual o[S::NOUT];
         s.template eval<Dual>(a, c, tile, oi, oj, k, o);
         for (int n = 0; n < S::NOUT; ++n)
-          if (s.orect[n].has(oi, oj))
+          if (((a.want >> n) & 1u) && s.orect[n].has(oi, oj))
             acc += o[n].d * s.out[n].p[(size_t)(tile * s.out[n].nk + k - 1) * c.g.plane + c.g.idx(oi, oj)];
       }
     }

@@ -7,13 +7,19 @@
 
 namespace fv3 {
 
-#define STAGE_COMMON(NAME, NI, NO)                                   \
+#define STAGE_BASE(NAME, NI, NO)                                     \
   static constexpr int NIN = NI, NOUT = NO;                          \
   Fld in[NI];                                                        \
   Fld out[NO];                                                       \
   Rect orect[NO];                                                    \
   int k0 = 1, k1 = 1;                                                \
   static const char* name() { return NAME; }
+#define STAGE_COMMON(NAME, NI, NO) STAGE_BASE(NAME, NI, NO) STAGE_DEFAULTS_ON
+// Adjoint refinements a stage may override: uses(M, di, dj, dk) = does any output read input M at that
+// offset (exact stencil inside the box); wants(M) = bit mask of the outputs that depend on input M.
+#define STAGE_DEFAULTS_ON                                             \
+  HD static bool uses(int, int, int, int) { return true; }           \
+  HD static unsigned wants(int) { return ~0u; }
 #define MET(nm, i, j) c.m.nm[c.mi(tile, (i), (j))]
 #define SSG(n, i, j) c.m.sin_sg[n][c.mi(tile, (i), (j))]
 #define CSG(n, i, j) c.m.cos_sg[n][c.mi(tile, (i), (j))]
@@ -89,19 +95,21 @@ struct CswInterpA {
 
 // d2a2c_vect C: A-grid -> C-grid + contravariant flux-form winds (:6655-6661, :6786-6792, :713-733)
 struct CswInterpC {
-  STAGE_COMMON("CswInterpC", 4, 4)   // in: utmp vtmp u v   out: uc0 utf vc0 vtf
+  STAGE_BASE("CswInterpC", 4, 4)   // in: utmp vtmp u v   out: uc0 utf vc0 vtf
   double dt2;
+  HD static bool uses(int, int, int, int) { return true; }
+  HD static unsigned wants(int M) { return M == 0 ? 0x3u : M == 1 ? 0xCu : M == 2 ? 0x8u : 0x2u; }
   HD static Box box(int M) { return M == 0 ? Box{-2, 1, 0, 0, 0, 0} : M == 1 ? Box{0, 0, -2, 1, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = o[2] = o[3] = T(0.);
-    if (orect[0].has(i, j)) {
+    if ((a.want & 0x3u) && orect[0].has(i, j)) {
       T uc = A2 * (a.template in<0>(i - 2, j) + a.template in<0>(i + 1, j)) + A1 * (a.template in<0>(i - 1, j) + a.template in<0>(i, j));
       T ut = (uc - a.template in<3>(i, j) * MET(cosa_u, i, j)) * MET(rsin_u, i, j);
       o[0] = uc;
       o[1] = (val(ut) > 0.) ? dt2 * ut * MET(dy, i, j) * SSG(3, i - 1, j) : dt2 * ut * MET(dy, i, j) * SSG(1, i, j);
     }
-    if (orect[2].has(i, j)) {
+    if ((a.want & 0xCu) && orect[2].has(i, j)) {
       T vc = A2 * (a.template in<1>(i, j - 2) + a.template in<1>(i, j + 1)) + A1 * (a.template in<1>(i, j - 1) + a.template in<1>(i, j));
       T vt = (vc - a.template in<2>(i, j) * MET(cosa_v, i, j)) * MET(rsin_v, i, j);
       o[2] = vc;
@@ -133,7 +141,9 @@ struct CswDivg {
 
 // first-order upwind transport of delp, pt on the C grid (sw_core_tlm.F90:744-808)
 struct CswTransport {
-  STAGE_COMMON("CswTransport", 4, 2)   // in: delp pt utf vtf   out: delpc ptc
+  STAGE_BASE("CswTransport", 4, 2)   // in: delp pt utf vtf   out: delpc ptc
+  HD static bool uses(int M, int di, int dj, int) { return M >= 2 || di == 0 || dj == 0; }
+  HD static unsigned wants(int M) { return M == 1 ? 0x2u : 0x3u; }
   HD static Box box(int M) { return M < 2 ? Box{-1, 1, -1, 1, 0, 0} : M == 2 ? Box{0, 1, 0, 0, 0, 0} : Box{0, 0, 0, 1, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
@@ -158,13 +168,15 @@ struct CswTransport {
 
 // kinetic energy at cell centres and absolute vorticity at corners (sw_core_tlm.F90:870-957)
 struct CswKeVort {
-  STAGE_COMMON("CswKeVort", 4, 2)   // in: ua va uc0 vc0   out: ke vort
+  STAGE_BASE("CswKeVort", 4, 2)   // in: ua va uc0 vc0   out: ke vort
   double dt2;
+  HD static bool uses(int M, int di, int dj, int) { return M < 2 || (M == 2 ? !(di == 1 && dj == -1) : !(di == -1 && dj == 1)); }
+  HD static unsigned wants(int M) { return M < 2 ? 0x1u : 0x3u; }
   HD static Box box(int M) { return M < 2 ? Box{0, 0, 0, 0, 0, 0} : M == 2 ? Box{0, 1, -1, 0, 0, 0} : Box{-1, 0, 0, 1, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = T(0.);
-    if (orect[0].has(i, j)) {
+    if ((a.want & 0x1u) && orect[0].has(i, j)) {
       T ua = a.template in<0>(i, j), va = a.template in<1>(i, j);
       T ku = (val(ua) > 0.) ? a.template in<2>(i, j) : a.template in<2>(i + 1, j);
       T kv = (val(va) > 0.) ? a.template in<3>(i, j) : a.template in<3>(i, j + 1);
@@ -180,19 +192,21 @@ struct CswKeVort {
 
 // time-centred C-grid winds (sw_core_tlm.F90:991-1037)
 struct CswUpdate {
-  STAGE_COMMON("CswUpdate", 6, 2)   // in: uc0 vc0 u v vort ke   out: uc1 vc1
+  STAGE_BASE("CswUpdate", 6, 2)   // in: uc0 vc0 u v vort ke   out: uc1 vc1
   double dt2;
+  HD static bool uses(int M, int di, int dj, int) { return M < 4 || (M == 4 ? !(di == 1 && dj == 1) : !(di == -1 && dj == -1)); }
+  HD static unsigned wants(int M) { return (M == 0 || M == 3) ? 0x1u : (M == 1 || M == 2) ? 0x2u : 0x3u; }
   HD static Box box(int M) { return M < 4 ? Box{0, 0, 0, 0, 0, 0} : M == 4 ? Box{0, 1, 0, 1, 0, 0} : Box{-1, 0, -1, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = T(0.);
-    if (orect[0].has(i, j)) {
+    if ((a.want & 0x1u) && orect[0].has(i, j)) {
       T uc = a.template in<0>(i, j);
       T fy1 = dt2 * (a.template in<3>(i, j) - uc * MET(cosa_u, i, j)) / MET(sina_u, i, j);
       T fy = (val(fy1) > 0.) ? a.template in<4>(i, j) : a.template in<4>(i, j + 1);
       o[0] = uc + fy1 * fy + MET(rdxc, i, j) * (a.template in<5>(i - 1, j) - a.template in<5>(i, j));
     }
-    if (orect[1].has(i, j)) {
+    if ((a.want & 0x2u) && orect[1].has(i, j)) {
       T vc = a.template in<1>(i, j);
       T fx1 = dt2 * (a.template in<2>(i, j) - vc * MET(cosa_v, i, j)) / MET(sina_v, i, j);
       T fx = (val(fx1) > 0.) ? a.template in<4>(i, j) : a.template in<4>(i + 1, j);
@@ -203,8 +217,10 @@ struct CswUpdate {
 
 // p_grad_c, hydrostatic (dyn_core_tlm.F90:3310-3334)
 struct PGradC {
-  STAGE_COMMON("PGradC", 4, 2)   // in: pkc gz (npz+1) uc1 vc1   out: uc2 vc2
+  STAGE_BASE("PGradC", 4, 2)   // in: pkc gz (npz+1) uc1 vc1   out: uc2 vc2
   double dt2;
+  HD static bool uses(int M, int di, int dj, int) { return M >= 2 || !(di == -1 && dj == -1); }
+  HD static unsigned wants(int M) { return M == 2 ? 0x1u : M == 3 ? 0x2u : 0x3u; }
   HD static Box box(int M) { return M < 2 ? Box{-1, 0, -1, 0, 0, 1} : Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
@@ -212,13 +228,13 @@ struct PGradC {
     T pk00 = a.template in<0>(i, j, 0), pk01 = a.template in<0>(i, j, 1);
     T gz00 = a.template in<1>(i, j, 0), gz01 = a.template in<1>(i, j, 1);
     T wk0 = pk01 - pk00;
-    if (orect[0].has(i, j)) {
+    if ((a.want & 0x1u) && orect[0].has(i, j)) {
       T pkm0 = a.template in<0>(i - 1, j, 0), pkm1 = a.template in<0>(i - 1, j, 1);
       T gzm0 = a.template in<1>(i - 1, j, 0), gzm1 = a.template in<1>(i - 1, j, 1);
       o[0] = a.template in<2>(i, j) + dt2 * MET(rdxc, i, j) / ((pkm1 - pkm0) + wk0) *
              ((gzm1 - gz00) * (pk01 - pkm0) + (gzm0 - gz01) * (pkm1 - pk00));
     }
-    if (orect[1].has(i, j)) {
+    if ((a.want & 0x2u) && orect[1].has(i, j)) {
       T pkm0 = a.template in<0>(i, j - 1, 0), pkm1 = a.template in<0>(i, j - 1, 1);
       T gzm0 = a.template in<1>(i, j - 1, 0), gzm1 = a.template in<1>(i, j - 1, 1);
       o[1] = a.template in<3>(i, j) + dt2 * MET(rdyc, i, j) / ((pkm1 - pkm0) + wk0) *
@@ -327,7 +343,10 @@ HD void damp_of(const LevelParams& l, int sel, int& nord, double& damp_c) {
   else { nord = -1; damp_c = 0.; }
 }
 struct TpD2 {
-  STAGE_COMMON("TpD2", 1, 1)   // in: q   out: d2b  (is-1..ie+1, js-1..je+1); zero where the level does not use nord=1
+  STAGE_BASE("TpD2", 1, 1)
+  HD static bool uses(int, int di, int dj, int) { return di == 0 || dj == 0; }
+  HD static unsigned wants(int) { return 0x1u; }
+    // in: q   out: d2b  (is-1..ie+1, js-1..je+1); zero where the level does not use nord=1
   int dsel; int use_mass;
   HD static Box box(int) { return Box{-1, 1, -1, 1, 0, 0}; }
   template <class T, class A>
@@ -346,8 +365,10 @@ struct TpD2 {
 };
 // flux averaging + damping fluxes (tp_core_tlm.F90:187-234, deln_flux :1918-2043)
 struct TpFlux {
-  STAGE_COMMON("TpFlux", 9, 2)   // in: fx_o fx2 mx fy_o fy2 my q d2b mass   out: fx fy
+  STAGE_BASE("TpFlux", 9, 2)   // in: fx_o fx2 mx fy_o fy2 my q d2b mass   out: fx fy
   int dsel; int use_mass;
+  HD static bool uses(int M, int di, int dj, int) { return M < 6 || !(di == -1 && dj == -1); }
+  HD static unsigned wants(int M) { return M < 3 ? 0x1u : M < 6 ? 0x2u : 0x3u; }
   HD static Box box(int M) {
     return (M == 6 || M == 7 || M == 8) ? Box{-1, 0, -1, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0};
   }
@@ -358,7 +379,7 @@ struct TpFlux {
     double damp = 0.;
     if (dmp) { damp = dc * c.m.da_min; if (nord == 1) damp = damp * damp; }
     o[0] = o[1] = T(0.);
-    if (orect[0].has(i, j)) {
+    if ((a.want & 0x1u) && orect[0].has(i, j)) {
       T f = 0.5 * (a.template in<0>(i, j) + a.template in<1>(i, j)) * a.template in<2>(i, j);
       if (dmp) {
         T f2;
@@ -373,7 +394,7 @@ struct TpFlux {
       }
       o[0] = f;
     }
-    if (orect[1].has(i, j)) {
+    if ((a.want & 0x2u) && orect[1].has(i, j)) {
       T f = 0.5 * (a.template in<3>(i, j) + a.template in<4>(i, j)) * a.template in<5>(i, j);
       if (dmp) {
         T f2;
@@ -449,7 +470,9 @@ struct DswVort {
 
 // ---- divergence damping (compute_divergence_damping, sw_core_tlm.F90:7760-8072), nord in {0,1} ----
 struct DdA {
-  STAGE_COMMON("DdA", 5, 2)   // in: divgd u v ua va   out: da db
+  STAGE_BASE("DdA", 5, 2)   // in: divgd u v ua va   out: da db
+  HD static bool uses(int M, int di, int dj, int) { return M == 0 ? !(di == 1 && dj == 1) : M == 3 ? dj == 0 : M == 4 ? di == 0 : true; }
+  HD static unsigned wants(int M) { return M == 0 ? 0x3u : (M == 1 || M == 4) ? 0x1u : 0x2u; }
   HD static Box box(int M) { return M == 0 ? Box{0, 1, 0, 1, 0, 0} : (M == 3 || M == 4) ? Box{-1, 0, -1, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
@@ -476,7 +499,9 @@ struct DdB {   // :7924-7937 (nord=0: delpc) / :7990-8006 (nord>0: new divg_d)
 };
 // a2b_ord4 interior (a2b_edge_tlm.F90:163-176, :268-291, :365-420, :441-505)
 struct A2bA {
-  STAGE_COMMON("A2bA", 1, 2)   // in: q   out: qx qy
+  STAGE_BASE("A2bA", 1, 2)   // in: q   out: qx qy
+  HD static bool uses(int, int di, int dj, int) { return di == 0 || dj == 0; }
+  HD static unsigned wants(int) { return 0x3u; }
   HD static Box box(int) { return Box{-2, 1, -2, 1, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
@@ -529,7 +554,9 @@ struct DdC {   // Smagorinsky-type coefficient and damping term added to KE (:79
 };
 // del6_vt_flux inner Laplacian without the damp factor (sw_core_tlm.F90:3747-3776, nord_v = 1)
 struct Del6A {
-  STAGE_COMMON("Del6A", 1, 1)   // in: wk   out: d2b
+  STAGE_BASE("Del6A", 1, 1)   // in: wk   out: d2b
+  HD static bool uses(int, int di, int dj, int) { return di == 0 || dj == 0; }
+  HD static unsigned wants(int) { return 0x1u; }
   HD static Box box(int) { return Box{-1, 1, -1, 1, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
@@ -544,7 +571,9 @@ struct Del6A {
 // momentum update (sw_core_tlm.F90:3555-3564) + vorticity-damping fluxes, trajectory and
 // perturbation coefficients kept apart (sw_core_tlm.F90:2436-2452, :2502-2530)
 struct DswUpdateUV {
-  STAGE_COMMON("DswUpdateUV", 7, 2)   // in: u v ke2 fxv fyv wk d2b   out: u_n v_n
+  STAGE_BASE("DswUpdateUV", 7, 2)   // in: u v ke2 fxv fyv wk d2b   out: u_n v_n
+  HD static bool uses(int M, int di, int dj, int) { return M == 2 ? !(di == 1 && dj == 1) : (M == 5 || M == 6) ? !(di == -1 && dj == -1) : true; }
+  HD static unsigned wants(int M) { return (M == 0 || M == 4) ? 0x1u : (M == 1 || M == 3) ? 0x2u : 0x3u; }
   HD static Box box(int M) {
     return M == 2 ? Box{0, 1, 0, 1, 0, 0} : (M == 5 || M == 6) ? Box{-1, 0, -1, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0};
   }
@@ -556,14 +585,14 @@ struct DswUpdateUV {
     const double d4t = dt_ ? pw(l.damp_vt * c.m.da_min_c, l.nord_v) : 0., d4p = dp_ ? pw(l.damp_vt_pert * c.m.da_min_c, l.nord_v_pert) : 0.;
     T ke = a.template in<2>(i, j);
     o[0] = o[1] = T(0.);
-    if (orect[0].has(i, j)) {
+    if ((a.want & 0x1u) && orect[0].has(i, j)) {
       T e0 = T(0.), e1 = T(0.);
       if ((dt_ && l.nord_v == 0) || (dp_ && l.nord_v_pert == 0)) e0 = MET(del6_u, i, j) * (a.template in<5>(i, j - 1) - a.template in<5>(i, j));
       if ((dt_ && l.nord_v == 1) || (dp_ && l.nord_v_pert == 1)) e1 = MET(del6_u, i, j) * (a.template in<6>(i, j) - a.template in<6>(i, j - 1));
       T vt_t = d4t * (l.nord_v == 0 ? e0 : e1), vt_p = d4p * (l.nord_v_pert == 0 ? e0 : e1);
       o[0] = a.template in<0>(i, j) * MET(dx, i, j) + (ke - a.template in<2>(i + 1, j)) + a.template in<4>(i, j) + combine(vt_t, vt_p);
     }
-    if (orect[1].has(i, j)) {
+    if ((a.want & 0x2u) && orect[1].has(i, j)) {
       T e0 = T(0.), e1 = T(0.);
       if ((dt_ && l.nord_v == 0) || (dp_ && l.nord_v_pert == 0)) e0 = MET(del6_v, i, j) * (a.template in<5>(i - 1, j) - a.template in<5>(i, j));
       if ((dt_ && l.nord_v == 1) || (dp_ && l.nord_v_pert == 1)) e1 = MET(del6_v, i, j) * (a.template in<6>(i, j) - a.template in<6>(i - 1, j));
@@ -631,8 +660,10 @@ struct DynPtIn {
 // one_grad_p wind update from corner pk, gz (dyn_core_tlm.F90:4128-4157); level 1 of pk is the
 // constant top value (:4068-4072).
 struct OneGradP {
-  STAGE_COMMON("OneGradP", 4, 2)   // in: u v pk_b gz_b (npz+1)   out: u_n v_n
+  STAGE_BASE("OneGradP", 4, 2)   // in: u v pk_b gz_b (npz+1)   out: u_n v_n
   double dt, ptk;
+  HD static bool uses(int M, int di, int dj, int) { return M < 2 || !(di == 1 && dj == 1); }
+  HD static unsigned wants(int M) { return M == 0 ? 0x1u : M == 1 ? 0x2u : 0x3u; }
   HD static Box box(int M) { return M < 2 ? Box{0, 0, 0, 0, 0, 0} : Box{0, 1, 0, 1, 0, 1}; }
   template <class T, class A>
   HD T pk(const A& a, int i, int j, int k, int dk) const { return (k + dk == 1) ? T(ptk) : a.template in<2>(i, j, dk); }
@@ -642,12 +673,12 @@ struct OneGradP {
     T g00 = a.template in<3>(i, j, 0), g01 = a.template in<3>(i, j, 1);
     T wk0 = p01 - p00;
     o[0] = o[1] = T(0.);
-    if (orect[0].has(i, j)) {
+    if ((a.want & 0x1u) && orect[0].has(i, j)) {
       T p10 = pk<T>(a, i + 1, j, k, 0), p11 = pk<T>(a, i + 1, j, k, 1);
       T g10 = a.template in<3>(i + 1, j, 0), g11 = a.template in<3>(i + 1, j, 1);
       o[0] = MET(rdx, i, j) * (a.template in<0>(i, j) + dt / (wk0 + (p11 - p10)) * ((g01 - g10) * (p11 - p00) + (g00 - g11) * (p01 - p10)));
     }
-    if (orect[1].has(i, j)) {
+    if ((a.want & 0x2u) && orect[1].has(i, j)) {
       T p10 = pk<T>(a, i, j + 1, k, 0), p11 = pk<T>(a, i, j + 1, k, 1);
       T g10 = a.template in<3>(i, j + 1, 0), g11 = a.template in<3>(i, j + 1, 1);
       o[1] = MET(rdy, i, j) * (a.template in<1>(i, j) + dt / (wk0 + (p11 - p10)) * ((g01 - g10) * (p11 - p00) + (g00 - g11) * (p01 - p10)));
