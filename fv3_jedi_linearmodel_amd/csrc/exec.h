@@ -79,29 +79,38 @@ HD void body_tl(const S& s, const Ctx& c, int i, int j, int z) {
     }
 }
 // Adjoint of input M at point (i,j) of plane z (z counts levels 1..in[M].nk per tile).
+// The stencil box is a compile-time constant and the offset loops are fully unrolled: after inlining,
+// "is this load the seeded one" folds to a constant for every load of the stage, so each of the K
+// evaluations keeps only the derivative chain that starts at its seeded load (forward-mode partial
+// evaluation; built with -fno-signed-zeros -ffinite-math-only so that 0*x and x+0 fold).
 template <class S, int M>
 HD void body_ad_one(const S& s, const Ctx& c, const Rect& R, int i, int j, int z) {
   const Fld& f = s.in[M];
   if (!f.p) return;
   const int tile = z / f.nk, kk = 1 + z % f.nk;
-  const Box b = S::box(M);
+  constexpr Box b = S::box(M);
+  constexpr unsigned want = S::wants(M);
   if (i < R.i0 + b.di0 || i > R.i1 + b.di1 || j < R.j0 + b.dj0 || j > R.j1 + b.dj1) return;
   double acc = 0.0;
+#pragma unroll
   for (int dk = b.dk0; dk <= b.dk1; ++dk) {
     const int k = kk - dk;
     if (k < s.k0 || k > s.k1) continue;
-    AccAD<S, M> a{s, c, tile, k, i, j, kk, S::wants(M)};
+    AccAD<S, M> a{s, c, tile, k, i, j, kk, want};
+#pragma unroll
     for (int dj = b.dj0; dj <= b.dj1; ++dj) {
       const int oj = j - dj;
       if (oj < R.j0 || oj > R.j1) continue;
+#pragma unroll
       for (int di = b.di0; di <= b.di1; ++di) {
         const int oi = i - di;
         if (oi < R.i0 || oi > R.i1) continue;
         if (!S::uses(M, di, dj, dk)) continue;
         Dual o[S::NOUT];
         s.template eval<Dual>(a, c, tile, oi, oj, k, o);
+#pragma unroll
         for (int n = 0; n < S::NOUT; ++n)
-          if (((a.want >> n) & 1u) && s.orect[n].has(oi, oj))
+          if (((want >> n) & 1u) && s.orect[n].has(oi, oj))
             acc += o[n].d * s.out[n].p[(size_t)(tile * s.out[n].nk + k - 1) * c.g.plane + c.g.idx(oi, oj)];
       }
     }

@@ -18,8 +18,8 @@ namespace fv3 {
 // Adjoint refinements a stage may override: uses(M, di, dj, dk) = does any output read input M at that
 // offset (exact stencil inside the box); wants(M) = bit mask of the outputs that depend on input M.
 #define STAGE_DEFAULTS_ON                                             \
-  HD static bool uses(int, int, int, int) { return true; }           \
-  HD static unsigned wants(int) { return ~0u; }
+  HD static constexpr bool uses(int, int, int, int) { return true; }           \
+  HD static constexpr unsigned wants(int) { return ~0u; }
 #define MET(nm, i, j) c.m.nm[c.mi(tile, (i), (j))]
 #define SSG(n, i, j) c.m.sin_sg[n][c.mi(tile, (i), (j))]
 #define CSG(n, i, j) c.m.cos_sg[n][c.mi(tile, (i), (j))]
@@ -79,7 +79,7 @@ HD T tp_uv_flux(int iord, const Q& q, T cc, double rd_m, double rd_0) {
 // d2a2c_vect A: D-grid winds -> A-grid (sw_core_tlm.F90:6505-6544, :6605-6611)
 struct CswInterpA {
   STAGE_COMMON("CswInterpA", 2, 4)   // in: u v   out: utmp vtmp ua va
-  HD static Box box(int M) { return M == 0 ? Box{0, 0, -1, 2, 0, 0} : Box{-1, 2, 0, 0, 0, 0}; }
+  HD static constexpr Box box(int M) { return M == 0 ? Box{0, 0, -1, 2, 0, 0} : Box{-1, 2, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     T ut = T(0.), vt = T(0.);
@@ -97,9 +97,9 @@ struct CswInterpA {
 struct CswInterpC {
   STAGE_BASE("CswInterpC", 4, 4)   // in: utmp vtmp u v   out: uc0 utf vc0 vtf
   double dt2;
-  HD static bool uses(int, int, int, int) { return true; }
-  HD static unsigned wants(int M) { return M == 0 ? 0x3u : M == 1 ? 0xCu : M == 2 ? 0x8u : 0x2u; }
-  HD static Box box(int M) { return M == 0 ? Box{-2, 1, 0, 0, 0, 0} : M == 1 ? Box{0, 0, -2, 1, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
+  HD static constexpr bool uses(int, int, int, int) { return true; }
+  HD static constexpr unsigned wants(int M) { return M == 0 ? 0x3u : M == 1 ? 0xCu : M == 2 ? 0x8u : 0x2u; }
+  HD static constexpr Box box(int M) { return M == 0 ? Box{-2, 1, 0, 0, 0, 0} : M == 1 ? Box{0, 0, -2, 1, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = o[2] = o[3] = T(0.);
@@ -121,7 +121,7 @@ struct CswInterpC {
 // divergence_corner (sw_core_tlm.F90:4044-4081)
 struct CswDivg {
   STAGE_COMMON("CswDivg", 4, 1)   // in: u v ua va   out: divgd
-  HD static Box box(int M) { return M == 0 ? Box{-1, 0, 0, 0, 0, 0} : M == 1 ? Box{0, 0, -1, 0, 0, 0} : Box{-1, 0, -1, 0, 0, 0}; }
+  HD static constexpr Box box(int M) { return M == 0 ? Box{-1, 0, 0, 0, 0, 0} : M == 1 ? Box{0, 0, -1, 0, 0, 0} : Box{-1, 0, -1, 0, 0, 0}; }
   template <class T, class A>
   HD T uf(const A& a, const Ctx& c, int tile, int i, int j) const {
     return (a.template in<0>(i, j) - 0.25 * (a.template in<3>(i, j - 1) + a.template in<3>(i, j)) * (CSG(4, i, j - 1) + CSG(2, i, j))) *
@@ -142,9 +142,9 @@ struct CswDivg {
 // first-order upwind transport of delp, pt on the C grid (sw_core_tlm.F90:744-808)
 struct CswTransport {
   STAGE_BASE("CswTransport", 4, 2)   // in: delp pt utf vtf   out: delpc ptc
-  HD static bool uses(int M, int di, int dj, int) { return M >= 2 || di == 0 || dj == 0; }
-  HD static unsigned wants(int M) { return M == 1 ? 0x2u : 0x3u; }
-  HD static Box box(int M) { return M < 2 ? Box{-1, 1, -1, 1, 0, 0} : M == 2 ? Box{0, 1, 0, 0, 0, 0} : Box{0, 0, 0, 1, 0, 0}; }
+  HD static constexpr bool uses(int M, int di, int dj, int) { return M >= 2 || di == 0 || dj == 0; }
+  HD static constexpr unsigned wants(int M) { return M == 1 ? 0x2u : 0x3u; }
+  HD static constexpr Box box(int M) { return M < 2 ? Box{-1, 1, -1, 1, 0, 0} : M == 2 ? Box{0, 1, 0, 0, 0, 0} : Box{0, 0, 0, 1, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     T fx1[2], fx[2], fy1[2], fy[2];
@@ -170,9 +170,9 @@ struct CswTransport {
 struct CswKeVort {
   STAGE_BASE("CswKeVort", 4, 2)   // in: ua va uc0 vc0   out: ke vort
   double dt2;
-  HD static bool uses(int M, int di, int dj, int) { return M < 2 || (M == 2 ? !(di == 1 && dj == -1) : !(di == -1 && dj == 1)); }
-  HD static unsigned wants(int M) { return M < 2 ? 0x1u : 0x3u; }
-  HD static Box box(int M) { return M < 2 ? Box{0, 0, 0, 0, 0, 0} : M == 2 ? Box{0, 1, -1, 0, 0, 0} : Box{-1, 0, 0, 1, 0, 0}; }
+  HD static constexpr bool uses(int M, int di, int dj, int) { return M < 2 || (M == 2 ? !(di == 1 && dj == -1) : !(di == -1 && dj == 1)); }
+  HD static constexpr unsigned wants(int M) { return M < 2 ? 0x1u : 0x3u; }
+  HD static constexpr Box box(int M) { return M < 2 ? Box{0, 0, 0, 0, 0, 0} : M == 2 ? Box{0, 1, -1, 0, 0, 0} : Box{-1, 0, 0, 1, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = T(0.);
@@ -194,9 +194,9 @@ struct CswKeVort {
 struct CswUpdate {
   STAGE_BASE("CswUpdate", 6, 2)   // in: uc0 vc0 u v vort ke   out: uc1 vc1
   double dt2;
-  HD static bool uses(int M, int di, int dj, int) { return M < 4 || (M == 4 ? !(di == 1 && dj == 1) : !(di == -1 && dj == -1)); }
-  HD static unsigned wants(int M) { return (M == 0 || M == 3) ? 0x1u : (M == 1 || M == 2) ? 0x2u : 0x3u; }
-  HD static Box box(int M) { return M < 4 ? Box{0, 0, 0, 0, 0, 0} : M == 4 ? Box{0, 1, 0, 1, 0, 0} : Box{-1, 0, -1, 0, 0, 0}; }
+  HD static constexpr bool uses(int M, int di, int dj, int) { return M < 4 || (M == 4 ? !(di == 1 && dj == 1) : !(di == -1 && dj == -1)); }
+  HD static constexpr unsigned wants(int M) { return (M == 0 || M == 3) ? 0x1u : (M == 1 || M == 2) ? 0x2u : 0x3u; }
+  HD static constexpr Box box(int M) { return M < 4 ? Box{0, 0, 0, 0, 0, 0} : M == 4 ? Box{0, 1, 0, 1, 0, 0} : Box{-1, 0, -1, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = T(0.);
@@ -219,9 +219,9 @@ struct CswUpdate {
 struct PGradC {
   STAGE_BASE("PGradC", 4, 2)   // in: pkc gz (npz+1) uc1 vc1   out: uc2 vc2
   double dt2;
-  HD static bool uses(int M, int di, int dj, int) { return M >= 2 || !(di == -1 && dj == -1); }
-  HD static unsigned wants(int M) { return M == 2 ? 0x1u : M == 3 ? 0x2u : 0x3u; }
-  HD static Box box(int M) { return M < 2 ? Box{-1, 0, -1, 0, 0, 1} : Box{0, 0, 0, 0, 0, 0}; }
+  HD static constexpr bool uses(int M, int di, int dj, int) { return M >= 2 || !(di == -1 && dj == -1); }
+  HD static constexpr unsigned wants(int M) { return M == 2 ? 0x1u : M == 3 ? 0x2u : 0x3u; }
+  HD static constexpr Box box(int M) { return M < 2 ? Box{-1, 0, -1, 0, 0, 1} : Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = T(0.);
@@ -248,7 +248,7 @@ struct PGradC {
 struct DswWinds {
   STAGE_COMMON("DswWinds", 2, 6)   // in: uc vc   out: ut crx xfx vt cry yfx
   double dt;
-  HD static Box box(int M) { return M == 0 ? Box{0, 1, -1, 0, 0, 0} : Box{-1, 0, 0, 1, 0, 0}; }
+  HD static constexpr Box box(int M) { return M == 0 ? Box{0, 1, -1, 0, 0, 0} : Box{-1, 0, 0, 1, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     for (int n = 0; n < 6; ++n) o[n] = T(0.);
@@ -277,7 +277,7 @@ struct DswWinds {
 
 struct DswRa {   // sw_core_tlm.F90:2969-2978
   STAGE_COMMON("DswRa", 2, 2)   // in: xfx yfx   out: ra_x ra_y
-  HD static Box box(int M) { return M == 0 ? Box{0, 1, 0, 0, 0, 0} : Box{0, 0, 0, 1, 0, 0}; }
+  HD static constexpr Box box(int M) { return M == 0 ? Box{0, 1, 0, 0, 0, 0} : Box{0, 0, 0, 1, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = T(0.);
@@ -300,7 +300,7 @@ struct LineY { const A& a; int i, j; HD auto operator()(int d) const { return a.
 struct TpPpmX {
   STAGE_COMMON("TpPpmX", 2, 1)   // in: q crx   out: flux
   int hsel;
-  HD static Box box(int M) { return M == 0 ? Box{-3, 2, 0, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
+  HD static constexpr Box box(int M) { return M == 0 ? Box{-3, 2, 0, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     LineX<A, 0> q{a, i, j};
@@ -310,7 +310,7 @@ struct TpPpmX {
 struct TpPpmY {
   STAGE_COMMON("TpPpmY", 2, 1)   // in: q cry   out: flux
   int hsel;
-  HD static Box box(int M) { return M == 0 ? Box{0, 0, -3, 2, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
+  HD static constexpr Box box(int M) { return M == 0 ? Box{0, 0, -3, 2, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     LineY<A, 0> q{a, i, j};
@@ -319,7 +319,7 @@ struct TpPpmY {
 };
 struct TpQi {   // tp_core_tlm.F90:149-159
   STAGE_COMMON("TpQi", 4, 1)   // in: q fy2 yfx ra_y   out: q_i
-  HD static Box box(int M) { return (M == 1 || M == 2) ? Box{0, 0, 0, 1, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
+  HD static constexpr Box box(int M) { return (M == 1 || M == 2) ? Box{0, 0, 0, 1, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     T f0 = a.template in<2>(i, j) * a.template in<1>(i, j), f1 = a.template in<2>(i, j + 1) * a.template in<1>(i, j + 1);
@@ -328,7 +328,7 @@ struct TpQi {   // tp_core_tlm.F90:149-159
 };
 struct TpQj {   // tp_core_tlm.F90:173-181
   STAGE_COMMON("TpQj", 4, 1)   // in: q fx2 xfx ra_x   out: q_j
-  HD static Box box(int M) { return (M == 1 || M == 2) ? Box{0, 1, 0, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
+  HD static constexpr Box box(int M) { return (M == 1 || M == 2) ? Box{0, 1, 0, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     T f0 = a.template in<2>(i, j) * a.template in<1>(i, j), f1 = a.template in<2>(i + 1, j) * a.template in<1>(i + 1, j);
@@ -344,11 +344,11 @@ HD void damp_of(const LevelParams& l, int sel, int& nord, double& damp_c) {
 }
 struct TpD2 {
   STAGE_BASE("TpD2", 1, 1)
-  HD static bool uses(int, int di, int dj, int) { return di == 0 || dj == 0; }
-  HD static unsigned wants(int) { return 0x1u; }
+  HD static constexpr bool uses(int, int di, int dj, int) { return di == 0 || dj == 0; }
+  HD static constexpr unsigned wants(int) { return 0x1u; }
     // in: q   out: d2b  (is-1..ie+1, js-1..je+1); zero where the level does not use nord=1
   int dsel; int use_mass;
-  HD static Box box(int) { return Box{-1, 1, -1, 1, 0, 0}; }
+  HD static constexpr Box box(int) { return Box{-1, 1, -1, 1, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     int nord; double dc; damp_of(c.lev[k - 1], dsel, nord, dc);
@@ -367,9 +367,9 @@ struct TpD2 {
 struct TpFlux {
   STAGE_BASE("TpFlux", 9, 2)   // in: fx_o fx2 mx fy_o fy2 my q d2b mass   out: fx fy
   int dsel; int use_mass;
-  HD static bool uses(int M, int di, int dj, int) { return M < 6 || !(di == -1 && dj == -1); }
-  HD static unsigned wants(int M) { return M < 3 ? 0x1u : M < 6 ? 0x2u : 0x3u; }
-  HD static Box box(int M) {
+  HD static constexpr bool uses(int M, int di, int dj, int) { return M < 6 || !(di == -1 && dj == -1); }
+  HD static constexpr unsigned wants(int M) { return M < 3 ? 0x1u : M < 6 ? 0x2u : 0x3u; }
+  HD static constexpr Box box(int M) {
     return (M == 6 || M == 7 || M == 8) ? Box{-1, 0, -1, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0};
   }
   template <class T, class A>
@@ -415,7 +415,7 @@ struct TpFlux {
 // forward-in-time update of delp and pt (sw_core_tlm.F90:3107-3116)
 struct DswUpdateDp {
   STAGE_COMMON("DswUpdateDp", 6, 2)   // in: delp pt fx fy gx gy   out: delp_n pt_n
-  HD static Box box(int M) { return M < 2 ? Box{0, 0, 0, 0, 0, 0} : (M == 2 || M == 4) ? Box{0, 1, 0, 0, 0, 0} : Box{0, 0, 0, 1, 0, 0}; }
+  HD static constexpr Box box(int M) { return M < 2 ? Box{0, 0, 0, 0, 0, 0} : (M == 2 || M == 4) ? Box{0, 1, 0, 0, 0, 0} : Box{0, 0, 0, 1, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     const double ra = MET(rarea, i, j);
@@ -431,7 +431,7 @@ struct DswUpdateDp {
 struct DswKeWinds {
   STAGE_COMMON("DswKeWinds", 2, 2)   // in: uc vc   out: vb ub
   double dt;
-  HD static Box box(int M) { return M == 0 ? Box{0, 0, -1, 0, 0, 0} : Box{-1, 0, 0, 0, 0, 0}; }
+  HD static constexpr Box box(int M) { return M == 0 ? Box{0, 0, -1, 0, 0, 0} : Box{-1, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     const double dt5 = 0.5 * dt, cs = MET(cosa, i, j), rs = MET(rsina, i, j);
@@ -443,7 +443,7 @@ struct DswKeWinds {
 // KE = 0.5*(vb*ytp_v + ub*xtp_u) (sw_core_tlm.F90:3197-3254)
 struct DswKe {
   STAGE_COMMON("DswKe", 4, 1)   // in: vb ub u v   out: ke
-  HD static Box box(int M) { return M < 2 ? Box{0, 0, 0, 0, 0, 0} : M == 2 ? Box{-3, 2, 0, 0, 0, 0} : Box{0, 0, -3, 2, 0, 0}; }
+  HD static constexpr Box box(int M) { return M < 2 ? Box{0, 0, 0, 0, 0, 0} : M == 2 ? Box{-3, 2, 0, 0, 0, 0} : Box{0, 0, -3, 2, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     const int iord = c.lev[k - 1].hord_mt;
@@ -458,7 +458,7 @@ struct DswKe {
 // relative and absolute vorticity (sw_core_tlm.F90:3275-3293, :3535-3540)
 struct DswVort {
   STAGE_COMMON("DswVort", 2, 2)   // in: u v   out: wk vort_abs
-  HD static Box box(int M) { return M == 0 ? Box{0, 0, 0, 1, 0, 0} : Box{0, 1, 0, 0, 0, 0}; }
+  HD static constexpr Box box(int M) { return M == 0 ? Box{0, 0, 0, 1, 0, 0} : Box{0, 1, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     T w = MET(rarea, i, j) * (a.template in<0>(i, j) * MET(dx, i, j) - a.template in<0>(i, j + 1) * MET(dx, i, j + 1) +
@@ -471,9 +471,9 @@ struct DswVort {
 // ---- divergence damping (compute_divergence_damping, sw_core_tlm.F90:7760-8072), nord in {0,1} ----
 struct DdA {
   STAGE_BASE("DdA", 5, 2)   // in: divgd u v ua va   out: da db
-  HD static bool uses(int M, int di, int dj, int) { return M == 0 ? !(di == 1 && dj == 1) : M == 3 ? dj == 0 : M == 4 ? di == 0 : true; }
-  HD static unsigned wants(int M) { return M == 0 ? 0x3u : (M == 1 || M == 4) ? 0x1u : 0x2u; }
-  HD static Box box(int M) { return M == 0 ? Box{0, 1, 0, 1, 0, 0} : (M == 3 || M == 4) ? Box{-1, 0, -1, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
+  HD static constexpr bool uses(int M, int di, int dj, int) { return M == 0 ? !(di == 1 && dj == 1) : M == 3 ? dj == 0 : M == 4 ? di == 0 : true; }
+  HD static constexpr unsigned wants(int M) { return M == 0 ? 0x3u : (M == 1 || M == 4) ? 0x1u : 0x2u; }
+  HD static constexpr Box box(int M) { return M == 0 ? Box{0, 1, 0, 1, 0, 0} : (M == 3 || M == 4) ? Box{-1, 0, -1, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     const int nord = c.lev[k - 1].nord;
@@ -491,7 +491,7 @@ struct DdA {
 };
 struct DdB {   // :7924-7937 (nord=0: delpc) / :7990-8006 (nord>0: new divg_d)
   STAGE_COMMON("DdB", 2, 1)   // in: da db   out: dc
-  HD static Box box(int M) { return M == 0 ? Box{-1, 0, 0, 0, 0, 0} : Box{0, 0, -1, 0, 0, 0}; }
+  HD static constexpr Box box(int M) { return M == 0 ? Box{-1, 0, 0, 0, 0, 0} : Box{0, 0, -1, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = MET(rarea_c, i, j) * (a.template in<1>(i, j - 1) - a.template in<1>(i, j) + a.template in<0>(i - 1, j) - a.template in<0>(i, j));
@@ -500,9 +500,9 @@ struct DdB {   // :7924-7937 (nord=0: delpc) / :7990-8006 (nord>0: new divg_d)
 // a2b_ord4 interior (a2b_edge_tlm.F90:163-176, :268-291, :365-420, :441-505)
 struct A2bA {
   STAGE_BASE("A2bA", 1, 2)   // in: q   out: qx qy
-  HD static bool uses(int, int di, int dj, int) { return di == 0 || dj == 0; }
-  HD static unsigned wants(int) { return 0x3u; }
-  HD static Box box(int) { return Box{-2, 1, -2, 1, 0, 0}; }
+  HD static constexpr bool uses(int, int di, int dj, int) { return di == 0 || dj == 0; }
+  HD static constexpr unsigned wants(int) { return 0x3u; }
+  HD static constexpr Box box(int) { return Box{-2, 1, -2, 1, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = T(0.);
@@ -512,7 +512,7 @@ struct A2bA {
 };
 struct A2bB {
   STAGE_COMMON("A2bB", 2, 1)   // in: qx qy   out: qout
-  HD static Box box(int M) { return M == 0 ? Box{0, 0, -2, 1, 0, 0} : Box{-2, 1, 0, 0, 0, 0}; }
+  HD static constexpr Box box(int M) { return M == 0 ? Box{0, 0, -2, 1, 0, 0} : Box{-2, 1, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     T qxx = A2 * (a.template in<0>(i, j - 2) + a.template in<0>(i, j + 1)) + A1 * (a.template in<0>(i, j - 1) + a.template in<0>(i, j));
@@ -523,7 +523,7 @@ struct A2bB {
 struct DdC {   // Smagorinsky-type coefficient and damping term added to KE (:7938-7956, :8023-8070)
   STAGE_COMMON("DdC", 4, 1)   // in: ke dc divgd vort_b   out: ke2
   double dt, dddmp, d4_bg;
-  HD static Box box(int) { return Box{0, 0, 0, 0, 0, 0}; }
+  HD static constexpr Box box(int) { return Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     const LevelParams& l = c.lev[k - 1];
@@ -555,9 +555,9 @@ struct DdC {   // Smagorinsky-type coefficient and damping term added to KE (:79
 // del6_vt_flux inner Laplacian without the damp factor (sw_core_tlm.F90:3747-3776, nord_v = 1)
 struct Del6A {
   STAGE_BASE("Del6A", 1, 1)   // in: wk   out: d2b
-  HD static bool uses(int, int di, int dj, int) { return di == 0 || dj == 0; }
-  HD static unsigned wants(int) { return 0x1u; }
-  HD static Box box(int) { return Box{-1, 1, -1, 1, 0, 0}; }
+  HD static constexpr bool uses(int, int di, int dj, int) { return di == 0 || dj == 0; }
+  HD static constexpr unsigned wants(int) { return 0x1u; }
+  HD static constexpr Box box(int) { return Box{-1, 1, -1, 1, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     T q0 = a.template in<0>(i, j);
@@ -572,9 +572,9 @@ struct Del6A {
 // perturbation coefficients kept apart (sw_core_tlm.F90:2436-2452, :2502-2530)
 struct DswUpdateUV {
   STAGE_BASE("DswUpdateUV", 7, 2)   // in: u v ke2 fxv fyv wk d2b   out: u_n v_n
-  HD static bool uses(int M, int di, int dj, int) { return M == 2 ? !(di == 1 && dj == 1) : (M == 5 || M == 6) ? !(di == -1 && dj == -1) : true; }
-  HD static unsigned wants(int M) { return (M == 0 || M == 4) ? 0x1u : (M == 1 || M == 3) ? 0x2u : 0x3u; }
-  HD static Box box(int M) {
+  HD static constexpr bool uses(int M, int di, int dj, int) { return M == 2 ? !(di == 1 && dj == 1) : (M == 5 || M == 6) ? !(di == -1 && dj == -1) : true; }
+  HD static constexpr unsigned wants(int M) { return (M == 0 || M == 4) ? 0x1u : (M == 1 || M == 3) ? 0x2u : 0x3u; }
+  HD static constexpr Box box(int M) {
     return M == 2 ? Box{0, 1, 0, 1, 0, 0} : (M == 5 || M == 6) ? Box{-1, 0, -1, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0};
   }
   HD static double pw(double x, int n) { double r = x; for (int m = 0; m < n; ++m) r *= x; return r; }
@@ -606,7 +606,7 @@ struct DswUpdateUV {
 // accumulated Courant numbers -> area fluxes (:1226-1247)
 struct TrFlux {
   STAGE_COMMON("TrFlux", 2, 2)   // in: cx cy   out: xfx yfx
-  HD static Box box(int) { return Box{0, 0, 0, 0, 0, 0}; }
+  HD static constexpr Box box(int) { return Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = T(0.);
@@ -623,7 +623,7 @@ struct TrFlux {
 // dp2 and the flux-form areas (:1375-1392)
 struct TrDp2Ra {
   STAGE_COMMON("TrDp2Ra", 5, 3)   // in: dp1 mfx mfy xfx yfx   out: dp2 ra_x ra_y
-  HD static Box box(int M) { return M == 0 ? Box{0, 0, 0, 0, 0, 0} : (M == 1 || M == 3) ? Box{0, 1, 0, 0, 0, 0} : Box{0, 0, 0, 1, 0, 0}; }
+  HD static constexpr Box box(int M) { return M == 0 ? Box{0, 0, 0, 0, 0, 0} : (M == 1 || M == 3) ? Box{0, 1, 0, 0, 0, 0} : Box{0, 0, 0, 1, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = o[2] = T(0.);
@@ -637,7 +637,7 @@ struct TrDp2Ra {
 // q update (:1423-1430)
 struct TrUpdate {
   STAGE_COMMON("TrUpdate", 5, 1)   // in: q dp1 dp2 fx fy   out: q_o
-  HD static Box box(int M) { return M == 3 ? Box{0, 1, 0, 0, 0, 0} : M == 4 ? Box{0, 0, 0, 1, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
+  HD static constexpr Box box(int M) { return M == 3 ? Box{0, 1, 0, 0, 0, 0} : M == 4 ? Box{0, 0, 0, 1, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = (a.template in<0>(i, j) * a.template in<1>(i, j) +
@@ -649,7 +649,7 @@ struct TrUpdate {
 struct DynPtIn {
   STAGE_COMMON("DynPtIn", 3, 1)   // in: pt(T) qv pkz   out: pt(theta_v)
   double zvir; int has_q;
-  HD static Box box(int) { return Box{0, 0, 0, 0, 0, 0}; }
+  HD static constexpr Box box(int) { return Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     T d = has_q ? zvir * a.template in<1>(i, j) : T(0.);
@@ -662,9 +662,9 @@ struct DynPtIn {
 struct OneGradP {
   STAGE_BASE("OneGradP", 4, 2)   // in: u v pk_b gz_b (npz+1)   out: u_n v_n
   double dt, ptk;
-  HD static bool uses(int M, int di, int dj, int) { return M < 2 || !(di == 1 && dj == 1); }
-  HD static unsigned wants(int M) { return M == 0 ? 0x1u : M == 1 ? 0x2u : 0x3u; }
-  HD static Box box(int M) { return M < 2 ? Box{0, 0, 0, 0, 0, 0} : Box{0, 1, 0, 1, 0, 1}; }
+  HD static constexpr bool uses(int M, int di, int dj, int) { return M < 2 || !(di == 1 && dj == 1); }
+  HD static constexpr unsigned wants(int M) { return M == 0 ? 0x1u : M == 1 ? 0x2u : 0x3u; }
+  HD static constexpr Box box(int M) { return M < 2 ? Box{0, 0, 0, 0, 0, 0} : Box{0, 1, 0, 1, 0, 1}; }
   template <class T, class A>
   HD T pk(const A& a, int i, int j, int k, int dk) const { return (k + dk == 1) ? T(ptk) : a.template in<2>(i, j, dk); }
   template <class T, class A>

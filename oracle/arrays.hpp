@@ -30,6 +30,11 @@ struct Bounds {
     ioff = 1000; joff = 1000; npx = 1 << 28; npy = 1 << 28;
   }
   bool any_edge() const { return edge_w || edge_e || edge_s || edge_n; }
+  // whole cube face: is=1, ie=npx-1, js=1, je=npy-1, all four edges and corners present
+  void set_face(int n) {
+    set(n, n); ioff = joff = 0; npx = n + 1; npy = n + 1;
+    edge_w = edge_e = edge_s = edge_n = true; sw_corner = se_corner = nw_corner = ne_corner = true;
+  }
 };
 
 template <class T>
@@ -69,6 +74,11 @@ struct Grid {
   Arr2<double> f0, fC, del6_u, del6_v, divg_u, divg_v;
   Arr2<double> sin_sg[10], cos_sg[10];  // index 1..9 used (sin_sg(i,j,1:9))
   double da_min = 0, da_min_c = 0;
+  // a2b_ord4 cube-edge data: edge_w(j), edge_e(j), edge_s(i), edge_n(i) (fv_grid_type edge_w..edge_n) and the
+  // extrap_corner coefficients x1/(x2-x1) for the 3 extrapolations of each corner (order sw, se, ne, nw),
+  // precomputed from grid/agrid with great_circle_dist (a2b_edge_tlm.F90:1478-1487).
+  std::vector<double> edge_w, edge_e, edge_s, edge_n;
+  double ecorner[4][3] = {};
   static constexpr int NMETRIC = 33 + 18;
   void init(const Bounds& b) {
     Arr2<double>* all[] = {&area, &rarea, &rarea_c, &dx, &dy, &dxa, &dya, &dxc, &dyc, &rdx, &rdy, &rdxa, &rdya, &rdxc,

@@ -12,18 +12,50 @@ static const double ppm_p1 = 7. / 12., ppm_p2 = -1. / 12.;   // tp_core_tlm.F90:
 static const double ppm_c1 = -2. / 14., ppm_c2 = 11. / 14., ppm_c3 = 5. / 14.;
 
 // xppm: 1-D flux in x along rows jfirst..jlast.  c and flux live on is..ie+1.
-// tp_core_tlm.F90:2328-2492.  Interior-rank version: is1=is-1, ie3=ie+2 (:2380-2386).
+// tp_core_tlm.F90:2328-2492, with the one-sided edge values at cube-face edges (:2402-2429).
+// copy_corners, tp_core_tlm.F90:2046-2118 (no-op unless the tile owns a cube corner).
+template <class T>
+void copy_corners(Arr2<T>& q, int dir, const Bounds& bd) {
+  const int ng = bd.ng, npx = bd.npx, npy = bd.npy;
+  if (dir == 1) {
+    if (bd.sw_corner) for (int j = 1 - ng; j <= 0; ++j) for (int i = 1 - ng; i <= 0; ++i) q(i, j) = q(j, 1 - i);
+    if (bd.se_corner) for (int j = 1 - ng; j <= 0; ++j) for (int i = npx; i <= npx + ng - 1; ++i) q(i, j) = q(npy - j, i - npx + 1);
+    if (bd.ne_corner) for (int j = npy; j <= npy + ng - 1; ++j) for (int i = npx; i <= npx + ng - 1; ++i) q(i, j) = q(j, 2 * npx - 1 - i);
+    if (bd.nw_corner) for (int j = npy; j <= npy + ng - 1; ++j) for (int i = 1 - ng; i <= 0; ++i) q(i, j) = q(npy - j, i - 1 + npx);
+  } else {
+    if (bd.sw_corner) for (int j = 1 - ng; j <= 0; ++j) for (int i = 1 - ng; i <= 0; ++i) q(i, j) = q(1 - j, i);
+    if (bd.se_corner) for (int j = 1 - ng; j <= 0; ++j) for (int i = npx; i <= npx + ng - 1; ++i) q(i, j) = q(npy + j - 1, npx - i);
+    if (bd.ne_corner) for (int j = npy; j <= npy + ng - 1; ++j) for (int i = npx; i <= npx + ng - 1; ++i) q(i, j) = q(2 * npy - 1 - j, i);
+    if (bd.nw_corner) for (int j = npy; j <= npy + ng - 1; ++j) for (int i = 1 - ng; i <= 0; ++i) q(i, j) = q(j + 1 - npx, npy - i);
+  }
+}
+
 template <class T>
 void xppm(Arr2<T>& flux, const Arr2<T>& q, const Arr2<T>& c, int iord, int is, int ie, int jfirst, int jlast,
           const Bounds& bd, const Grid& g) {
-  assert(!bd.any_edge());
   assert(iord == 1 || iord == 2 || iord == 333);
-  const int is1 = is - 1, ie3 = ie + 2;
-  std::vector<T> al(ie3 - is1 + 2);
-  auto AL = [&](int i) -> T& { return al[i - is1]; };
+  const int npx = bd.npx;
+  int is1 = is - 1, ie3 = ie + 2;
+  if (bd.any_edge()) { is1 = std::max(3, is - 1); ie3 = std::min(npx - 2, ie + 2); }   // :2363-2378
+  std::vector<T> al(ie + 2 - (is - 1) + 2);
+  auto AL = [&](int i) -> T& { return al[i - (is - 1)]; };
   for (int j = jfirst; j <= jlast; ++j) {
     for (int i = is1; i <= ie3; ++i)   // :2397-2399
       AL(i) = ppm_p1 * (q(i - 1, j) + q(i, j)) + ppm_p2 * (q(i - 2, j) + q(i + 1, j));
+    if (bd.edge_w) {                   // is == 1, :2402-2413
+      AL(0) = ppm_c1 * q(-2, j) + ppm_c2 * q(-1, j) + ppm_c3 * q(0, j);
+      AL(1) = 0.5 * (((2. * g.dxa(0, j) + g.dxa(-1, j)) * q(0, j) - g.dxa(0, j) * q(-1, j)) / (g.dxa(-1, j) + g.dxa(0, j)) +
+                     ((2. * g.dxa(1, j) + g.dxa(2, j)) * q(1, j) - g.dxa(1, j) * q(2, j)) / (g.dxa(1, j) + g.dxa(2, j)));
+      AL(2) = ppm_c3 * q(1, j) + ppm_c2 * q(2, j) + ppm_c1 * q(3, j);
+    }
+    if (bd.edge_e) {                   // ie+1 == npx, :2414-2429
+      AL(npx - 1) = ppm_c1 * q(npx - 3, j) + ppm_c2 * q(npx - 2, j) + ppm_c3 * q(npx - 1, j);
+      AL(npx) = 0.5 * (((2. * g.dxa(npx - 1, j) + g.dxa(npx - 2, j)) * q(npx - 1, j) - g.dxa(npx - 1, j) * q(npx - 2, j)) /
+                           (g.dxa(npx - 2, j) + g.dxa(npx - 1, j)) +
+                       ((2. * g.dxa(npx, j) + g.dxa(npx + 1, j)) * q(npx, j) - g.dxa(npx, j) * q(npx + 1, j)) /
+                           (g.dxa(npx, j) + g.dxa(npx + 1, j)));
+      AL(npx + 1) = ppm_c3 * q(npx, j) + ppm_c2 * q(npx + 1, j) + ppm_c1 * q(npx + 2, j);
+    }
     if (iord == 1) {                   // :2431-2440
       for (int i = is; i <= ie + 1; ++i) flux(i, j) = (val(c(i, j)) > 0.) ? q(i - 1, j) : q(i, j);
     } else if (iord == 2) {            // :2441-2466
@@ -55,9 +87,10 @@ void xppm(Arr2<T>& flux, const Arr2<T>& q, const Arr2<T>& c, int iord, int is, i
 template <class T>
 void yppm(Arr2<T>& flux, const Arr2<T>& q, const Arr2<T>& c, int jord, int ifirst, int ilast, int js, int je,
           const Bounds& bd, const Grid& g) {
-  assert(!bd.any_edge());
   assert(jord == 1 || jord == 2 || jord == 333);
-  const int js1 = js - 1, je3 = je + 2;
+  const int npy = bd.npy;
+  int js1 = js - 1, je3 = je + 2;
+  if (bd.any_edge()) { js1 = std::max(3, js - 1); je3 = std::min(npy - 2, je + 2); }
   if (jord == 1) {
     for (int j = js; j <= je + 1; ++j)
       for (int i = ifirst; i <= ilast; ++i) flux(i, j) = (val(c(i, j)) > 0.) ? q(i, j - 1) : q(i, j);
@@ -67,6 +100,22 @@ void yppm(Arr2<T>& flux, const Arr2<T>& q, const Arr2<T>& c, int jord, int ifirs
   for (int j = js1; j <= je3; ++j)
     for (int i = ifirst; i <= ilast; ++i)
       al(i, j) = ppm_p1 * (q(i, j - 1) + q(i, j)) + ppm_p2 * (q(i, j - 2) + q(i, j + 1));
+  if (bd.edge_s)     // js == 1, :2559-2573
+    for (int i = ifirst; i <= ilast; ++i) {
+      al(i, 0) = ppm_c1 * q(i, -2) + ppm_c2 * q(i, -1) + ppm_c3 * q(i, 0);
+      al(i, 1) = 0.5 * (((2. * g.dya(i, 0) + g.dya(i, -1)) * q(i, 0) - g.dya(i, 0) * q(i, -1)) / (g.dya(i, -1) + g.dya(i, 0)) +
+                        ((2. * g.dya(i, 1) + g.dya(i, 2)) * q(i, 1) - g.dya(i, 1) * q(i, 2)) / (g.dya(i, 1) + g.dya(i, 2)));
+      al(i, 2) = ppm_c3 * q(i, 1) + ppm_c2 * q(i, 2) + ppm_c1 * q(i, 3);
+    }
+  if (bd.edge_n)     // je+1 == npy
+    for (int i = ifirst; i <= ilast; ++i) {
+      al(i, npy - 1) = ppm_c1 * q(i, npy - 3) + ppm_c2 * q(i, npy - 2) + ppm_c3 * q(i, npy - 1);
+      al(i, npy) = 0.5 * (((2. * g.dya(i, npy - 1) + g.dya(i, npy - 2)) * q(i, npy - 1) - g.dya(i, npy - 1) * q(i, npy - 2)) /
+                              (g.dya(i, npy - 2) + g.dya(i, npy - 1)) +
+                          ((2. * g.dya(i, npy) + g.dya(i, npy + 1)) * q(i, npy) - g.dya(i, npy) * q(i, npy + 1)) /
+                              (g.dya(i, npy) + g.dya(i, npy + 1)));
+      al(i, npy + 1) = ppm_c3 * q(i, npy) + ppm_c2 * q(i, npy + 1) + ppm_c1 * q(i, npy + 2);
+    }
   if (jord == 2) {
     for (int j = js; j <= je + 1; ++j)
       for (int i = ifirst; i <= ilast; ++i) {
@@ -98,14 +147,15 @@ void yppm(Arr2<T>& flux, const Arr2<T>& q, const Arr2<T>& c, int jord, int ifirs
 template <class T>
 void deln_flux(int nord, const Bounds& bd, double damp, const Arr2<T>& q, Arr2<T>& fx, Arr2<T>& fy, const Grid& g,
                const Arr2<T>* mass) {
-  assert(!bd.any_edge());  // copy_corners calls are no-ops away from cube corners
   const int is = bd.is, ie = bd.ie, js = bd.js, je = bd.je;
   Arr2<T> fx2(bd), fy2(bd), d2(bd);
   const int i1 = is - 1 - nord, i2 = ie + 1 + nord, j1 = js - 1 - nord, j2 = je + 1 + nord;
   for (int j = j1; j <= j2; ++j)
     for (int i = i1; i <= i2; ++i) d2(i, j) = mass ? q(i, j) : damp * q(i, j);
+  if (nord > 0) copy_corners(d2, 1, bd);
   for (int j = js - nord; j <= je + nord; ++j)
     for (int i = is - nord; i <= ie + nord + 1; ++i) fx2(i, j) = g.del6_v(i, j) * (d2(i - 1, j) - d2(i, j));
+  if (nord > 0) copy_corners(d2, 2, bd);
   for (int j = js - nord; j <= je + nord + 1; ++j)
     for (int i = is - nord; i <= ie + nord; ++i) fy2(i, j) = g.del6_u(i, j) * (d2(i, j - 1) - d2(i, j));
   for (int n = 1; n <= nord; ++n) {
@@ -113,8 +163,10 @@ void deln_flux(int nord, const Bounds& bd, double damp, const Arr2<T>& q, Arr2<T
     for (int j = js - nt - 1; j <= je + nt + 1; ++j)
       for (int i = is - nt - 1; i <= ie + nt + 1; ++i)
         d2(i, j) = (fx2(i, j) - fx2(i + 1, j) + fy2(i, j) - fy2(i, j + 1)) * g.rarea(i, j);
+    copy_corners(d2, 1, bd);
     for (int j = js - nt; j <= je + nt; ++j)
       for (int i = is - nt; i <= ie + nt + 1; ++i) fx2(i, j) = g.del6_v(i, j) * (d2(i, j) - d2(i - 1, j));
+    copy_corners(d2, 2, bd);
     for (int j = js - nt; j <= je + nt + 1; ++j)
       for (int i = is - nt; i <= ie + nt; ++i) fy2(i, j) = g.del6_u(i, j) * (d2(i, j) - d2(i, j - 1));
   }
@@ -136,20 +188,22 @@ void deln_flux(int nord, const Bounds& bd, double damp, const Arr2<T>& q, Arr2<T
 // mfx/mfy non-null → "transport of pt and tracers" branch; mass+nord+damp_c → mass-weighted damping.
 // nord<0 means "nord/damp_c not present".
 template <class T>
-void fv_tp_2d(const Arr2<T>& q, const Arr2<T>& crx, const Arr2<T>& cry, int hord, Arr2<T>& fx, Arr2<T>& fy,
+void fv_tp_2d(const Arr2<T>& q_in, const Arr2<T>& crx, const Arr2<T>& cry, int hord, Arr2<T>& fx, Arr2<T>& fy,
               const Arr2<T>& xfx, const Arr2<T>& yfx, const Grid& g, const Bounds& bd, const Arr2<T>& ra_x,
               const Arr2<T>& ra_y, const Arr2<T>* mfx, const Arr2<T>* mfy, const Arr2<T>* mass, int nord,
               double damp_c) {
   const int is = bd.is, ie = bd.ie, js = bd.js, je = bd.je, isd = bd.isd, ied = bd.ied, jsd = bd.jsd, jed = bd.jed;
   const int ord_in = (hord == 10) ? 8 : hord, ord_ou = hord;
   Arr2<T> q_i(bd), q_j(bd), fx2(bd), fy2(bd), fyy(bd);
-  // copy_corners(q,2) is a no-op on an interior rank (:2046-2118 only touches cube corners)
+  Arr2<T> q = q_in;                 // the reference fills q's corner halo in place (intent(inout))
+  copy_corners(q, 2, bd);           // :138-143
   yppm(fy2, q, cry, ord_in, isd, ied, js, je, bd, g);
   for (int j = js; j <= je + 1; ++j)
     for (int i = isd; i <= ied; ++i) fyy(i, j) = yfx(i, j) * fy2(i, j);
   for (int j = js; j <= je; ++j)
     for (int i = isd; i <= ied; ++i) q_i(i, j) = (q(i, j) * g.area(i, j) + fyy(i, j) - fyy(i, j + 1)) / ra_y(i, j);
   xppm(fx, q_i, crx, ord_ou, is, ie, js, je, bd, g);
+  copy_corners(q, 1, bd);           // :162-167
   xppm(fx2, q, crx, ord_in, is, ie, jsd, jed, bd, g);
   for (int j = jsd; j <= jed; ++j) {
     std::vector<T> fx1(ie + 2 - is + 1);
