@@ -185,6 +185,27 @@ class Dycore:
     def launch_count(self):
         return self.lib.L.fv3lm_launch_count(self.h)
 
+    # ---- face mode (dims.face = 1) -------------------------------------------------------
+    def set_face_data(self, edge, ecorner):
+        """a2b_ord4 edge weights [ntile,4,pj] and extrap_corner factors [ntile,4,3] (cube.cubed_sphere_metrics)."""
+        e = np.ascontiguousarray(edge, dtype=np.float64); c = np.ascontiguousarray(ecorner, dtype=np.float64)
+        assert e.shape == (self.dims.ntile, 4, self.pj) and c.shape == (self.dims.ntile, 4, 3)
+        self.lib.L.fv3lm_set_face_data.argtypes = [C.c_void_p, _dp, _dp]
+        self._chk(self.lib.L.fv3lm_set_face_data(self.h, _ptr(e), _ptr(c)))
+
+    HALO_KINDS = {"cell": 0, "dvec": 1, "cvec": 2, "corner": 3, "dedge": 4}
+
+    def set_exchange(self, kind, rows):
+        """Exchange table of one kind (cube.exchange_table / cube.boundary_table), int32 [n,7]."""
+        r = np.ascontiguousarray(rows, dtype=np.int32)
+        assert r.ndim == 2 and r.shape[1] == 7
+        self.lib.L.fv3lm_set_exchange.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
+        self._chk(self.lib.L.fv3lm_set_exchange(self.h, self.HALO_KINDS[kind], r.ctypes.data_as(C.POINTER(C.c_int)), r.shape[0]))
+
+    def halo(self, kind, name0, name1="", mode=0):
+        self.lib.L.fv3lm_halo.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int]
+        self._chk(self.lib.L.fv3lm_halo(self.h, self.HALO_KINDS[kind], name0.encode(), name1.encode(), mode))
+
     def level_params(self, k):
         ip = (C.c_int * 10)(); rp = (C.c_double * 6)()
         if self.lib.L.fv3lm_level_params(self.h, k, ip, rp) != 0:

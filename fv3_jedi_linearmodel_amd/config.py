@@ -30,7 +30,7 @@ class Options(C.Structure):
 
 
 class Dims(C.Structure):
-    _fields_ = [(n, C.c_int) for n in "nx ny npz ntile nq n_split k_split pad_".split()] + [("dt", C.c_double)]
+    _fields_ = [(n, C.c_int) for n in "nx ny npz ntile nq n_split k_split face".split()] + [("dt", C.c_double)]
 
 
 def default_options(**kw):

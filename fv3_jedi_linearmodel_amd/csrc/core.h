@@ -70,6 +70,7 @@ HD Dual combine(const Dual& a, const Dual& b) { return Dual(a.v, b.d); }
 // All 2-D planes share one padded index map: (isd:ied+1, jsd:jed+1), isd = 1-ng, ng = 3.
 struct Geom {
   int nx, ny, ng, npz, ntile;
+  int face;            // 1: every tile is a whole cube face (is=1, ie=npx-1: edge and corner branches on)
   int pi, pj;          // padded plane dims
   int plane;           // pi*pj
   HD int idx(int i, int j) const { return (j + ng - 1) * pi + (i + ng - 1); }   // local i,j (1-based)
@@ -100,6 +101,8 @@ struct Metrics {
   const double *f0, *fC, *del6_u, *del6_v, *divg_u, *divg_v;
   const double* sin_sg[10];
   const double* cos_sg[10];
+  const double* edge;      // a2b_ord4 edge weights [ntile][4: w,e,s,n][pj] (face mode)
+  const double* ecorner;   // extrap_corner coefficients [ntile][4: sw,se,ne,nw][3] (face mode)
   double da_min, da_min_c;
 };
 constexpr int NMETRIC = 32 + 18;
@@ -160,8 +163,16 @@ struct AccChk {
   static constexpr unsigned want = ~0u;
   template <int M> Dual in(int i, int j, int dk = 0) const {
     Box b = S::box(M);
-    if (i - ei < b.di0 || i - ei > b.di1 || j - ej < b.dj0 || j - ej > b.dj1 || dk < b.dk0 || dk > b.dk1 ||
-        !S::uses(M, i - ei, j - ej, dk)) {
+    bool ok = !(i - ei < b.di0 || i - ei > b.di1 || j - ej < b.dj0 || j - ej > b.dj1 || dk < b.dk0 || dk > b.dk1 ||
+                !S::uses(M, i - ei, j - ej, dk));
+    for (int n = 0; !ok && n < S::NALIAS; ++n) {   // a corner-halo read redirected to (i,j): check the virtual location
+      int ai, aj;
+      if (!s.alias(c, M, i, j, n, ai, aj)) continue;
+      Box ba = S::box(S::alias_box(M));
+      ok = !(ai - ei < ba.di0 || ai - ei > ba.di1 || aj - ej < ba.dj0 || aj - ej > ba.dj1 || dk < ba.dk0 || dk > ba.dk1 ||
+             !S::uses(S::alias_box(M), ai - ei, aj - ej, dk));
+    }
+    if (!ok) {
       std::fprintf(stderr, "stage %s: input %d accessed at offset (%d,%d,%d) outside declared box\n", S::name(), M,
                    i - ei, j - ej, dk);
       std::abort();

@@ -11,6 +11,7 @@
 #include "../../include/fv3lm.h"
 #include "stages.h"
 #include "column.h"
+#include "exchange.h"
 #include <functional>
 #include <map>
 #include <string>
@@ -129,6 +130,10 @@ struct Dycore {
   int ck_base = 0;                    // first acoustic-step slot of the current k_split iteration
   size_t n3 = 0, n3p = 0;             // doubles per npz / npz+1 field
   std::string err;
+  ExTable xt[H_NKIND];                // cube-face exchange tables (face mode), set by set_exchange
+  double *edge_dev = nullptr, *ecorner_dev = nullptr;
+  bool last_acoustic = false;         // the acoustic step being run is the last of its dyn_core call
+  bool halo_missing = false;          // an exchange was needed before its table was set
 
   Fld& f(const char* n) {
     auto it = F.find(n);
@@ -145,10 +150,25 @@ struct Dycore {
     Ctx* cp = &ctx;
     P.push_back(Op{group, [s, cp](Exec& e, int mode) { run(e, mode, s, *cp); }});
   }
-  void add_halo(Program& P, const char* group, Fld fld) {
-    Geom gg = g;
-    P.push_back(Op{group, [fld, gg](Exec& e, int mode) { run_halo(e, mode, gg, fld); }});
+  // Halo update of one field or of a staggered vector pair.  Single tile: doubly-periodic wrap; cube faces:
+  // table-driven exchange (exchange.h).
+  void halo(int mode, int kind, const Fld& f0, const Fld& f1 = Fld{}) {
+    if (!g.face) { run_halo(ex, mode, g, f0); if (f1.t) run_halo(ex, mode, g, f1); return; }
+    if (xt[kind].n == 0) { halo_missing = true; return; }
+    run_exchange(ex, mode, g, xt[kind], f0, f1);
   }
+  // when: 0 every acoustic step, 1 all but the last, 2 the last only (face mode; the periodic wrap does
+  // both jobs at once and ignores it)
+  void add_halo(Program& P, const char* group, int kind, Fld f0, Fld f1 = Fld{}, int when = 0) {
+    Dycore* self = this;
+    P.push_back(Op{group, [self, kind, f0, f1, when](Exec&, int mode) {
+      if (self->g.face && ((when == 1 && self->last_acoustic) || (when == 2 && !self->last_acoustic))) return;
+      if (!self->g.face && when == 2) return;
+      self->halo(mode, kind, f0, f1);
+    }});
+  }
+  bool set_face_data(const double* edge, const double* ecorner);
+  bool set_exchange(int kind, const int* rows, int n);
   void add_accum(Program& P, const char* group, Fld acc, Fld x, Rect r) {
     Geom gg = g;
     P.push_back(Op{group, [acc, x, r, gg](Exec& e, int mode) { run_accum(e, mode, gg, acc, x, r); }, true});
@@ -161,12 +181,14 @@ struct Dycore {
     Fld fy2 = W((pre + "_fy2").c_str(), npz), q_i = W((pre + "_qi").c_str(), npz), fxo = W((pre + "_fxo").c_str(), npz);
     Fld fx2 = W((pre + "_fx2").c_str(), npz), q_j = W((pre + "_qj").c_str(), npz), fyo = W((pre + "_fyo").c_str(), npz);
     TpPpmY a; a.in[0] = q; a.in[1] = cry; a.out[0] = fy2; a.orect[0] = R(isd, ied, js, je + 1); a.k1 = npz; a.hsel = hsel;
+    a.cdir = g.face ? 2 : 0;
     add(P, grp, a);
     TpQi b; b.in[0] = q; b.in[1] = fy2; b.in[2] = yfx; b.in[3] = ray; b.out[0] = q_i; b.orect[0] = R(isd, ied, js, je); b.k1 = npz;
     add(P, grp, b);
     TpPpmX c_; c_.in[0] = q_i; c_.in[1] = crx; c_.out[0] = fxo; c_.orect[0] = R(is, ie + 1, js, je); c_.k1 = npz; c_.hsel = hsel;
     add(P, grp, c_);
     TpPpmX d; d.in[0] = q; d.in[1] = crx; d.out[0] = fx2; d.orect[0] = R(is, ie + 1, jsd, jed); d.k1 = npz; d.hsel = hsel;
+    d.cdir = g.face ? 1 : 0;
     add(P, grp, d);
     TpQj e; e.in[0] = q; e.in[1] = fx2; e.in[2] = xfx; e.in[3] = rax; e.out[0] = q_j; e.orect[0] = R(is, ie, jsd, jed); e.k1 = npz;
     add(P, grp, e);
@@ -185,18 +207,20 @@ struct Dycore {
     t.dsel = dsel; t.use_mass = use_mass;
     add(P, grp, t);
   }
-  // a2b_ord4 (a2b_edge_tlm.F90:48-542), interior: q (nk levels) -> qb on is..ie+1, js..je+1
+  // a2b_ord4 (a2b_edge_tlm.F90:48-542): q (nk levels) -> qb on is..ie+1, js..je+1
   void build_a2b(Program& P, const char* grp, const std::string& pre, Fld q, Fld qb, int nk) {
     const int is = 1, ie = g.nx, js = 1, je = g.ny;
     Fld qx = W((pre + "_qx").c_str(), nk), qy = W((pre + "_qy").c_str(), nk);
-    A2bA a; a.in[0] = q; a.out[0] = qx; a.out[1] = qy; a.orect[0] = R(is, ie + 1, js - 2, je + 2); a.orect[1] = R(is - 2, ie + 2, js, je + 1); a.k1 = nk;
+    A2bA a; a.in[0] = q; a.out[0] = qx; a.out[1] = qy; a.k1 = nk;
+    if (g.face) { a.orect[0] = R(is, ie + 1, js, je); a.orect[1] = R(is, ie, js, je + 1); }
+    else { a.orect[0] = R(is, ie + 1, js - 2, je + 2); a.orect[1] = R(is - 2, ie + 2, js, je + 1); }
     add(P, grp, a);
-    A2bB b; b.in[0] = qx; b.in[1] = qy; b.out[0] = qb; b.orect[0] = R(is, ie + 1, js, je + 1); b.k1 = nk;
+    A2bB b; b.in[0] = qx; b.in[1] = qy; b.in[2] = g.face ? q : Fld{}; b.out[0] = qb; b.orect[0] = R(is, ie + 1, js, je + 1); b.k1 = nk;
     add(P, grp, b);
   }
 
   void build_acoustic();
-  bool init(int nx, int ny, int npz, int ntile, int nq_, double bdt_, int n_split_, int k_split_, const Options& o,
+  bool init(int nx, int ny, int npz, int ntile, int face, int nq_, double bdt_, int n_split_, int k_split_, const Options& o,
             const double* const* metrics_host, double da_min, double da_min_c, const double* phis_host);
   void destroy();
 
@@ -214,14 +238,16 @@ inline void Dycore::run_group(const Program& P, const char* group, int mode, boo
   }
 }
 
-inline bool Dycore::init(int nx, int ny, int npz, int ntile, int nq_, double bdt_, int n_split_, int k_split_,
+inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, double bdt_, int n_split_, int k_split_,
                          const Options& o, const double* const* metrics_host, double da_min, double da_min_c,
                          const double* phis_host) {
-  g.nx = nx; g.ny = ny; g.ng = 3; g.npz = npz; g.ntile = ntile; g.pi = nx + 2 * g.ng + 1; g.pj = ny + 2 * g.ng + 1;
+  g.nx = nx; g.ny = ny; g.ng = 3; g.npz = npz; g.ntile = ntile; g.face = face ? 1 : 0; g.pi = nx + 2 * g.ng + 1; g.pj = ny + 2 * g.ng + 1;
   g.plane = g.pi * g.pj;
   opt = o; bdt = bdt_; n_split = n_split_; k_split = k_split_; nq = nq_;
   if (nx < 8 || ny < 8 || npz < 1) { err = "tile too small (need nx,ny >= 8)"; return false; }
-  if (ntile != 1) { err = "multi-tile cube exchange not built yet: ntile must be 1 (doubly-periodic tile)"; return false; }
+  if (!face && ntile != 1) { err = "ntile > 1 needs face = 1 (whole cube faces); face = 0 is the single doubly-periodic tile"; return false; }
+  if (face && nx != ny) { err = "cube faces are square: nx must equal ny"; return false; }
+  if (ntile < 1) { err = "ntile < 1"; return false; }
   if (o.nord > 1 || o.nord_pert > 1 || o.nord < 0) { err = "nord/nord_pert in {0,1} only"; return false; }
   if (!o.hydrostatic) { err = "non-hydrostatic path (nh_core) not built yet"; return false; }
   lev_host.resize(npz);
@@ -248,6 +274,8 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int nq_, double bdt
   for (int n = 1; n <= 9; ++n) M.sin_sg[n] = metric_dev[m++];
   for (int n = 1; n <= 9; ++n) M.cos_sg[n] = metric_dev[m++];
   M.da_min = da_min; M.da_min_c = da_min_c;
+  edge_dev = (double*)dev_alloc((size_t)ntile * 4 * g.pj * 8); ecorner_dev = (double*)dev_alloc((size_t)ntile * 12 * 8);
+  M.edge = edge_dev; M.ecorner = ecorner_dev;
   hs_dev = (double*)dev_alloc(np * 8);
   if (phis_host) h2d(ex, hs_dev, phis_host, np * 8);
   ctx.g = g; ctx.lev = lev_dev; ctx.nlev = npz;
@@ -259,9 +287,30 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int nq_, double bdt
   return true;
 }
 
+inline bool Dycore::set_face_data(const double* edge, const double* ecorner) {
+  if (!g.face) { err = "set_face_data: handle was not created with face = 1"; return false; }
+  h2d(ex, edge_dev, edge, (size_t)g.ntile * 4 * g.pj * 8);
+  h2d(ex, ecorner_dev, ecorner, (size_t)g.ntile * 12 * 8);
+  return true;
+}
+inline bool Dycore::set_exchange(int kind, const int* rows, int n) {
+  if (!g.face) { err = "set_exchange: handle was not created with face = 1"; return false; }
+  if (kind < 0 || kind >= H_NKIND || n < 0) { err = "set_exchange: bad kind"; return false; }
+  std::vector<int> src, ptr, dst; const char* why = "";
+  if (!build_extable_host(rows, n, g.ntile, g.plane, src, ptr, dst, &why)) { err = why; return false; }
+  ExTable& t = xt[kind];
+  dev_free(t.rows); dev_free(t.src); dev_free(t.ptr); dev_free(t.dst);
+  t.n = n; t.ns = (int)ptr.size() - 1;
+  t.rows = (int*)dev_alloc((size_t)n * 7 * 4 + 4); t.src = (int*)dev_alloc(src.size() * 4 + 4); t.ptr = (int*)dev_alloc(ptr.size() * 4); t.dst = (int*)dev_alloc(dst.size() * 4 + 4);
+  if (n) { h2d(ex, t.rows, rows, (size_t)n * 7 * 4); h2d(ex, t.src, src.data(), src.size() * 4); h2d(ex, t.dst, dst.data(), dst.size() * 4); }
+  h2d(ex, t.ptr, ptr.data(), ptr.size() * 4);
+  return true;
+}
+
 inline void Dycore::destroy() {
   for (double* p : metric_dev) dev_free(p);
-  dev_free(lev_dev); dev_free(hs_dev); dev_free(ckpt);
+  dev_free(lev_dev); dev_free(hs_dev); dev_free(ckpt); dev_free(edge_dev); dev_free(ecorner_dev);
+  for (ExTable& t : xt) { dev_free(t.rows); dev_free(t.src); dev_free(t.ptr); dev_free(t.dst); }
   state.destroy(); work.destroy();
 #ifndef FV3LM_HOST_EMUL
   if (ex.stream) (void)hipStreamDestroy(ex.stream);
@@ -283,9 +332,12 @@ inline void Dycore::build_acoustic() {
   Fld utmp = W("utmp", npz), vtmp = W("vtmp", npz), ua = W("ua", npz), va = W("va", npz);
   { CswInterpA s; s.in[0] = u; s.in[1] = v; s.out[0] = utmp; s.out[1] = vtmp; s.out[2] = ua; s.out[3] = va;
     s.orect[0] = R(isd, ied, js - 1, je + 1); s.orect[1] = R(is - 1, ie + 1, jsd, jed);
-    s.orect[2] = s.orect[3] = R(is - 1, ie + 1, js - 1, je + 1); s.k1 = npz; add(P, "c_sw", s); }
+    s.orect[2] = s.orect[3] = R(is - 1, ie + 1, js - 1, je + 1);
+    if (g.face) for (int n = 0; n < 4; ++n) s.orect[n] = R(isd, ied, jsd, jed);   // 2-point bands + corner views reach the whole halo
+    s.k1 = npz; add(P, "c_sw", s); }
   Fld uc0 = W("uc0", npz), utf = W("utf", npz), vc0 = W("vc0", npz), vtf = W("vtf", npz);
-  { CswInterpC s; s.in[0] = utmp; s.in[1] = vtmp; s.in[2] = u; s.in[3] = v; s.out[0] = uc0; s.out[1] = utf; s.out[2] = vc0; s.out[3] = vtf;
+  const Fld none{};
+  { CswInterpC s; s.in[0] = utmp; s.in[1] = vtmp; s.in[2] = u; s.in[3] = v; s.in[4] = g.face ? ua : none; s.in[5] = g.face ? va : none; s.out[0] = uc0; s.out[1] = utf; s.out[2] = vc0; s.out[3] = vtf;
     s.orect[0] = s.orect[1] = R(is - 1, ie + 2, js - 1, je + 1); s.orect[2] = s.orect[3] = R(is - 1, ie + 1, js - 1, je + 2);
     s.dt2 = dt2; s.k1 = npz; add(P, "c_sw", s); }
   Fld divgd = W("divgd", npz);
@@ -297,12 +349,12 @@ inline void Dycore::build_acoustic() {
   { CswTransport s; s.in[0] = delp; s.in[1] = pt; s.in[2] = utf; s.in[3] = vtf; s.out[0] = delpc; s.out[1] = ptc;
     s.orect[0] = s.orect[1] = R(is - 1, ie + 1, js - 1, je + 1); s.k1 = npz; add(P, "c_sw", s); }
   Fld ke_c = W("ke_c", npz), vort_c = W("vort_c", npz);
-  { CswKeVort s; s.in[0] = ua; s.in[1] = va; s.in[2] = uc0; s.in[3] = vc0; s.out[0] = ke_c; s.out[1] = vort_c;
+  { CswKeVort s; s.in[0] = ua; s.in[1] = va; s.in[2] = uc0; s.in[3] = vc0; s.in[4] = g.face ? u : none; s.in[5] = g.face ? v : none; s.out[0] = ke_c; s.out[1] = vort_c;
     s.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); s.orect[1] = R(is, ie + 1, js, je + 1); s.dt2 = dt2; s.k1 = npz; add(P, "c_sw", s); }
   Fld uc1 = W("uc1", npz), vc1 = W("vc1", npz);
   { CswUpdate s; s.in[0] = uc0; s.in[1] = vc0; s.in[2] = u; s.in[3] = v; s.in[4] = vort_c; s.in[5] = ke_c; s.out[0] = uc1; s.out[1] = vc1;
     s.orect[0] = R(is, ie + 1, js, je); s.orect[1] = R(is, ie, js, je + 1); s.dt2 = dt2; s.k1 = npz; add(P, "c_sw", s); }
-  if (opt.nord > 0) add_halo(P, "halo_divgd", divgd);
+  if (opt.nord > 0) add_halo(P, "halo_divgd", H_CORNER, divgd);
   // ---- geopk (C grid) + p_grad_c
   Fld pe_c = W("pe_c", npz + 1), peln_c = W("peln_c", npz + 1), pkc = W("pkc", npz + 1), gz = W("gz", npz + 1);
   { GeopkArgs a; a.g = g; a.R = R(is - 1, ie + 1, js - 1, je + 1); a.delp = delpc; a.pt = ptc; a.pe = pe_c; a.peln = peln_c; a.pk = pkc;
@@ -311,12 +363,21 @@ inline void Dycore::build_acoustic() {
   Fld uc = W("uc", npz), vc = W("vc", npz);
   { PGradC s; s.in[0] = pkc; s.in[1] = gz; s.in[2] = uc1; s.in[3] = vc1; s.out[0] = uc; s.out[1] = vc;
     s.orect[0] = R(is, ie + 1, js, je); s.orect[1] = R(is, ie, js, je + 1); s.dt2 = dt2; s.k1 = npz; add(P, "p_grad_c", s); }
-  add_halo(P, "halo_uc", uc); add_halo(P, "halo_uc", vc);
+  add_halo(P, "halo_uc", H_CVEC, uc, vc);
   // ---- d_sw
   Fld ut = W("ut", npz), crx = W("crx", npz), xfx = W("xfx", npz), vt = W("vt", npz), cry = W("cry", npz), yfx = W("yfx", npz);
-  { DswWinds s; s.in[0] = uc; s.in[1] = vc; s.out[0] = ut; s.out[1] = crx; s.out[2] = xfx; s.out[3] = vt; s.out[4] = cry; s.out[5] = yfx;
+  if (!g.face) {
+    DswWinds s; s.in[0] = uc; s.in[1] = vc; s.out[0] = ut; s.out[1] = crx; s.out[2] = xfx; s.out[3] = vt; s.out[4] = cry; s.out[5] = yfx;
     s.orect[0] = R(is - 1, ie + 2, jsd, jed); s.orect[1] = s.orect[2] = R(is, ie + 1, jsd, jed);
-    s.orect[3] = R(isd, ied, js - 1, je + 2); s.orect[4] = s.orect[5] = R(isd, ied, js, je + 1); s.dt = dt; s.k1 = npz; add(P, "d_sw", s); }
+    s.orect[3] = R(isd, ied, js - 1, je + 2); s.orect[4] = s.orect[5] = R(isd, ied, js, je + 1); s.dt = dt; s.k1 = npz; add(P, "d_sw", s);
+  } else {
+    Fld ut_a = W("ut_a", npz), vt_a = W("vt_a", npz);
+    { DswWindsA s; s.in[0] = uc; s.in[1] = vc; s.out[0] = ut_a; s.out[1] = vt_a; s.orect[0] = R(is - 1, ie + 2, jsd, jed); s.orect[1] = R(isd, ied, js - 1, je + 2);
+      s.dt = dt; s.k1 = npz; add(P, "d_sw", s); }
+    DswWindsB s; s.in[0] = ut_a; s.in[1] = vt_a; s.in[2] = uc; s.in[3] = vc; s.out[0] = ut; s.out[1] = crx; s.out[2] = xfx; s.out[3] = vt; s.out[4] = cry; s.out[5] = yfx;
+    s.orect[0] = R(is - 1, ie + 2, jsd, jed); s.orect[1] = s.orect[2] = R(is, ie + 1, jsd, jed);
+    s.orect[3] = R(isd, ied, js - 1, je + 2); s.orect[4] = s.orect[5] = R(isd, ied, js, je + 1); s.dt = dt; s.k1 = npz; add(P, "d_sw", s);
+  }
   Fld rax = W("ra_x", npz), ray = W("ra_y", npz);
   { DswRa s; s.in[0] = xfx; s.in[1] = yfx; s.out[0] = rax; s.out[1] = ray; s.orect[0] = R(is, ie, jsd, jed); s.orect[1] = R(isd, ied, js, je);
     s.k1 = npz; add(P, "d_sw", s); }
@@ -328,13 +389,13 @@ inline void Dycore::build_acoustic() {
   { DswUpdateDp s; s.in[0] = delp; s.in[1] = pt; s.in[2] = fx; s.in[3] = fy; s.in[4] = gx; s.in[5] = gy; s.out[0] = delp_o; s.out[1] = pt_o;
     s.orect[0] = s.orect[1] = R(is, ie, js, je); s.k1 = npz; add(P, "d_sw", s); }
   Fld vb = W("vb", npz), ub = W("ub", npz), ke = W("ke", npz);
-  { DswKeWinds s; s.in[0] = uc; s.in[1] = vc; s.out[0] = vb; s.out[1] = ub; s.orect[0] = s.orect[1] = R(is, ie + 1, js, je + 1); s.dt = dt;
+  { DswKeWinds s; s.in[0] = uc; s.in[1] = vc; s.in[2] = g.face ? ut : none; s.in[3] = g.face ? vt : none; s.out[0] = vb; s.out[1] = ub; s.orect[0] = s.orect[1] = R(is, ie + 1, js, je + 1); s.dt = dt;
     s.k1 = npz; add(P, "d_sw", s); }
-  { DswKe s; s.in[0] = vb; s.in[1] = ub; s.in[2] = u; s.in[3] = v; s.out[0] = ke; s.orect[0] = R(is, ie + 1, js, je + 1); s.k1 = npz; add(P, "d_sw", s); }
+  { DswKe s; s.in[0] = vb; s.in[1] = ub; s.in[2] = u; s.in[3] = v; s.in[4] = g.face ? ut : none; s.in[5] = g.face ? vt : none; s.dt = dt; s.out[0] = ke; s.orect[0] = R(is, ie + 1, js, je + 1); s.k1 = npz; add(P, "d_sw", s); }
   Fld wk = W("wk", npz), vorta = W("vort_abs", npz);
   { DswVort s; s.in[0] = u; s.in[1] = v; s.out[0] = wk; s.out[1] = vorta; s.orect[0] = s.orect[1] = R(isd, ied, jsd, jed); s.k1 = npz; add(P, "d_sw", s); }
   Fld da = W("dd_a", npz), db = W("dd_b", npz), dc = W("dd_c", npz), vortb = W("vort_b", npz), ke2 = W("ke2", npz);
-  { DdA s; s.in[0] = divgd; s.in[1] = u; s.in[2] = v; s.in[3] = ua; s.in[4] = va; s.out[0] = da; s.out[1] = db;
+  { DdA s; s.in[0] = divgd; s.in[1] = u; s.in[2] = v; s.in[3] = ua; s.in[4] = va; s.in[5] = g.face ? uc : none; s.in[6] = g.face ? vc : none; s.out[0] = da; s.out[1] = db;
     s.orect[0] = R(is - 1, ie + 1, js, je + 1); s.orect[1] = R(is, ie + 1, js - 1, je + 1); s.k1 = npz; add(P, "d_sw", s); }
   { DdB s; s.in[0] = da; s.in[1] = db; s.out[0] = dc; s.orect[0] = R(is, ie + 1, js, je + 1); s.k1 = npz; add(P, "d_sw", s); }
   build_a2b(P, "d_sw", "a2bw", wk, vortb, npz);
@@ -347,7 +408,7 @@ inline void Dycore::build_acoustic() {
   Fld u_m = W("u_m", npz), v_m = W("v_m", npz);
   { DswUpdateUV s; s.in[0] = u; s.in[1] = v; s.in[2] = ke2; s.in[3] = fxv; s.in[4] = fyv; s.in[5] = wk; s.in[6] = d6; s.out[0] = u_m; s.out[1] = v_m;
     s.orect[0] = R(is, ie, js, je + 1); s.orect[1] = R(is, ie + 1, js, je); s.k1 = npz; add(P, "d_sw", s); }
-  add_halo(P, "halo_dp", delp_o); add_halo(P, "halo_dp", pt_o);
+  add_halo(P, "halo_dp", H_CELL, delp_o); add_halo(P, "halo_dp", H_CELL, pt_o);
   // ---- geopk (D grid) + one_grad_p
   Fld pkd = pk, gzd = W("gzd", npz + 1);
   { GeopkArgs a; a.g = g; a.R = R(is - 2, ie + 2, js - 2, je + 2); a.delp = delp_o; a.pt = pt_o; a.pe = pe; a.peln = peln; a.pk = pkd;
@@ -359,7 +420,8 @@ inline void Dycore::build_acoustic() {
   { OneGradP s; s.in[0] = u_m; s.in[1] = v_m; s.in[2] = pkb; s.in[3] = gzb; s.out[0] = u_o; s.out[1] = v_o;
     s.orect[0] = R(is, ie, js, je + 1); s.orect[1] = R(is, ie + 1, js, je); s.dt = dt; s.ptk = std::pow(opt.ptop, opt.akap); s.k1 = npz;
     add(P, "one_grad_p", s); }
-  add_halo(P, "halo_uv", u_o); add_halo(P, "halo_uv", v_o);
+  // it < n_split: halo update of u, v (:2432-2434); last step: shared edge rows only, mpp_get_boundary (:2418-2431)
+  add_halo(P, "halo_uv", H_DVEC, u_o, v_o, 1); add_halo(P, "halo_uv", H_DEDGE, u_o, v_o, 2);
 }
 
 // n_split acoustic steps.  NL/TL: state fields u,v,delp,pt are advanced in place (via the *_o
@@ -375,6 +437,7 @@ inline void Dycore::dyn_core(int mode) {
     for (int it = 0; it < n_split; ++it) {
       if (mode == MODE_NL)
         for (int n = 0; n < 4; ++n) dev_copy(ex, ckpt + ((size_t)(ck_base + it) * 4 + n) * n3, f(names[n]).t, b3);
+      last_acoustic = (it == n_split - 1);
       run_group(acoustic, nullptr, mode);
       for (int n = 0; n < 4; ++n) {
         dev_copy(ex, f(names[n]).t, f(onames[n]).t, b3);
@@ -386,6 +449,7 @@ inline void Dycore::dyn_core(int mode) {
     for (int it = n_split - 1; it >= 0; --it) {
       for (int n = 0; n < 4; ++n) dev_copy(ex, f(names[n]).t, ckpt + ((size_t)(ck_base + it) * 4 + n) * n3, b3);
       // recompute this step's nonlinear intermediates (flux capacitors left alone)
+      last_acoustic = (it == n_split - 1);
       run_group(acoustic, nullptr, MODE_NL, true);
       zero_work_adjoint();
       for (int n = 0; n < 4; ++n) { dev_copy(ex, f(onames[n]).p, f(names[n]).p, b3); dev_zero(ex, f(names[n]).p, b3); }

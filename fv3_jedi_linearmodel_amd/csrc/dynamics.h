@@ -204,20 +204,19 @@ inline void Dynamics::tracer_ad() {
 
 inline void Dynamics::fv_dynamics(int mode) {
   const size_t b3 = n3 * 8, b3p = n3p * 8;
-  const char* st4[4] = {"u", "v", "delp", "pt"};
   if (mode != MODE_AD) {
     if (mode == MODE_NL) { dev_copy(ex, ck_0, f("pt").t, b3); dev_copy(ex, ck_0 + n3, f("pkz").t, b3); }
     run_group(pt_in, nullptr, mode);
     dev_copy(ex, f("pt").t, f("pt_o").t, b3);
     if (mode == MODE_TL) dev_copy(ex, f("pt").p, f("pt_o").p, b3);
     for (int km = 0; km < k_split; ++km) {
-      for (const char* n : st4) run_halo(ex, mode, g, f(n));
+      halo(mode, H_DVEC, f("u"), f("v")); halo(mode, H_CELL, f("delp")); halo(mode, H_CELL, f("pt"));
       dev_copy(ex, dp1.t, f("delp").t, b3);
       if (mode == MODE_TL) dev_copy(ex, dp1.p, f("delp").p, b3);
       ck_base = km * n_split;
       dyn_core(mode);
       if (nq > 0) {
-        for (int n = 0; n < nq; ++n) run_halo(ex, mode, g, q[n]);
+        for (int n = 0; n < nq; ++n) halo(mode, H_CELL, q[n]);
         if (mode == MODE_NL) {
           for (int n = 0; n < nq; ++n) dev_copy(ex, ckq(km, n), q[n].t, b3);
           const char* mf[4] = {"mfx", "mfy", "cx", "cy"};
@@ -258,12 +257,12 @@ inline void Dynamics::fv_dynamics(int mode) {
       for (int n = 0; n < 4; ++n) dev_copy(ex, f(mf[n]).t, ckm(km, n), b3);
       dev_copy(ex, dp1.t, ckpt + ((size_t)(km * n_split) * 4 + 2) * n3, b3);   // delp at the start of this k_split step
       tracer_ad();
-      for (int n = 0; n < nq; ++n) run_halo(ex, MODE_AD, g, q[n]);
+      for (int n = 0; n < nq; ++n) halo(MODE_AD, H_CELL, q[n]);
     }
     ck_base = km * n_split;
     dyn_core(MODE_AD);
     for_points(ex, Rect{g.isd(), g.ied() + 1, g.jsd(), g.jed() + 1}, g.ntile * g.npz, AccumFn{g, dp1, f("delp"), MODE_AD}, "accum");   // delp.p += dp1.p
-    for (const char* n : st4) run_halo(ex, MODE_AD, g, f(n));
+    halo(MODE_AD, H_CELL, f("pt")); halo(MODE_AD, H_CELL, f("delp")); halo(MODE_AD, H_DVEC, f("u"), f("v"));
   }
   // pt_in: pt(theta_v) = T (1 + zvir qv) / pkz
   dev_copy(ex, f("pt").t, ck_0, b3); dev_copy(ex, f("pkz").t, ck_0 + n3, b3);

@@ -90,6 +90,7 @@ HD void body_ad_one(const S& s, const Ctx& c, const Rect& R, int i, int j, int z
   const int tile = z / f.nk, kk = 1 + z % f.nk;
   constexpr Box b = S::box(M);
   constexpr unsigned want = S::wants(M);
+  if (!want) return;
   if (i < R.i0 + b.di0 || i > R.i1 + b.di1 || j < R.j0 + b.dj0 || j > R.j1 + b.dj1) return;
   double acc = 0.0;
 #pragma unroll
@@ -117,6 +118,69 @@ HD void body_ad_one(const S& s, const Ctx& c, const Rect& R, int i, int j, int z
   }
   f.p[(size_t)(tile * f.nk + kk - 1) * c.g.plane + c.g.idx(i, j)] += acc;
 }
+// Corner-halo reads through an index map (edges.h): input point (i,j) is also read at its alias
+// locations.  Outputs reached only that way are added here, by a second, small launch over the points
+// around the four face corners (the main kernel keeps its fully unrolled fast path).  mask = outputs of
+// this visit not already covered by the main loop or by an earlier alias of the same point.
+template <class S, int M>
+HD void body_ad_alias(const S& s, const Ctx& c, const Rect& R, int i, int j, int z) {
+  const Fld& f = s.in[M];
+  if (!f.p) return;
+  constexpr int MA = S::alias_box(M);
+  constexpr Box b = S::box(M), ba = S::box(MA);
+  constexpr unsigned wm = S::wants(M), wa = S::wants(MA);
+  if (!wa) return;
+  const int tile = z / f.nk, kk = 1 + z % f.nk;
+  double acc = 0.0;
+  for (int n = 0; n < S::NALIAS; ++n) {
+    int qi, qj;
+    if (!s.alias(c, M, i, j, n, qi, qj)) continue;
+    for (int dk = ba.dk0; dk <= ba.dk1; ++dk) {
+      const int k = kk - dk;
+      if (k < s.k0 || k > s.k1) continue;
+      for (int dj = ba.dj0; dj <= ba.dj1; ++dj)
+        for (int di = ba.di0; di <= ba.di1; ++di) {
+          const int oi = qi - di, oj = qj - dj;
+          if (!R.has(oi, oj) || !S::uses(MA, di, dj, dk)) continue;
+          unsigned mask = wa;
+          const int ei = i - oi, ej = j - oj;
+          if (ei >= b.di0 && ei <= b.di1 && ej >= b.dj0 && ej <= b.dj1 && dk >= b.dk0 && dk <= b.dk1 && S::uses(M, ei, ej, dk)) mask &= ~wm;
+          for (int n2 = 0; n2 < n; ++n2) {
+            int pi2, pj2;
+            if (!s.alias(c, M, i, j, n2, pi2, pj2)) continue;
+            const int fi = pi2 - oi, fj = pj2 - oj;
+            if (fi >= ba.di0 && fi <= ba.di1 && fj >= ba.dj0 && fj <= ba.dj1 && S::uses(MA, fi, fj, dk)) mask = 0u;
+          }
+          if (!mask) continue;
+          AccAD<S, M> a{s, c, tile, k, i, j, kk, mask};
+          Dual o[S::NOUT];
+          s.template eval<Dual>(a, c, tile, oi, oj, k, o);
+          for (int m = 0; m < S::NOUT; ++m)
+            if (((mask >> m) & 1u) && s.orect[m].has(oi, oj))
+              acc += o[m].d * s.out[m].p[(size_t)(tile * s.out[m].nk + k - 1) * c.g.plane + c.g.idx(oi, oj)];
+        }
+    }
+  }
+  if (acc != 0.0) f.p[(size_t)(tile * f.nk + kk - 1) * c.g.plane + c.g.idx(i, j)] += acc;
+}
+template <class S, int M, bool END = (M >= S::NIN)>
+struct AdAliasLoop {
+  HD static void run(const S& s, const Ctx& c, const Rect& R, int i, int j, int z) {
+    if (z < c.g.ntile * s.in[M].nk) body_ad_alias<S, M>(s, c, R, i, j, z);
+    AdAliasLoop<S, M + 1>::run(s, c, R, i, j, z);
+  }
+};
+template <class S, int M>
+struct AdAliasLoop<S, M, true> {
+  HD static void run(const S&, const Ctx&, const Rect&, int, int, int) {}
+};
+// the (2 ng)^2 points around face corner cn (0 sw, 1 se, 2 ne, 3 nw), n = 0 .. 4 ng^2 - 1
+HD void corner_block_point(const Geom& g, int cn, int n, int& i, int& j) {
+  const int w = 2 * g.ng;
+  const int i0 = (cn == 0 || cn == 3) ? 1 - g.ng : g.nx + 1 - g.ng, j0 = (cn < 2) ? 1 - g.ng : g.ny + 1 - g.ng;
+  i = i0 + n % w; j = j0 + n / w;
+}
+
 template <class S, int M, bool END = (M >= S::NIN)>
 struct AdLoop {
   HD static void run(const S& s, const Ctx& c, const Rect& R, int i, int j, int z, int nkmax) {
@@ -177,6 +241,13 @@ __global__ void __launch_bounds__(BX* BY) k_stage_ad(S s, Ctx c, Rect R, Rect Q,
   const int i = Q.i0 + blockIdx.x * BX + threadIdx.x, j = Q.j0 + blockIdx.y * BY + threadIdx.y;
   if (i <= Q.i1 && j <= Q.j1) AdLoop<S, 0>::run(s, c, R, i, j, blockIdx.z, nkmax);
 }
+template <class S>
+__global__ void __launch_bounds__(64) k_stage_ad_alias(S s, Ctx c, Rect R) {
+  if ((int)threadIdx.x >= 4 * c.g.ng * c.g.ng) return;
+  int i, j;
+  corner_block_point(c.g, blockIdx.x, threadIdx.x, i, j);
+  AdAliasLoop<S, 0>::run(s, c, R, i, j, blockIdx.y);
+}
 inline dim3 grid_for(const Rect& R, int nz) {
   return dim3((R.i1 - R.i0 + BX) / BX, (R.j1 - R.j0 + BY) / BY, nz);
 }
@@ -206,6 +277,12 @@ void run_ad(Exec& ex, const S& s, const Ctx& c) {
   hipLaunchKernelGGL(k_stage_ad<S>, grid_for(Q, c.g.ntile * nkmax), dim3(BX, BY), 0, ex.stream, s, c, R, Q, nkmax);
   ex.mark_end();
   ex.launches++;
+  if constexpr (S::NALIAS > 0) if (c.g.face) {
+    ex.mark_begin(S::name(), ".ad_corner", 0.);
+    hipLaunchKernelGGL(k_stage_ad_alias<S>, dim3(4, c.g.ntile * nkmax), dim3(64), 0, ex.stream, s, c, R);
+    ex.mark_end();
+    ex.launches++;
+  }
 }
 // generic per-point functor launch: f(i, j, z)
 template <class F>
@@ -256,6 +333,14 @@ void run_ad(Exec& ex, const S& s, const Ctx& c) {
   for (int z = 0; z < c.g.ntile * nkmax; ++z)
     for (int j = Q.j0; j <= Q.j1; ++j)
       for (int i = Q.i0; i <= Q.i1; ++i) AdLoop<S, 0>::run(s, c, R, i, j, z, nkmax);
+  if constexpr (S::NALIAS > 0) if (c.g.face)
+    for (int z = 0; z < c.g.ntile * nkmax; ++z)
+      for (int cn = 0; cn < 4; ++cn)
+        for (int n = 0; n < 4 * c.g.ng * c.g.ng; ++n) {
+          int i, j;
+          corner_block_point(c.g, cn, n, i, j);
+          AdAliasLoop<S, 0>::run(s, c, R, i, j, z);
+        }
   ex.launches++;
 }
 template <class F>

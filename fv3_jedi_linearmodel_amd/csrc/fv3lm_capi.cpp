@@ -32,7 +32,7 @@ int fv3lm_create(fv3lm_handle** out, const fv3lm_dims* dm, const fv3lm_options* 
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail("fv3lm_create: no HIP device visible (this library has no CPU fallback)");
 #endif
   fv3lm_handle* h = new fv3lm_handle;
-  if (!h->d.init(dm->nx, dm->ny, dm->npz, dm->ntile, dm->nq, dm->dt, dm->n_split, dm->k_split, *opt, metrics, da_min,
+  if (!h->d.init(dm->nx, dm->ny, dm->npz, dm->ntile, dm->face, dm->nq, dm->dt, dm->n_split, dm->k_split, *opt, metrics, da_min,
                  da_min_c, phis)) {
     std::string e = h->d.err; delete h; return fail("fv3lm_create: " + e);
   }
@@ -62,29 +62,50 @@ int fv3lm_field_get(fv3lm_handle* h, const char* name, int which, double* host) 
   d2h(h->d.ex, host, which ? f.p : f.t, (size_t)h->d.g.ntile * f.nk * h->d.g.plane * 8);
   return 0;
 }
+// sticky conditions a sweep may have run into
+static int status(fv3lm_handle* h) {
+  if (h->d.halo_missing) return fail("halo exchange needed before fv3lm_set_exchange provided its table (face mode)");
+  if (h->d.tracer_subcycle_error) return fail("tracer_2d: max Courant number >= 1 needs sub-cycling (nsplt > 1), not built yet");
+  return 0;
+}
+int fv3lm_set_face_data(fv3lm_handle* h, const double* edge, const double* ecorner) {
+  if (!edge || !ecorner) return fail("fv3lm_set_face_data: null argument");
+  return h->d.set_face_data(edge, ecorner) ? 0 : fail(h->d.err);
+}
+int fv3lm_set_exchange(fv3lm_handle* h, int kind, const int* rows, int nrows) {
+  if (!rows && nrows > 0) return fail("fv3lm_set_exchange: null table");
+  return h->d.set_exchange(kind, rows, nrows) ? 0 : fail(h->d.err);
+}
+int fv3lm_halo(fv3lm_handle* h, int kind, const char* name0, const char* name1, int mode) {
+  if (mode < 0 || mode > 2 || kind < 0 || kind >= H_NKIND) return fail("bad mode or kind");
+  Fld f0, f1{};
+  auto it = h->d.F.find(name0);
+  if (it == h->d.F.end()) return fail(std::string("unknown field ") + name0);
+  f0 = it->second;
+  if (name1 && name1[0]) { it = h->d.F.find(name1); if (it == h->d.F.end()) return fail(std::string("unknown field ") + name1); f1 = it->second; }
+  h->d.halo(mode, kind, f0, f1);
+  return status(h);
+}
 int fv3lm_run_group(fv3lm_handle* h, const char* group, int mode) {
   if (mode < 0 || mode > 2) return fail("bad mode");
   h->d.run_group(h->d.acoustic, group, mode);
-  return 0;
+  return status(h);
 }
 int fv3lm_dyn_core(fv3lm_handle* h, int mode) {
   if (mode < 0 || mode > 2) return fail("bad mode");
   h->d.dyn_core(mode);
-  return 0;
+  return status(h);
 }
 int fv3lm_pressures(fv3lm_handle* h, int mode) { h->d.pressures(mode); return 0; }
 int fv3lm_tracer_2d(fv3lm_handle* h, int mode) {
   if (mode == MODE_AD) h->d.tracer_ad(); else h->d.tracer_fwd(mode);
-  return h->d.tracer_subcycle_error ? fail("tracer_2d: max Courant number >= 1 needs sub-cycling (nsplt > 1), not built yet") : 0;
+  return status(h);
 }
 int fv3lm_remap(fv3lm_handle* h, int mode, int last_step) { run_remap(h->d.ex, mode, h->d.remap_args(last_step != 0)); return 0; }
-int fv3lm_fv_dynamics(fv3lm_handle* h, int mode) {
-  h->d.fv_dynamics(mode);
-  return h->d.tracer_subcycle_error ? fail("tracer_2d: max Courant number >= 1 needs sub-cycling (nsplt > 1), not built yet") : 0;
-}
-int fv3lm_step_tl(fv3lm_handle* h) { h->d.step_tl(); return h->d.tracer_subcycle_error ? fail("tracer sub-cycling not built") : 0; }
-int fv3lm_step_nl(fv3lm_handle* h) { h->d.step_nl(); return h->d.tracer_subcycle_error ? fail("tracer sub-cycling not built") : 0; }
-int fv3lm_step_ad(fv3lm_handle* h) { h->d.step_ad(); return 0; }
+int fv3lm_fv_dynamics(fv3lm_handle* h, int mode) { h->d.fv_dynamics(mode); return status(h); }
+int fv3lm_step_tl(fv3lm_handle* h) { h->d.step_tl(); return status(h); }
+int fv3lm_step_nl(fv3lm_handle* h) { h->d.step_nl(); return status(h); }
+int fv3lm_step_ad(fv3lm_handle* h) { h->d.step_ad(); return status(h); }
 int fv3lm_zero_work_adjoint(fv3lm_handle* h) { h->d.zero_work_adjoint(); return 0; }
 int fv3lm_sync(fv3lm_handle* h) { dev_sync(h->d.ex); return 0; }
 long fv3lm_launch_count(fv3lm_handle* h) { return h->d.ex.launches; }

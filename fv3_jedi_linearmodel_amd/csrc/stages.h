@@ -1,9 +1,12 @@
 // fv3lm-hip: stage functors of the hydrostatic acoustic step (c_sw, p_grad_c, d_sw, fv_tp_2d,
-// divergence/vorticity damping, a2b_ord4, one_grad_p).  Each stage restates the nonlinear formula of
-// the cited reference lines on a generic scalar T; tangent and adjoint come from exec.h.
-// Interior-rank path: tiles that touch no cube-face edge (edge/corner branches: csrc/edges.h, next).
+// divergence/vorticity damping, a2b_ord4, one_grad_p) and of tracer_2d.  Each stage restates the
+// nonlinear formula of the cited reference lines on a generic scalar T; tangent and adjoint come
+// from exec.h.  Two tile kinds (Geom::face): 0 = no cube edge in the tile (interior MPI rank of the
+// reference; used with the doubly-periodic single tile), 1 = whole cube face with all the
+// `is .EQ. 1` / `j .EQ. npy` / corner branches of the reference (helpers in edges.h).
 #pragma once
 #include "exec.h"
+#include "edges.h"
 
 namespace fv3 {
 
@@ -14,78 +17,85 @@ namespace fv3 {
   Rect orect[NO];                                                    \
   int k0 = 1, k1 = 1;                                                \
   static const char* name() { return NAME; }
-#define STAGE_COMMON(NAME, NI, NO) STAGE_BASE(NAME, NI, NO) STAGE_DEFAULTS_ON
 // Adjoint refinements a stage may override: uses(M, di, dj, dk) = does any output read input M at that
-// offset (exact stencil inside the box); wants(M) = bit mask of the outputs that depend on input M.
-#define STAGE_DEFAULTS_ON                                             \
-  HD static constexpr bool uses(int, int, int, int) { return true; }           \
+// offset (exact stencil inside the box); wants(M) = bit mask of the outputs that depend on input M
+// (0: the input only steers branches).  Stages that read corner-halo points through an index map
+// (edges.h) also declare the inverse map: alias(c, M, i, j, n, ai, aj) = n-th virtual location at which
+// input point (i,j) of input M is read, as seen through the stencil box of input alias_box(M).
+#define STAGE_DEFAULTS_ON                                                      \
+  HD static constexpr bool uses(int, int, int, int) { return true; }          \
   HD static constexpr unsigned wants(int) { return ~0u; }
+#define STAGE_NO_ALIAS                                                         \
+  static constexpr int NALIAS = 0;                                             \
+  HD static constexpr int alias_box(int M) { return M; }                       \
+  HD bool alias(const Ctx&, int, int, int, int, int&, int&) const { return false; }
+#define STAGE_COMMON(NAME, NI, NO) STAGE_BASE(NAME, NI, NO) STAGE_DEFAULTS_ON STAGE_NO_ALIAS
 #define MET(nm, i, j) c.m.nm[c.mi(tile, (i), (j))]
 #define SSG(n, i, j) c.m.sin_sg[n][c.mi(tile, (i), (j))]
 #define CSG(n, i, j) c.m.cos_sg[n][c.mi(tile, (i), (j))]
+#define IN(M, ...) a.template in<M>(__VA_ARGS__)
 
 constexpr double A1 = 0.5625, A2 = -0.0625;            // sw_core_tlm.F90:56-57
 constexpr double P1 = 7. / 12., P2 = -1. / 12.;        // tp_core_tlm.F90 p1,p2
 constexpr double B1 = 7. / 12., B2 = -1. / 12.;        // a2b_edge_tlm.F90 b1,b2
 
-// 1-D PPM flux at the interface between cells -1 and 0 of the line q(d), d = -3..2, Courant number
-// cc (xppm/yppm iord in {1,2,333}: tp_core_tlm.F90:2397-2487).
-template <class T, class Q>
-HD T ppm_flux(int iord, const Q& q, T cc) {
-  if (iord == 1) return (val(cc) > 0.) ? q(-1) : q(0);
+// 1-D PPM flux at interface m (between cells m-1 and m) of a line: q(k), da(k) by absolute cell index
+// (xppm/yppm iord in {1,2,333}: tp_core_tlm.F90:2397-2487; one-sided edge values :2402-2429).
+template <class T, class Q, class D>
+HD T ppm_flux(int iord, bool face, int m, int n1, const Q& q, const D& da, T cc) {
+  if (iord == 1) return (val(cc) > 0.) ? q(m - 1) : q(m);
   if (iord == 2) {
-    T al0 = P1 * (q(-1) + q(0)) + P2 * (q(-2) + q(1));
+    T al0 = ppm_al<T>(face, m, n1, q, da);
     if (val(cc) > 0.) {
-      T alm = P1 * (q(-2) + q(-1)) + P2 * (q(-3) + q(0));
-      T qt = q(-1);
+      T alm = ppm_al<T>(face, m - 1, n1, q, da);
+      T qt = q(m - 1);
       return qt + (1. - cc) * (al0 - qt - cc * (alm + al0 - (qt + qt)));
     } else {
-      T alp = P1 * (q(0) + q(1)) + P2 * (q(-1) + q(2));
-      T qt = q(0);
+      T alp = ppm_al<T>(face, m + 1, n1, q, da);
+      T qt = q(m);
       return qt + (1. + cc) * (al0 - qt + cc * (al0 + alp - (qt + qt)));
     }
   }
   // iord == 333
   if (val(cc) > 0.)
-    return (2.0 * q(0) + 5.0 * q(-1) - q(-2)) / 6.0 - 0.5 * cc * (q(0) - q(-1)) + cc * cc / 6.0 * (q(0) - 2.0 * q(-1) + q(-2));
-  return (2.0 * q(-1) + 5.0 * q(0) - q(1)) / 6.0 - 0.5 * cc * (q(0) - q(-1)) + cc * cc / 6.0 * (q(1) - 2.0 * q(0) + q(-1));
+    return (2.0 * q(m) + 5.0 * q(m - 1) - q(m - 2)) / 6.0 - 0.5 * cc * (q(m) - q(m - 1)) + cc * cc / 6.0 * (q(m) - 2.0 * q(m - 1) + q(m - 2));
+  return (2.0 * q(m - 1) + 5.0 * q(m) - q(m + 1)) / 6.0 - 0.5 * cc * (q(m) - q(m - 1)) + cc * cc / 6.0 * (q(m + 1) - 2.0 * q(m) + q(m - 1));
 }
 
-// xtp_u / ytp_v flux (sw_core_tlm.F90:7272-7486, :7490-7759): same stencils, cfl = c * rd(upwind cell).
-template <class T, class Q>
-HD T tp_uv_flux(int iord, const Q& q, T cc, double rd_m, double rd_0) {
-  if (iord == 1) return (val(cc) > 0.) ? q(-1) : q(0);
+// xtp_u / ytp_v flux at interface m (sw_core_tlm.F90:7272-7486, :7490-7759): cfl = c * rd(upwind cell).
+template <class T, class Q, class D>
+HD T tp_uv_flux(int iord, bool face, int m, int n1, bool row_edge, const Q& q, const D& dd, T cc, double rd_m, double rd_0) {
+  if (iord == 1) return (val(cc) > 0.) ? q(m - 1) : q(m);
   if (iord == 333) {
     if (val(cc) > 0.)
-      return (2.0 * q(0) + 5.0 * q(-1) - q(-2)) / 6.0 - 0.5 * cc * rd_m * (q(0) - q(-1)) +
-             cc * rd_m * cc * rd_m / 6.0 * (q(0) - 2.0 * q(-1) + q(-2));
-    return (2.0 * q(-1) + 5.0 * q(0) - q(1)) / 6.0 - 0.5 * cc * rd_0 * (q(0) - q(-1)) +
-           cc * rd_0 * cc * rd_0 / 6.0 * (q(1) - 2.0 * q(0) + q(-1));
+      return (2.0 * q(m) + 5.0 * q(m - 1) - q(m - 2)) / 6.0 - 0.5 * cc * rd_m * (q(m) - q(m - 1)) +
+             cc * rd_m * cc * rd_m / 6.0 * (q(m) - 2.0 * q(m - 1) + q(m - 2));
+    return (2.0 * q(m - 1) + 5.0 * q(m) - q(m + 1)) / 6.0 - 0.5 * cc * rd_0 * (q(m) - q(m - 1)) +
+           cc * rd_0 * cc * rd_0 / 6.0 * (q(m + 1) - 2.0 * q(m) + q(m - 1));
   }
-  T al0 = P1 * (q(-1) + q(0)) + P2 * (q(-2) + q(1));
+  T bl, br;
   if (val(cc) > 0.) {
-    T alm = P1 * (q(-2) + q(-1)) + P2 * (q(-3) + q(0));
-    T bl = alm - q(-1), br = al0 - q(-1), b0 = bl + br;
+    uv_blbr<T>(face, m - 1, n1, row_edge, q, dd, bl, br);
     T cfl = cc * rd_m;
-    return q(-1) + (1. - cfl) * (br - cfl * b0);
+    return q(m - 1) + (1. - cfl) * (br - cfl * (bl + br));
   }
-  T alp = P1 * (q(0) + q(1)) + P2 * (q(-1) + q(2));
-  T bl = al0 - q(0), br = alp - q(0), b0 = bl + br;
+  uv_blbr<T>(face, m, n1, row_edge, q, dd, bl, br);
   T cfl = cc * rd_0;
-  return q(0) + (1. + cfl) * (bl + cfl * b0);
+  return q(m) + (1. + cfl) * (bl + cfl * (bl + br));
 }
 
 // ===================================================================== c_sw
-// d2a2c_vect A: D-grid winds -> A-grid (sw_core_tlm.F90:6505-6544, :6605-6611)
+// d2a2c_vect A: D-grid winds -> A-grid (sw_core_tlm.F90:6505-6611); within 3 cells of a face edge the
+// 4-point Lagrange interpolation gives way to 2-point averages (:6548-6602, npt = 4).
 struct CswInterpA {
   STAGE_COMMON("CswInterpA", 2, 4)   // in: u v   out: utmp vtmp ua va
   HD static constexpr Box box(int M) { return M == 0 ? Box{0, 0, -1, 2, 0, 0} : Box{-1, 2, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     T ut = T(0.), vt = T(0.);
-    const bool hu = orect[0].has(i, j), hv = orect[1].has(i, j);
-    if (hu) ut = A2 * (a.template in<0>(i, j - 1) + a.template in<0>(i, j + 2)) + A1 * (a.template in<0>(i, j) + a.template in<0>(i, j + 1));
-    if (hv) vt = A2 * (a.template in<1>(i - 1, j) + a.template in<1>(i + 2, j)) + A1 * (a.template in<1>(i, j) + a.template in<1>(i + 1, j));
+    const bool band = c.g.face && (i <= 3 || i >= c.g.nx - 2 || j <= 3 || j >= c.g.ny - 2);
+    if (orect[0].has(i, j)) ut = band ? 0.5 * (IN(0, i, j) + IN(0, i, j + 1)) : A2 * (IN(0, i, j - 1) + IN(0, i, j + 2)) + A1 * (IN(0, i, j) + IN(0, i, j + 1));
+    if (orect[1].has(i, j)) vt = band ? 0.5 * (IN(1, i, j) + IN(1, i + 1, j)) : A2 * (IN(1, i - 1, j) + IN(1, i + 2, j)) + A1 * (IN(1, i, j) + IN(1, i + 1, j));
     o[0] = ut; o[1] = vt;
     const double cs = MET(cosa_s, i, j), r2 = MET(rsin2, i, j);
     o[2] = (ut - vt * cs) * r2;
@@ -93,106 +103,179 @@ struct CswInterpA {
   }
 };
 
-// d2a2c_vect C: A-grid -> C-grid + contravariant flux-form winds (:6655-6661, :6786-6792, :713-733)
+// d2a2c_vect C: A-grid -> C-grid + contravariant flux-form winds (:6617-6803, :713-733).  The corner
+// fixes of utmp/vtmp/ua/va (:6617-6640, :6662-6677, :6726-6760) are read through d2a2c_xview/yview.
 struct CswInterpC {
-  STAGE_BASE("CswInterpC", 4, 4)   // in: utmp vtmp u v   out: uc0 utf vc0 vtf
+  STAGE_BASE("CswInterpC", 6, 4)   // in: utmp vtmp u v ua va   out: uc0 utf vc0 vtf
   double dt2;
   HD static constexpr bool uses(int, int, int, int) { return true; }
-  HD static constexpr unsigned wants(int M) { return M == 0 ? 0x3u : M == 1 ? 0xCu : M == 2 ? 0x8u : 0x2u; }
-  HD static constexpr Box box(int M) { return M == 0 ? Box{-2, 1, 0, 0, 0, 0} : M == 1 ? Box{0, 0, -2, 1, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
+  HD static constexpr unsigned wants(int M) { return (M == 0 || M == 4) ? 0x3u : (M == 1 || M == 5) ? 0xCu : M == 2 ? 0x8u : 0x2u; }
+  HD static constexpr Box box(int M) { return (M == 0 || M == 4) ? Box{-2, 1, 0, 0, 0, 0} : (M == 1 || M == 5) ? Box{0, 0, -2, 1, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
+  static constexpr int NALIAS = 1;
+  HD static constexpr int alias_box(int M) { return M == 0 ? 1 : M == 1 ? 0 : M == 4 ? 5 : M == 5 ? 4 : M; }
+  HD bool alias(const Ctx& c, int M, int i, int j, int, int& ai, int& aj) const {
+    if (M == 1 || M == 5) return d2a2c_xalias(c.g, i, j, ai, aj);
+    if (M == 0 || M == 4) return d2a2c_yalias(c.g, i, j, ai, aj);
+    return false;
+  }
+  template <int MU, int MV, class T, class A>
+  HD T rx(const A& a, const Ctx& c, int i, int j) const {   // utmp / ua as the x-direction pass sees them
+    int oi, oj; double sg;
+    if (c.g.face && d2a2c_xview(c.g, i, j, oi, oj, sg)) return sg * IN(MV, oi, oj);
+    return IN(MU, i, j);
+  }
+  template <int MV, int MU, class T, class A>
+  HD T ry(const A& a, const Ctx& c, int i, int j) const {   // vtmp / va as the y-direction pass sees them
+    int oi, oj; double sg;
+    if (c.g.face && d2a2c_yview(c.g, i, j, oi, oj, sg)) return sg * IN(MU, oi, oj);
+    return IN(MV, i, j);
+  }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = o[2] = o[3] = T(0.);
+    const bool F = c.g.face; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
     if ((a.want & 0x3u) && orect[0].has(i, j)) {
-      T uc = A2 * (a.template in<0>(i - 2, j) + a.template in<0>(i + 1, j)) + A1 * (a.template in<0>(i - 1, j) + a.template in<0>(i, j));
-      T ut = (uc - a.template in<3>(i, j) * MET(cosa_u, i, j)) * MET(rsin_u, i, j);
+      T uc, ut;
+      if (F && (i == 1 || i == npx)) {
+        ut = edge_interp4<T>(rx<4, 5, T>(a, c, i - 2, j), rx<4, 5, T>(a, c, i - 1, j), rx<4, 5, T>(a, c, i, j), rx<4, 5, T>(a, c, i + 1, j),
+                             MET(dxa, i - 2, j), MET(dxa, i - 1, j), MET(dxa, i, j), MET(dxa, i + 1, j));
+        uc = (val(ut) > 0.) ? ut * SSG(3, i - 1, j) : ut * SSG(1, i, j);
+      } else {
+        if (F && (i == 0 || i == npx - 1)) uc = EC1 * rx<0, 1, T>(a, c, i - 2, j) + EC2 * rx<0, 1, T>(a, c, i - 1, j) + EC3 * rx<0, 1, T>(a, c, i, j);
+        else if (F && (i == 2 || i == npx + 1)) uc = EC1 * rx<0, 1, T>(a, c, i + 1, j) + EC2 * rx<0, 1, T>(a, c, i, j) + EC3 * rx<0, 1, T>(a, c, i - 1, j);
+        else uc = A2 * (rx<0, 1, T>(a, c, i - 2, j) + rx<0, 1, T>(a, c, i + 1, j)) + A1 * (rx<0, 1, T>(a, c, i - 1, j) + rx<0, 1, T>(a, c, i, j));
+        ut = (uc - IN(3, i, j) * MET(cosa_u, i, j)) * MET(rsin_u, i, j);
+      }
       o[0] = uc;
       o[1] = (val(ut) > 0.) ? dt2 * ut * MET(dy, i, j) * SSG(3, i - 1, j) : dt2 * ut * MET(dy, i, j) * SSG(1, i, j);
     }
     if ((a.want & 0xCu) && orect[2].has(i, j)) {
-      T vc = A2 * (a.template in<1>(i, j - 2) + a.template in<1>(i, j + 1)) + A1 * (a.template in<1>(i, j - 1) + a.template in<1>(i, j));
-      T vt = (vc - a.template in<2>(i, j) * MET(cosa_v, i, j)) * MET(rsin_v, i, j);
+      T vc, vt;
+      if (F && (j == 1 || j == npy)) {
+        vt = edge_interp4<T>(ry<5, 4, T>(a, c, i, j - 2), ry<5, 4, T>(a, c, i, j - 1), ry<5, 4, T>(a, c, i, j), ry<5, 4, T>(a, c, i, j + 1),
+                             MET(dya, i, j - 2), MET(dya, i, j - 1), MET(dya, i, j), MET(dya, i, j + 1));
+        vc = (val(vt) > 0.) ? vt * SSG(4, i, j - 1) : vt * SSG(2, i, j);
+      } else {
+        if (F && (j == 0 || j == npy - 1)) vc = EC1 * ry<1, 0, T>(a, c, i, j - 2) + EC2 * ry<1, 0, T>(a, c, i, j - 1) + EC3 * ry<1, 0, T>(a, c, i, j);
+        else if (F && (j == 2 || j == npy + 1)) vc = EC1 * ry<1, 0, T>(a, c, i, j + 1) + EC2 * ry<1, 0, T>(a, c, i, j) + EC3 * ry<1, 0, T>(a, c, i, j - 1);
+        else vc = A2 * (ry<1, 0, T>(a, c, i, j - 2) + ry<1, 0, T>(a, c, i, j + 1)) + A1 * (ry<1, 0, T>(a, c, i, j - 1) + ry<1, 0, T>(a, c, i, j));
+        vt = (vc - IN(2, i, j) * MET(cosa_v, i, j)) * MET(rsin_v, i, j);
+      }
       o[2] = vc;
       o[3] = (val(vt) > 0.) ? dt2 * vt * MET(dx, i, j) * SSG(4, i, j - 1) : dt2 * vt * MET(dx, i, j) * SSG(2, i, j);
     }
   }
 };
 
-// divergence_corner (sw_core_tlm.F90:4044-4081)
+// divergence_corner (sw_core_tlm.F90:4036-4081)
 struct CswDivg {
   STAGE_COMMON("CswDivg", 4, 1)   // in: u v ua va   out: divgd
   HD static constexpr Box box(int M) { return M == 0 ? Box{-1, 0, 0, 0, 0, 0} : M == 1 ? Box{0, 0, -1, 0, 0, 0} : Box{-1, 0, -1, 0, 0, 0}; }
   template <class T, class A>
   HD T uf(const A& a, const Ctx& c, int tile, int i, int j) const {
-    return (a.template in<0>(i, j) - 0.25 * (a.template in<3>(i, j - 1) + a.template in<3>(i, j)) * (CSG(4, i, j - 1) + CSG(2, i, j))) *
-           MET(dyc, i, j) * 0.5 * (SSG(4, i, j - 1) + SSG(2, i, j));
+    const double w = MET(dyc, i, j) * 0.5 * (SSG(4, i, j - 1) + SSG(2, i, j));
+    if (c.g.face && (j == 1 || j == c.g.ny + 1)) return IN(0, i, j) * w;
+    return (IN(0, i, j) - 0.25 * (IN(3, i, j - 1) + IN(3, i, j)) * (CSG(4, i, j - 1) + CSG(2, i, j))) * w;
   }
   template <class T, class A>
   HD T vf(const A& a, const Ctx& c, int tile, int i, int j) const {
-    return (a.template in<1>(i, j) - 0.25 * (a.template in<2>(i - 1, j) + a.template in<2>(i, j)) * (CSG(3, i - 1, j) + CSG(1, i, j))) *
-           MET(dxc, i, j) * 0.5 * (SSG(3, i - 1, j) + SSG(1, i, j));
+    const double w = MET(dxc, i, j) * 0.5 * (SSG(3, i - 1, j) + SSG(1, i, j));
+    if (c.g.face && (i == 1 || i == c.g.nx + 1)) return IN(1, i, j) * w;
+    return (IN(1, i, j) - 0.25 * (IN(2, i - 1, j) + IN(2, i, j)) * (CSG(3, i - 1, j) + CSG(1, i, j))) * w;
   }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    T d = vf<T>(a, c, tile, i, j - 1) - vf<T>(a, c, tile, i, j) + (uf<T>(a, c, tile, i - 1, j) - uf<T>(a, c, tile, i, j));
+    const int npx = c.g.nx + 1, npy = c.g.ny + 1;
+    const bool F = c.g.face;
+    const bool drop_lo = F && j == 1 && (i == 1 || i == npx), drop_hi = F && j == npy && (i == 1 || i == npx);   // :4071-4078
+    T d = uf<T>(a, c, tile, i - 1, j) - uf<T>(a, c, tile, i, j);
+    if (!drop_lo) d = d + vf<T>(a, c, tile, i, j - 1);
+    if (!drop_hi) d = d - vf<T>(a, c, tile, i, j);
     o[0] = MET(rarea_c, i, j) * d;
   }
 };
 
-// first-order upwind transport of delp, pt on the C grid (sw_core_tlm.F90:744-808)
+// first-order upwind transport of delp, pt on the C grid (sw_core_tlm.F90:739-808); the corner halo of
+// delp/pt is read through fill2_4corners' x-view for the x-fluxes and y-view otherwise.
 struct CswTransport {
   STAGE_BASE("CswTransport", 4, 2)   // in: delp pt utf vtf   out: delpc ptc
   HD static constexpr bool uses(int M, int di, int dj, int) { return M >= 2 || di == 0 || dj == 0; }
   HD static constexpr unsigned wants(int M) { return M == 1 ? 0x2u : 0x3u; }
   HD static constexpr Box box(int M) { return M < 2 ? Box{-1, 1, -1, 1, 0, 0} : M == 2 ? Box{0, 1, 0, 0, 0, 0} : Box{0, 0, 0, 1, 0, 0}; }
+  static constexpr int NALIAS = 2;
+  HD static constexpr int alias_box(int M) { return M; }
+  HD bool alias(const Ctx& c, int M, int i, int j, int n, int& ai, int& aj) const {
+    return M < 2 && fill2_alias(c.g, n + 1, i, j, ai, aj);
+  }
+  template <int M, class T, class A>
+  HD T rd(const A& a, const Ctx& c, int dir, int i, int j) const { fill2_map(c.g, dir, i, j); return IN(M, i, j); }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     T fx1[2], fx[2], fy1[2], fy[2];
     for (int d = 0; d < 2; ++d) {
-      T ut = a.template in<2>(i + d, j);
+      T ut = IN(2, i + d, j);
       const int iu = (val(ut) > 0.) ? i + d - 1 : i + d;
-      fx1[d] = ut * a.template in<0>(iu, j);
-      fx[d] = fx1[d] * a.template in<1>(iu, j);
-      T vt = a.template in<3>(i, j + d);
+      fx1[d] = ut * rd<0, T>(a, c, 1, iu, j);
+      fx[d] = fx1[d] * rd<1, T>(a, c, 1, iu, j);
+      T vt = IN(3, i, j + d);
       const int ju = (val(vt) > 0.) ? j + d - 1 : j + d;
-      fy1[d] = vt * a.template in<0>(i, ju);
-      fy[d] = fy1[d] * a.template in<1>(i, ju);
+      fy1[d] = vt * rd<0, T>(a, c, 2, i, ju);
+      fy[d] = fy1[d] * rd<1, T>(a, c, 2, i, ju);
     }
     const double ra = MET(rarea, i, j);
-    T dp = a.template in<0>(i, j), p = a.template in<1>(i, j);
+    T dp = rd<0, T>(a, c, 2, i, j), p = rd<1, T>(a, c, 2, i, j);
     T dpc = dp + (fx1[0] - fx1[1] + (fy1[0] - fy1[1])) * ra;
     o[0] = dpc;
     o[1] = (p * dp + (fx[0] - fx[1] + (fy[0] - fy[1])) * ra) / dpc;
   }
 };
 
-// kinetic energy at cell centres and absolute vorticity at corners (sw_core_tlm.F90:870-957)
+// kinetic energy at cell centres and absolute vorticity at corners (sw_core_tlm.F90:853-957)
 struct CswKeVort {
-  STAGE_BASE("CswKeVort", 4, 2)   // in: ua va uc0 vc0   out: ke vort
+  STAGE_BASE("CswKeVort", 6, 2)   // in: ua va uc0 vc0 u v   out: ke vort
+  STAGE_NO_ALIAS
   double dt2;
-  HD static constexpr bool uses(int M, int di, int dj, int) { return M < 2 || (M == 2 ? !(di == 1 && dj == -1) : !(di == -1 && dj == 1)); }
-  HD static constexpr unsigned wants(int M) { return M < 2 ? 0x1u : 0x3u; }
-  HD static constexpr Box box(int M) { return M < 2 ? Box{0, 0, 0, 0, 0, 0} : M == 2 ? Box{0, 1, -1, 0, 0, 0} : Box{-1, 0, 0, 1, 0, 0}; }
+  HD static constexpr bool uses(int M, int di, int dj, int) { return M == 2 ? !(di == 1 && dj == -1) : M == 3 ? !(di == -1 && dj == 1) : true; }
+  HD static constexpr unsigned wants(int M) { return (M < 2 || M > 3) ? 0x1u : 0x3u; }
+  HD static constexpr Box box(int M) {
+    return M < 2 ? Box{0, 0, 0, 0, 0, 0} : M == 2 ? Box{0, 1, -1, 0, 0, 0} : M == 3 ? Box{-1, 0, 0, 1, 0, 0} : M == 4 ? Box{0, 0, 0, 1, 0, 0} : Box{0, 1, 0, 0, 0, 0};
+  }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = T(0.);
+    const bool F = c.g.face; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
     if ((a.want & 0x1u) && orect[0].has(i, j)) {
-      T ua = a.template in<0>(i, j), va = a.template in<1>(i, j);
-      T ku = (val(ua) > 0.) ? a.template in<2>(i, j) : a.template in<2>(i + 1, j);
-      T kv = (val(va) > 0.) ? a.template in<3>(i, j) : a.template in<3>(i, j + 1);
+      T ua = IN(0, i, j), va = IN(1, i, j), ku, kv;
+      if (val(ua) > 0.) {
+        if (F && (i == 1 || i == npx)) ku = IN(2, i, j) * SSG(1, i, j) + IN(5, i, j) * CSG(1, i, j);
+        else ku = IN(2, i, j);
+      } else {
+        if (F && (i == 0 || i == npx - 1)) ku = IN(2, i + 1, j) * SSG(3, i, j) + IN(5, i + 1, j) * CSG(3, i, j);
+        else ku = IN(2, i + 1, j);
+      }
+      if (val(va) > 0.) {
+        if (F && (j == 1 || j == npy)) kv = IN(3, i, j) * SSG(2, i, j) + IN(4, i, j) * CSG(2, i, j);
+        else kv = IN(3, i, j);
+      } else {
+        if (F && (j == 0 || j == npy - 1)) kv = IN(3, i, j + 1) * SSG(4, i, j) + IN(4, i, j + 1) * CSG(4, i, j);
+        else kv = IN(3, i, j + 1);
+      }
       o[0] = (0.5 * dt2) * (ua * ku + va * kv);
     }
-    if (orect[1].has(i, j)) {
-      T v = a.template in<2>(i, j - 1) * MET(dxc, i, j - 1) - a.template in<2>(i, j) * MET(dxc, i, j) +
-            (a.template in<3>(i, j) * MET(dyc, i, j) - a.template in<3>(i - 1, j) * MET(dyc, i - 1, j));
+    if ((a.want & 0x2u) && orect[1].has(i, j)) {
+      const bool drop_m = F && i == 1 && (j == 1 || j == npy), drop_p = F && i == npx && (j == 1 || j == npy);   // :945-948
+      T v = IN(2, i, j - 1) * MET(dxc, i, j - 1) - IN(2, i, j) * MET(dxc, i, j);
+      if (!drop_p) v = v + IN(3, i, j) * MET(dyc, i, j);
+      if (!drop_m) v = v - IN(3, i - 1, j) * MET(dyc, i - 1, j);
       o[1] = MET(fC, i, j) + MET(rarea_c, i, j) * v;
     }
   }
 };
 
-// time-centred C-grid winds (sw_core_tlm.F90:991-1037)
+// time-centred C-grid winds (sw_core_tlm.F90:985-1037)
 struct CswUpdate {
   STAGE_BASE("CswUpdate", 6, 2)   // in: uc0 vc0 u v vort ke   out: uc1 vc1
+  STAGE_NO_ALIAS
   double dt2;
   HD static constexpr bool uses(int M, int di, int dj, int) { return M < 4 || (M == 4 ? !(di == 1 && dj == 1) : !(di == -1 && dj == -1)); }
   HD static constexpr unsigned wants(int M) { return (M == 0 || M == 3) ? 0x1u : (M == 1 || M == 2) ? 0x2u : 0x3u; }
@@ -200,17 +283,18 @@ struct CswUpdate {
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = T(0.);
+    const bool F = c.g.face; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
     if ((a.want & 0x1u) && orect[0].has(i, j)) {
-      T uc = a.template in<0>(i, j);
-      T fy1 = dt2 * (a.template in<3>(i, j) - uc * MET(cosa_u, i, j)) / MET(sina_u, i, j);
-      T fy = (val(fy1) > 0.) ? a.template in<4>(i, j) : a.template in<4>(i, j + 1);
-      o[0] = uc + fy1 * fy + MET(rdxc, i, j) * (a.template in<5>(i - 1, j) - a.template in<5>(i, j));
+      T uc = IN(0, i, j);
+      T fy1 = (F && (i == 1 || i == npx)) ? dt2 * IN(3, i, j) : dt2 * (IN(3, i, j) - uc * MET(cosa_u, i, j)) / MET(sina_u, i, j);
+      T fy = (val(fy1) > 0.) ? IN(4, i, j) : IN(4, i, j + 1);
+      o[0] = uc + fy1 * fy + MET(rdxc, i, j) * (IN(5, i - 1, j) - IN(5, i, j));
     }
     if ((a.want & 0x2u) && orect[1].has(i, j)) {
-      T vc = a.template in<1>(i, j);
-      T fx1 = dt2 * (a.template in<2>(i, j) - vc * MET(cosa_v, i, j)) / MET(sina_v, i, j);
-      T fx = (val(fx1) > 0.) ? a.template in<4>(i, j) : a.template in<4>(i + 1, j);
-      o[1] = vc - fx1 * fx + MET(rdyc, i, j) * (a.template in<5>(i, j - 1) - a.template in<5>(i, j));
+      T vc = IN(1, i, j);
+      T fx1 = (F && (j == 1 || j == npy)) ? dt2 * IN(2, i, j) : dt2 * (IN(2, i, j) - vc * MET(cosa_v, i, j)) / MET(sina_v, i, j);
+      T fx = (val(fx1) > 0.) ? IN(4, i, j) : IN(4, i + 1, j);
+      o[1] = vc - fx1 * fx + MET(rdyc, i, j) * (IN(5, i, j - 1) - IN(5, i, j));
     }
   }
 };
@@ -218,6 +302,7 @@ struct CswUpdate {
 // p_grad_c, hydrostatic (dyn_core_tlm.F90:3310-3334)
 struct PGradC {
   STAGE_BASE("PGradC", 4, 2)   // in: pkc gz (npz+1) uc1 vc1   out: uc2 vc2
+  STAGE_NO_ALIAS
   double dt2;
   HD static constexpr bool uses(int M, int di, int dj, int) { return M >= 2 || !(di == -1 && dj == -1); }
   HD static constexpr unsigned wants(int M) { return M == 2 ? 0x1u : M == 3 ? 0x2u : 0x3u; }
@@ -225,26 +310,37 @@ struct PGradC {
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = T(0.);
-    T pk00 = a.template in<0>(i, j, 0), pk01 = a.template in<0>(i, j, 1);
-    T gz00 = a.template in<1>(i, j, 0), gz01 = a.template in<1>(i, j, 1);
+    T pk00 = IN(0, i, j, 0), pk01 = IN(0, i, j, 1);
+    T gz00 = IN(1, i, j, 0), gz01 = IN(1, i, j, 1);
     T wk0 = pk01 - pk00;
     if ((a.want & 0x1u) && orect[0].has(i, j)) {
-      T pkm0 = a.template in<0>(i - 1, j, 0), pkm1 = a.template in<0>(i - 1, j, 1);
-      T gzm0 = a.template in<1>(i - 1, j, 0), gzm1 = a.template in<1>(i - 1, j, 1);
-      o[0] = a.template in<2>(i, j) + dt2 * MET(rdxc, i, j) / ((pkm1 - pkm0) + wk0) *
-             ((gzm1 - gz00) * (pk01 - pkm0) + (gzm0 - gz01) * (pkm1 - pk00));
+      T pkm0 = IN(0, i - 1, j, 0), pkm1 = IN(0, i - 1, j, 1);
+      T gzm0 = IN(1, i - 1, j, 0), gzm1 = IN(1, i - 1, j, 1);
+      o[0] = IN(2, i, j) + dt2 * MET(rdxc, i, j) / ((pkm1 - pkm0) + wk0) * ((gzm1 - gz00) * (pk01 - pkm0) + (gzm0 - gz01) * (pkm1 - pk00));
     }
     if ((a.want & 0x2u) && orect[1].has(i, j)) {
-      T pkm0 = a.template in<0>(i, j - 1, 0), pkm1 = a.template in<0>(i, j - 1, 1);
-      T gzm0 = a.template in<1>(i, j - 1, 0), gzm1 = a.template in<1>(i, j - 1, 1);
-      o[1] = a.template in<3>(i, j) + dt2 * MET(rdyc, i, j) / ((pkm1 - pkm0) + wk0) *
-             ((gzm1 - gz00) * (pk01 - pkm0) + (gzm0 - gz01) * (pkm1 - pk00));
+      T pkm0 = IN(0, i, j - 1, 0), pkm1 = IN(0, i, j - 1, 1);
+      T gzm0 = IN(1, i, j - 1, 0), gzm1 = IN(1, i, j - 1, 1);
+      o[1] = IN(3, i, j) + dt2 * MET(rdyc, i, j) / ((pkm1 - pkm0) + wk0) * ((gzm1 - gz00) * (pk01 - pkm0) + (gzm0 - gz01) * (pkm1 - pk00));
     }
   }
 };
 
 // ===================================================================== d_sw
-// contravariant winds, Courant numbers, area fluxes (sw_core_tlm.F90:2722-2738, :2932-2968)
+// Courant numbers and area fluxes from the contravariant winds (sw_core_tlm.F90:2932-2968)
+template <class T>
+HD void winds_to_flux_x(const Ctx& c, int tile, int i, int j, double dt, const T& ut, T& crx, T& xfx) {
+  T x = dt * ut;
+  if (val(x) > 0.) { crx = x * MET(rdxa, i - 1, j); xfx = MET(dy, i, j) * x * SSG(3, i - 1, j); }
+  else             { crx = x * MET(rdxa, i, j);     xfx = MET(dy, i, j) * x * SSG(1, i, j); }
+}
+template <class T>
+HD void winds_to_flux_y(const Ctx& c, int tile, int i, int j, double dt, const T& vt, T& cry, T& yfx) {
+  T y = dt * vt;
+  if (val(y) > 0.) { cry = y * MET(rdya, i, j - 1); yfx = MET(dx, i, j) * y * SSG(4, i, j - 1); }
+  else             { cry = y * MET(rdya, i, j);     yfx = MET(dx, i, j) * y * SSG(2, i, j); }
+}
+// contravariant winds, Courant numbers, area fluxes; no face edge in the tile (:2722-2738, :2932-2968)
 struct DswWinds {
   STAGE_COMMON("DswWinds", 2, 6)   // in: uc vc   out: ut crx xfx vt cry yfx
   double dt;
@@ -253,24 +349,89 @@ struct DswWinds {
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     for (int n = 0; n < 6; ++n) o[n] = T(0.);
     if (orect[0].has(i, j)) {
-      T ut = (a.template in<0>(i, j) - 0.25 * MET(cosa_u, i, j) * (a.template in<1>(i - 1, j) + a.template in<1>(i, j) +
-              a.template in<1>(i - 1, j + 1) + a.template in<1>(i, j + 1))) * MET(rsin_u, i, j);
+      T ut = (IN(0, i, j) - 0.25 * MET(cosa_u, i, j) * (IN(1, i - 1, j) + IN(1, i, j) + IN(1, i - 1, j + 1) + IN(1, i, j + 1))) * MET(rsin_u, i, j);
       o[0] = ut;
-      if (orect[1].has(i, j)) {
-        T x = dt * ut;
-        if (val(x) > 0.) { o[1] = x * MET(rdxa, i - 1, j); o[2] = MET(dy, i, j) * x * SSG(3, i - 1, j); }
-        else             { o[1] = x * MET(rdxa, i, j);     o[2] = MET(dy, i, j) * x * SSG(1, i, j); }
-      }
+      if (orect[1].has(i, j)) winds_to_flux_x<T>(c, tile, i, j, dt, ut, o[1], o[2]);
     }
     if (orect[3].has(i, j)) {
-      T vt = (a.template in<1>(i, j) - 0.25 * MET(cosa_v, i, j) * (a.template in<0>(i, j - 1) + a.template in<0>(i + 1, j - 1) +
-              a.template in<0>(i, j) + a.template in<0>(i + 1, j))) * MET(rsin_v, i, j);
+      T vt = (IN(1, i, j) - 0.25 * MET(cosa_v, i, j) * (IN(0, i, j - 1) + IN(0, i + 1, j - 1) + IN(0, i, j) + IN(0, i + 1, j))) * MET(rsin_v, i, j);
       o[3] = vt;
-      if (orect[4].has(i, j)) {
-        T y = dt * vt;
-        if (val(y) > 0.) { o[4] = y * MET(rdya, i, j - 1); o[5] = MET(dx, i, j) * y * SSG(4, i, j - 1); }
-        else             { o[4] = y * MET(rdya, i, j);     o[5] = MET(dx, i, j) * y * SSG(2, i, j); }
-      }
+      if (orect[4].has(i, j)) winds_to_flux_y<T>(c, tile, i, j, dt, vt, o[4], o[5]);
+    }
+  }
+};
+// Face tiles, pass A: the winds away from the edges and the edge-normal values on the edges
+// (:2717-2751, :2768-2776, :2795-2803, :2821-2830).  ut on the two rows next to a south/north edge is
+// left 0 here (pass B).
+struct DswWindsA {
+  STAGE_COMMON("DswWindsA", 2, 2)   // in: uc vc   out: ut_a vt_a
+  double dt;
+  HD static constexpr Box box(int M) { return M == 0 ? Box{0, 1, -1, 0, 0, 0} : Box{-1, 0, 0, 1, 0, 0}; }
+  template <class T, class A>
+  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+    o[0] = o[1] = T(0.);
+    const int npx = c.g.nx + 1, npy = c.g.ny + 1;
+    if (orect[0].has(i, j)) {
+      if (i == 1 || i == npx) { T uc = IN(0, i, j); o[0] = (val(uc) * dt > 0.) ? uc / SSG(3, i - 1, j) : uc / SSG(1, i, j); }
+      else if (!(j == 0 || j == 1 || j == npy - 1 || j == npy))
+        o[0] = (IN(0, i, j) - 0.25 * MET(cosa_u, i, j) * (IN(1, i - 1, j) + IN(1, i, j) + IN(1, i - 1, j + 1) + IN(1, i, j + 1))) * MET(rsin_u, i, j);
+    }
+    if (orect[1].has(i, j)) {
+      if (j == 1 || j == npy) { T vc = IN(1, i, j); o[1] = (val(vc) * dt > 0.) ? vc / SSG(4, i, j - 1) : vc / SSG(2, i, j); }
+      else o[1] = (IN(1, i, j) - 0.25 * MET(cosa_v, i, j) * (IN(0, i, j - 1) + IN(0, i + 1, j - 1) + IN(0, i, j) + IN(0, i + 1, j))) * MET(rsin_v, i, j);
+    }
+  }
+};
+// Pass B: rows/columns next to an edge from the pass-A winds (:2752-2766, :2777-2793, :2804-2819,
+// :2831-2846), the 2x2 systems at the four corners (:2856-2919, which also only read pass-A values),
+// then Courant numbers and area fluxes of the final winds.
+struct DswWindsB {
+  STAGE_COMMON("DswWindsB", 4, 6)   // in: ut_a vt_a uc vc   out: ut crx xfx vt cry yfx
+  double dt;
+  HD static constexpr Box box(int M) { return M < 2 ? Box{-1, 1, -1, 1, 0, 0} : M == 2 ? Box{0, 1, -1, 0, 0, 0} : Box{-1, 0, 0, 1, 0, 0}; }
+  // the four vt around ut(i,j) / the four ut around vt(i,j), one of them (ei,ej) left out
+  template <class T, class A>
+  HD T vt4(const A& a, int i, int j, int ei, int ej) const {
+    T s = T(0.);
+    for (int dj = 0; dj <= 1; ++dj) for (int di = -1; di <= 0; ++di) if (!(i + di == ei && j + dj == ej)) s = s + IN(1, i + di, j + dj);
+    return s;
+  }
+  template <class T, class A>
+  HD T ut4(const A& a, int i, int j, int ei, int ej) const {
+    T s = T(0.);
+    for (int dj = -1; dj <= 0; ++dj) for (int di = 0; di <= 1; ++di) if (!(i + di == ei && j + dj == ej)) s = s + IN(0, i + di, j + dj);
+    return s;
+  }
+  template <class T, class A>
+  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+    for (int n = 0; n < 6; ++n) o[n] = T(0.);
+    const int npx = c.g.nx + 1, npy = c.g.ny + 1;
+    constexpr int NONE = -1000;
+    if (orect[0].has(i, j)) {
+      T ut;
+      const bool erow = (j == 0 || j == 1 || j == npy - 1 || j == npy);
+      if (erow && (i == 2 || i == npx - 1)) {          // corner system: the unknown vt(qi,qj) eliminated
+        const int qi = (i == 2) ? 1 : npx - 1, qj = (j == 0) ? 0 : (j == 1) ? 2 : (j == npy - 1) ? npy - 1 : npy + 1;
+        const double cu = MET(cosa_u, i, j), cv = MET(cosa_v, qi, qj);
+        ut = (IN(2, i, j) - 0.25 * cu * (vt4<T>(a, i, j, qi, qj) + IN(3, qi, qj) - 0.25 * cv * ut4<T>(a, qi, qj, i, j))) * (1. / (1. - 0.0625 * cu * cv));
+      } else if (erow && i >= 3 && i <= npx - 2) {
+        ut = IN(2, i, j) - 0.25 * MET(cosa_u, i, j) * vt4<T>(a, i, j, NONE, NONE);
+      } else ut = IN(0, i, j);
+      o[0] = ut;
+      if (orect[1].has(i, j)) winds_to_flux_x<T>(c, tile, i, j, dt, ut, o[1], o[2]);
+    }
+    if (orect[3].has(i, j)) {
+      T vt;
+      const bool ecol = (i == 0 || i == 1 || i == npx - 1 || i == npx);
+      if (ecol && (j == 2 || j == npy - 1)) {
+        const int qj = (j == 2) ? 1 : npy - 1, qi = (i == 0) ? 0 : (i == 1) ? 2 : (i == npx - 1) ? npx - 1 : npx + 1;
+        const double cv = MET(cosa_v, i, j), cu = MET(cosa_u, qi, qj);
+        vt = (IN(3, i, j) - 0.25 * cv * (ut4<T>(a, i, j, qi, qj) + IN(2, qi, qj) - 0.25 * cu * vt4<T>(a, qi, qj, i, j))) * (1. / (1. - 0.0625 * cu * cv));
+      } else if (ecol && j >= 3 && j <= npy - 2) {
+        vt = IN(3, i, j) - 0.25 * MET(cosa_v, i, j) * ut4<T>(a, i, j, NONE, NONE);
+      } else vt = IN(1, i, j);
+      o[3] = vt;
+      if (orect[4].has(i, j)) winds_to_flux_y<T>(c, tile, i, j, dt, vt, o[4], o[5]);
     }
   }
 };
@@ -282,8 +443,8 @@ struct DswRa {   // sw_core_tlm.F90:2969-2978
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = T(0.);
     const double ar = MET(area, i, j);
-    if (orect[0].has(i, j)) o[0] = ar + (a.template in<0>(i, j) - a.template in<0>(i + 1, j));
-    if (orect[1].has(i, j)) o[1] = ar + (a.template in<1>(i, j) - a.template in<1>(i, j + 1));
+    if (orect[0].has(i, j)) o[0] = ar + (IN(0, i, j) - IN(0, i + 1, j));
+    if (orect[1].has(i, j)) o[1] = ar + (IN(1, i, j) - IN(1, i, j + 1));
   }
 };
 
@@ -292,29 +453,43 @@ enum HordSel { HORD_MT = 0, HORD_VT, HORD_TM, HORD_DP, HORD_TR };
 HD int hord_of(const LevelParams& l, int sel) {
   return sel == HORD_MT ? l.hord_mt : sel == HORD_VT ? l.hord_vt : sel == HORD_TM ? l.hord_tm : sel == HORD_DP ? l.hord_dp : l.hord_tr;
 }
+// Line accessors by absolute cell index along x / y; corner-halo points are read through the
+// copy_corners view of the sweep direction (cdir = 1 for x sweeps, 2 for y sweeps, 0: as stored).
 template <class A, int M>
-struct LineX { const A& a; int i, j; HD auto operator()(int d) const { return a.template in<M>(i + d, j); } };
+struct LineX { const A& a; const Geom& g; int j, cdir; HD auto operator()(int i) const { int ii = i, jj = j; if (cdir) corner_map(g, cdir, ii, jj); return a.template in<M>(ii, jj); } };
 template <class A, int M>
-struct LineY { const A& a; int i, j; HD auto operator()(int d) const { return a.template in<M>(i, j + d); } };
+struct LineY { const A& a; const Geom& g; int i, cdir; HD auto operator()(int j) const { int ii = i, jj = j; if (cdir) corner_map(g, cdir, ii, jj); return a.template in<M>(ii, jj); } };
+struct MetX { const double* p; const Ctx& c; int tile, j; HD double operator()(int i) const { return p[c.mi(tile, i, j)]; } };
+struct MetY { const double* p; const Ctx& c; int tile, i; HD double operator()(int j) const { return p[c.mi(tile, i, j)]; } };
 
 struct TpPpmX {
-  STAGE_COMMON("TpPpmX", 2, 1)   // in: q crx   out: flux
-  int hsel;
+  STAGE_BASE("TpPpmX", 2, 1)   // in: q crx   out: flux
+  STAGE_DEFAULTS_ON
+  int hsel; int cdir = 0;        // cdir = 1: the inner sweep, which covers the halo rows (copy_corners(q,1), :162-171)
   HD static constexpr Box box(int M) { return M == 0 ? Box{-3, 2, 0, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
+  static constexpr int NALIAS = 1;
+  HD static constexpr int alias_box(int M) { return M; }
+  HD bool alias(const Ctx& c, int M, int i, int j, int, int& ai, int& aj) const { return M == 0 && cdir && corner_alias(c.g, cdir, i, j, ai, aj); }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    LineX<A, 0> q{a, i, j};
-    o[0] = ppm_flux<T>(hord_of(c.lev[k - 1], hsel), q, a.template in<1>(i, j));
+    LineX<A, 0> q{a, c.g, j, cdir};
+    MetX da{c.m.dxa, c, tile, j};
+    o[0] = ppm_flux<T>(hord_of(c.lev[k - 1], hsel), c.g.face != 0, i, c.g.nx + 1, q, da, IN(1, i, j));
   }
 };
 struct TpPpmY {
-  STAGE_COMMON("TpPpmY", 2, 1)   // in: q cry   out: flux
-  int hsel;
+  STAGE_BASE("TpPpmY", 2, 1)   // in: q cry   out: flux
+  STAGE_DEFAULTS_ON
+  int hsel; int cdir = 0;        // cdir = 2: the inner sweep, which covers the halo columns (copy_corners(q,2), :138-147)
   HD static constexpr Box box(int M) { return M == 0 ? Box{0, 0, -3, 2, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
+  static constexpr int NALIAS = 1;
+  HD static constexpr int alias_box(int M) { return M; }
+  HD bool alias(const Ctx& c, int M, int i, int j, int, int& ai, int& aj) const { return M == 0 && cdir && corner_alias(c.g, cdir, i, j, ai, aj); }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    LineY<A, 0> q{a, i, j};
-    o[0] = ppm_flux<T>(hord_of(c.lev[k - 1], hsel), q, a.template in<1>(i, j));
+    LineY<A, 0> q{a, c.g, i, cdir};
+    MetY da{c.m.dya, c, tile, i};
+    o[0] = ppm_flux<T>(hord_of(c.lev[k - 1], hsel), c.g.face != 0, j, c.g.ny + 1, q, da, IN(1, i, j));
   }
 };
 struct TpQi {   // tp_core_tlm.F90:149-159
@@ -322,8 +497,8 @@ struct TpQi {   // tp_core_tlm.F90:149-159
   HD static constexpr Box box(int M) { return (M == 1 || M == 2) ? Box{0, 0, 0, 1, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    T f0 = a.template in<2>(i, j) * a.template in<1>(i, j), f1 = a.template in<2>(i, j + 1) * a.template in<1>(i, j + 1);
-    o[0] = (a.template in<0>(i, j) * MET(area, i, j) + f0 - f1) / a.template in<3>(i, j);
+    T f0 = IN(2, i, j) * IN(1, i, j), f1 = IN(2, i, j + 1) * IN(1, i, j + 1);
+    o[0] = (IN(0, i, j) * MET(area, i, j) + f0 - f1) / IN(3, i, j);
   }
 };
 struct TpQj {   // tp_core_tlm.F90:173-181
@@ -331,11 +506,23 @@ struct TpQj {   // tp_core_tlm.F90:173-181
   HD static constexpr Box box(int M) { return (M == 1 || M == 2) ? Box{0, 1, 0, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    T f0 = a.template in<2>(i, j) * a.template in<1>(i, j), f1 = a.template in<2>(i + 1, j) * a.template in<1>(i + 1, j);
-    o[0] = (a.template in<0>(i, j) * MET(area, i, j) + f0 - f1) / a.template in<3>(i, j);
+    T f0 = IN(2, i, j) * IN(1, i, j), f1 = IN(2, i + 1, j) * IN(1, i + 1, j);
+    o[0] = (IN(0, i, j) * MET(area, i, j) + f0 - f1) / IN(3, i, j);
   }
 };
-// deln_flux second-order pass for nord=1: d2 after one Laplacian (tp_core_tlm.F90:1984-2008)
+// del-4 inner Laplacian of deln_flux / del6_vt_flux (nord = 1): d2 after one pass, the corner halo of
+// the damped field read through copy_corners' x-view for the x-differences and y-view for the
+// y-differences (tp_core_tlm.F90:1970-2008, sw_core_tlm.F90:3747-3776).
+template <int M, class T, class A>
+HD T lap_corner(const A& a, const Ctx& c, int tile, int i, int j) {
+  auto rx = [&](int ii, int jj) -> T { corner_map(c.g, 1, ii, jj); return a.template in<M>(ii, jj); };
+  auto ry = [&](int ii, int jj) -> T { corner_map(c.g, 2, ii, jj); return a.template in<M>(ii, jj); };
+  T fxa = MET(del6_v, i, j) * (rx(i - 1, j) - rx(i, j));
+  T fxb = MET(del6_v, i + 1, j) * (rx(i, j) - rx(i + 1, j));
+  T fya = MET(del6_u, i, j) * (ry(i, j - 1) - ry(i, j));
+  T fyb = MET(del6_u, i, j + 1) * (ry(i, j) - ry(i, j + 1));
+  return (fxa - fxb + (fya - fyb)) * MET(rarea, i, j);
+}
 enum DampSel { DAMP_NONE = 0, DAMP_V = 1, DAMP_T = 2 };
 HD void damp_of(const LevelParams& l, int sel, int& nord, double& damp_c) {
   if (sel == DAMP_V) { nord = l.nord_v; damp_c = l.damp_vt; }
@@ -343,10 +530,12 @@ HD void damp_of(const LevelParams& l, int sel, int& nord, double& damp_c) {
   else { nord = -1; damp_c = 0.; }
 }
 struct TpD2 {
-  STAGE_BASE("TpD2", 1, 1)
+  STAGE_BASE("TpD2", 1, 1)   // in: q   out: d2b  (is-1..ie+1, js-1..je+1); zero where the level does not use nord=1
   HD static constexpr bool uses(int, int di, int dj, int) { return di == 0 || dj == 0; }
   HD static constexpr unsigned wants(int) { return 0x1u; }
-    // in: q   out: d2b  (is-1..ie+1, js-1..je+1); zero where the level does not use nord=1
+  static constexpr int NALIAS = 2;
+  HD static constexpr int alias_box(int M) { return M; }
+  HD bool alias(const Ctx& c, int, int i, int j, int n, int& ai, int& aj) const { return corner_alias(c.g, n + 1, i, j, ai, aj); }
   int dsel; int use_mass;
   HD static constexpr Box box(int) { return Box{-1, 1, -1, 1, 0, 0}; }
   template <class T, class A>
@@ -355,23 +544,17 @@ struct TpD2 {
     o[0] = T(0.);
     if (nord != 1 || !(dc > 1.e-4)) return;
     const double damp = use_mass ? 1.0 : (dc * c.m.da_min) * (dc * c.m.da_min);
-    T q0 = a.template in<0>(i, j);
-    T fxa = MET(del6_v, i, j) * (a.template in<0>(i - 1, j) - q0);
-    T fxb = MET(del6_v, i + 1, j) * (q0 - a.template in<0>(i + 1, j));
-    T fya = MET(del6_u, i, j) * (a.template in<0>(i, j - 1) - q0);
-    T fyb = MET(del6_u, i, j + 1) * (q0 - a.template in<0>(i, j + 1));
-    o[0] = damp * ((fxa - fxb + fya - fyb) * MET(rarea, i, j));
+    o[0] = damp * lap_corner<0, T>(a, c, tile, i, j);
   }
 };
 // flux averaging + damping fluxes (tp_core_tlm.F90:187-234, deln_flux :1918-2043)
 struct TpFlux {
   STAGE_BASE("TpFlux", 9, 2)   // in: fx_o fx2 mx fy_o fy2 my q d2b mass   out: fx fy
+  STAGE_NO_ALIAS
   int dsel; int use_mass;
   HD static constexpr bool uses(int M, int di, int dj, int) { return M < 6 || !(di == -1 && dj == -1); }
   HD static constexpr unsigned wants(int M) { return M < 3 ? 0x1u : M < 6 ? 0x2u : 0x3u; }
-  HD static constexpr Box box(int M) {
-    return (M == 6 || M == 7 || M == 8) ? Box{-1, 0, -1, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0};
-  }
+  HD static constexpr Box box(int M) { return (M == 6 || M == 7 || M == 8) ? Box{-1, 0, -1, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     int nord; double dc; damp_of(c.lev[k - 1], dsel, nord, dc);
@@ -380,31 +563,23 @@ struct TpFlux {
     if (dmp) { damp = dc * c.m.da_min; if (nord == 1) damp = damp * damp; }
     o[0] = o[1] = T(0.);
     if ((a.want & 0x1u) && orect[0].has(i, j)) {
-      T f = 0.5 * (a.template in<0>(i, j) + a.template in<1>(i, j)) * a.template in<2>(i, j);
+      T f = 0.5 * (IN(0, i, j) + IN(1, i, j)) * IN(2, i, j);
       if (dmp) {
         T f2;
-        if (nord == 0) {
-          f2 = MET(del6_v, i, j) * (a.template in<6>(i - 1, j) - a.template in<6>(i, j));
-          if (!use_mass) f2 = damp * f2;
-        } else {
-          f2 = MET(del6_v, i, j) * (a.template in<7>(i, j) - a.template in<7>(i - 1, j));
-        }
-        if (use_mass) f = f + (0.5 * damp) * (a.template in<8>(i - 1, j) + a.template in<8>(i, j)) * f2;
+        if (nord == 0) { f2 = MET(del6_v, i, j) * (IN(6, i - 1, j) - IN(6, i, j)); if (!use_mass) f2 = damp * f2; }
+        else f2 = MET(del6_v, i, j) * (IN(7, i, j) - IN(7, i - 1, j));
+        if (use_mass) f = f + (0.5 * damp) * (IN(8, i - 1, j) + IN(8, i, j)) * f2;
         else f = f + f2;
       }
       o[0] = f;
     }
     if ((a.want & 0x2u) && orect[1].has(i, j)) {
-      T f = 0.5 * (a.template in<3>(i, j) + a.template in<4>(i, j)) * a.template in<5>(i, j);
+      T f = 0.5 * (IN(3, i, j) + IN(4, i, j)) * IN(5, i, j);
       if (dmp) {
         T f2;
-        if (nord == 0) {
-          f2 = MET(del6_u, i, j) * (a.template in<6>(i, j - 1) - a.template in<6>(i, j));
-          if (!use_mass) f2 = damp * f2;
-        } else {
-          f2 = MET(del6_u, i, j) * (a.template in<7>(i, j) - a.template in<7>(i, j - 1));
-        }
-        if (use_mass) f = f + (0.5 * damp) * (a.template in<8>(i, j - 1) + a.template in<8>(i, j)) * f2;
+        if (nord == 0) { f2 = MET(del6_u, i, j) * (IN(6, i, j - 1) - IN(6, i, j)); if (!use_mass) f2 = damp * f2; }
+        else f2 = MET(del6_u, i, j) * (IN(7, i, j) - IN(7, i, j - 1));
+        if (use_mass) f = f + (0.5 * damp) * (IN(8, i, j - 1) + IN(8, i, j)) * f2;
         else f = f + f2;
       }
       o[1] = f;
@@ -419,39 +594,65 @@ struct DswUpdateDp {
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     const double ra = MET(rarea, i, j);
-    T dp = a.template in<0>(i, j);
-    T p = a.template in<1>(i, j) * dp + (a.template in<4>(i, j) - a.template in<4>(i + 1, j) + (a.template in<5>(i, j) - a.template in<5>(i, j + 1))) * ra;
-    T dpn = dp + (a.template in<2>(i, j) - a.template in<2>(i + 1, j) + (a.template in<3>(i, j) - a.template in<3>(i, j + 1))) * ra;
+    T dp = IN(0, i, j);
+    T p = IN(1, i, j) * dp + (IN(4, i, j) - IN(4, i + 1, j) + (IN(5, i, j) - IN(5, i, j + 1))) * ra;
+    T dpn = dp + (IN(2, i, j) - IN(2, i + 1, j) + (IN(3, i, j) - IN(3, i, j + 1))) * ra;
     o[0] = dpn;
     o[1] = p / dpn;
   }
 };
 
-// B-grid advective winds for the KE fluxes (sw_core_tlm.F90:3164-3170, :3218-3224)
+// B-grid advective winds for the KE fluxes (sw_core_tlm.F90:3126-3254): standard formula, mean of the
+// edge-normal winds along a face edge, 2-point extrapolation from both sides across it.
 struct DswKeWinds {
-  STAGE_COMMON("DswKeWinds", 2, 2)   // in: uc vc   out: vb ub
+  STAGE_COMMON("DswKeWinds", 4, 2)   // in: uc vc ut vt   out: vb ub
   double dt;
-  HD static constexpr Box box(int M) { return M == 0 ? Box{0, 0, -1, 0, 0, 0} : Box{-1, 0, 0, 0, 0, 0}; }
+  HD static constexpr Box box(int M) { return M == 0 ? Box{0, 0, -1, 0, 0, 0} : M == 1 ? Box{-1, 0, 0, 0, 0, 0} : M == 2 ? Box{0, 0, -2, 1, 0, 0} : Box{-2, 1, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    const double dt5 = 0.5 * dt, cs = MET(cosa, i, j), rs = MET(rsina, i, j);
-    T su = a.template in<0>(i, j - 1) + a.template in<0>(i, j), sv = a.template in<1>(i - 1, j) + a.template in<1>(i, j);
-    o[0] = dt5 * (sv - su * cs) * rs;
-    o[1] = dt5 * (su - sv * cs) * rs;
+    const double dt5 = 0.5 * dt, dt4 = 0.25 * dt;
+    const bool F = c.g.face; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
+    const bool ie_ = F && (i == 1 || i == npx), je_ = F && (j == 1 || j == npy);
+    if (!ie_ && !je_) {
+      const double cs = MET(cosa, i, j), rs = MET(rsina, i, j);
+      T su = IN(0, i, j - 1) + IN(0, i, j), sv = IN(1, i - 1, j) + IN(1, i, j);
+      o[0] = dt5 * (sv - su * cs) * rs;
+      o[1] = dt5 * (su - sv * cs) * rs;
+      return;
+    }
+    if (je_) o[0] = dt5 * (IN(3, i - 1, j) + IN(3, i, j));
+    else o[0] = dt4 * (-IN(3, i - 2, j) + 3. * (IN(3, i - 1, j) + IN(3, i, j)) - IN(3, i + 1, j));
+    if (ie_) o[1] = dt5 * (IN(2, i, j - 1) + IN(2, i, j));
+    else o[1] = dt4 * (-IN(2, i, j - 2) + 3. * (IN(2, i, j - 1) + IN(2, i, j)) - IN(2, i, j + 1));
   }
 };
-// KE = 0.5*(vb*ytp_v + ub*xtp_u) (sw_core_tlm.F90:3197-3254)
+// KE = 0.5*(vb*ytp_v + ub*xtp_u), face corners from the edge-normal winds (sw_core_tlm.F90:3197-3273)
 struct DswKe {
-  STAGE_COMMON("DswKe", 4, 1)   // in: vb ub u v   out: ke
-  HD static constexpr Box box(int M) { return M < 2 ? Box{0, 0, 0, 0, 0, 0} : M == 2 ? Box{-3, 2, 0, 0, 0, 0} : Box{0, 0, -3, 2, 0, 0}; }
+  STAGE_COMMON("DswKe", 6, 1)   // in: vb ub u v ut vt   out: ke
+  double dt;
+  HD static constexpr Box box(int M) { return M < 2 ? Box{0, 0, 0, 0, 0, 0} : M == 2 ? Box{-3, 2, 0, 0, 0, 0} : M == 3 ? Box{0, 0, -3, 2, 0, 0} : M == 4 ? Box{0, 0, -1, 0, 0, 0} : Box{-1, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+    const bool F = c.g.face; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
+    if (F && (i == 1 || i == npx) && (j == 1 || j == npy)) {   // :3258-3273
+      const double dt6 = dt / 6.;
+      if (i == 1 && j == 1)
+        o[0] = dt6 * ((IN(4, 1, 1) + IN(4, 1, 0)) * IN(2, 1, 1) + (IN(5, 1, 1) + IN(5, 0, 1)) * IN(3, 1, 1) + (IN(4, 1, 1) + IN(5, 1, 1)) * IN(2, 0, 1));
+      else if (i == npx && j == 1)
+        o[0] = dt6 * ((IN(4, npx, 1) + IN(4, npx, 0)) * IN(2, npx - 1, 1) + (IN(5, npx, 1) + IN(5, npx - 1, 1)) * IN(3, npx, 1) + (IN(4, npx, 1) - IN(5, npx - 1, 1)) * IN(2, npx, 1));
+      else if (i == npx)
+        o[0] = dt6 * ((IN(4, npx, npy) + IN(4, npx, npy - 1)) * IN(2, npx - 1, npy) + (IN(5, npx, npy) + IN(5, npx - 1, npy)) * IN(3, npx, npy - 1) +
+                      (IN(4, npx, npy - 1) + IN(5, npx - 1, npy)) * IN(2, npx, npy));
+      else
+        o[0] = dt6 * ((IN(4, 1, npy) + IN(4, 1, npy - 1)) * IN(2, 1, npy) + (IN(5, 1, npy) + IN(5, 0, npy)) * IN(3, 1, npy - 1) + (IN(4, 1, npy - 1) - IN(5, 1, npy)) * IN(2, 0, npy));
+      return;
+    }
     const int iord = c.lev[k - 1].hord_mt;
-    T vb = a.template in<0>(i, j), ub = a.template in<1>(i, j);
-    LineY<A, 3> qv{a, i, j};
-    T fv = tp_uv_flux<T>(iord, qv, vb, MET(rdy, i, j - 1), MET(rdy, i, j));
-    LineX<A, 2> qu{a, i, j};
-    T fu = tp_uv_flux<T>(iord, qu, ub, MET(rdx, i - 1, j), MET(rdx, i, j));
+    T vb = IN(0, i, j), ub = IN(1, i, j);
+    LineY<A, 3> qv{a, c.g, i, 0}; MetY ddy{c.m.dy, c, tile, i};
+    T fv = tp_uv_flux<T>(iord, F, j, npy, i == 1 || i == npx, qv, ddy, vb, MET(rdy, i, j - 1), MET(rdy, i, j));
+    LineX<A, 2> qu{a, c.g, j, 0}; MetX ddx{c.m.dx, c, tile, j};
+    T fu = tp_uv_flux<T>(iord, F, i, npx, j == 1 || j == npy, qu, ddx, ub, MET(rdx, i - 1, j), MET(rdx, i, j));
     o[0] = 0.5 * (vb * fv + ub * fu);
   }
 };
@@ -461,8 +662,7 @@ struct DswVort {
   HD static constexpr Box box(int M) { return M == 0 ? Box{0, 0, 0, 1, 0, 0} : Box{0, 1, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    T w = MET(rarea, i, j) * (a.template in<0>(i, j) * MET(dx, i, j) - a.template in<0>(i, j + 1) * MET(dx, i, j + 1) +
-                              (a.template in<1>(i + 1, j) * MET(dy, i + 1, j) - a.template in<1>(i, j) * MET(dy, i, j)));
+    T w = MET(rarea, i, j) * (IN(0, i, j) * MET(dx, i, j) - IN(0, i, j + 1) * MET(dx, i, j + 1) + (IN(1, i + 1, j) * MET(dy, i + 1, j) - IN(1, i, j) * MET(dy, i, j)));
     o[0] = w;
     o[1] = w + MET(f0, i, j);
   }
@@ -470,54 +670,130 @@ struct DswVort {
 
 // ---- divergence damping (compute_divergence_damping, sw_core_tlm.F90:7760-8072), nord in {0,1} ----
 struct DdA {
-  STAGE_BASE("DdA", 5, 2)   // in: divgd u v ua va   out: da db
+  STAGE_BASE("DdA", 7, 2)   // in: divgd u v ua va uc vc (uc, vc: upwind side on a face edge only)   out: da db
+  STAGE_NO_ALIAS
   HD static constexpr bool uses(int M, int di, int dj, int) { return M == 0 ? !(di == 1 && dj == 1) : M == 3 ? dj == 0 : M == 4 ? di == 0 : true; }
-  HD static constexpr unsigned wants(int M) { return M == 0 ? 0x3u : (M == 1 || M == 4) ? 0x1u : 0x2u; }
+  HD static constexpr unsigned wants(int M) { return M == 0 ? 0x3u : (M == 1 || M == 4) ? 0x1u : M >= 5 ? 0x0u : 0x2u; }
   HD static constexpr Box box(int M) { return M == 0 ? Box{0, 1, 0, 1, 0, 0} : (M == 3 || M == 4) ? Box{-1, 0, -1, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     const int nord = c.lev[k - 1].nord;
+    const bool F = c.g.face; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
     o[0] = o[1] = T(0.);
-    if (nord == 0) {   // :7874-7886 (interior)
-      if (orect[0].has(i, j))
-        o[0] = (a.template in<1>(i, j) - 0.5 * (a.template in<4>(i, j - 1) + a.template in<4>(i, j)) * MET(cosa_v, i, j)) * MET(dyc, i, j) * MET(sina_v, i, j);
-      if (orect[1].has(i, j))
-        o[1] = (a.template in<2>(i, j) - 0.5 * (a.template in<3>(i - 1, j) + a.template in<3>(i, j)) * MET(cosa_u, i, j)) * MET(dxc, i, j) * MET(sina_u, i, j);
+    if (nord == 0) {   // :7874-7922
+      if ((a.want & 0x1u) && orect[0].has(i, j)) {
+        if (F && (j == 1 || j == npy)) o[0] = (val(IN(6, i, j)) > 0) ? IN(1, i, j) * MET(dyc, i, j) * SSG(4, i, j - 1) : IN(1, i, j) * MET(dyc, i, j) * SSG(2, i, j);
+        else o[0] = (IN(1, i, j) - 0.5 * (IN(4, i, j - 1) + IN(4, i, j)) * MET(cosa_v, i, j)) * MET(dyc, i, j) * MET(sina_v, i, j);
+      }
+      if ((a.want & 0x2u) && orect[1].has(i, j)) {
+        if (F && (i == 1 || i == npx)) o[1] = (val(IN(5, i, j)) > 0) ? IN(2, i, j) * MET(dxc, i, j) * SSG(3, i - 1, j) : IN(2, i, j) * MET(dxc, i, j) * SSG(1, i, j);
+        else o[1] = (IN(2, i, j) - 0.5 * (IN(3, i - 1, j) + IN(3, i, j)) * MET(cosa_u, i, j)) * MET(dxc, i, j) * MET(sina_u, i, j);
+      }
     } else {           // :7976-7987, nt = 0
-      if (orect[0].has(i, j)) o[0] = (a.template in<0>(i + 1, j) - a.template in<0>(i, j)) * MET(divg_u, i, j);
-      if (orect[1].has(i, j)) o[1] = (a.template in<0>(i, j + 1) - a.template in<0>(i, j)) * MET(divg_v, i, j);
+      if ((a.want & 0x1u) && orect[0].has(i, j)) o[0] = (IN(0, i + 1, j) - IN(0, i, j)) * MET(divg_u, i, j);
+      if ((a.want & 0x2u) && orect[1].has(i, j)) o[1] = (IN(0, i, j + 1) - IN(0, i, j)) * MET(divg_v, i, j);
     }
   }
 };
-struct DdB {   // :7924-7937 (nord=0: delpc) / :7990-8006 (nord>0: new divg_d)
+struct DdB {   // :7924-7937 (nord=0: delpc) / :7990-8006 (nord>0: new divg_d); one term dropped at the face corners
   STAGE_COMMON("DdB", 2, 1)   // in: da db   out: dc
   HD static constexpr Box box(int M) { return M == 0 ? Box{-1, 0, 0, 0, 0, 0} : Box{0, 0, -1, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    o[0] = MET(rarea_c, i, j) * (a.template in<1>(i, j - 1) - a.template in<1>(i, j) + a.template in<0>(i - 1, j) - a.template in<0>(i, j));
+    const bool F = c.g.face; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
+    const bool drop_lo = F && j == 1 && (i == 1 || i == npx), drop_hi = F && j == npy && (i == 1 || i == npx);
+    T d = IN(0, i - 1, j) - IN(0, i, j);
+    if (!drop_lo) d = d + IN(1, i, j - 1);
+    if (!drop_hi) d = d - IN(1, i, j);
+    o[0] = MET(rarea_c, i, j) * d;
   }
 };
-// a2b_ord4 interior (a2b_edge_tlm.F90:163-176, :268-291, :365-420, :441-505)
+// a2b_ord4 (a2b_edge_tlm.F90:48-542): (A) the x- and y-interpolated edge-centred values qx, qy
 struct A2bA {
   STAGE_BASE("A2bA", 1, 2)   // in: q   out: qx qy
+  STAGE_NO_ALIAS
   HD static constexpr bool uses(int, int di, int dj, int) { return di == 0 || dj == 0; }
   HD static constexpr unsigned wants(int) { return 0x3u; }
-  HD static constexpr Box box(int) { return Box{-2, 1, -2, 1, 0, 0}; }
+  HD static constexpr Box box(int) { return Box{-3, 2, -3, 2, 0, 0}; }
+  template <class T, class Q, class D>
+  HD static T edge1(const Q& q, const D& d, int e, int s) {   // qx(1) / qx(npx): e = face cell at the edge, s = +1 (west) / -1 (east); :197-203
+    const double g_in = d(e + s) / d(e), g_ou = d(e - 2 * s) / d(e - s);
+    return 0.5 * (((2. + g_in) * q(e) - q(e + s)) / (1. + g_in) + ((2. + g_ou) * q(e - s) - q(e - 2 * s)) / (1. + g_ou));
+  }
+  template <class T, class Q, class D>
+  HD static T line(bool F, int m, int n1, const Q& q, const D& d) {
+    auto std4 = [&](int k) -> T { return B2 * (q(k - 2) + q(k + 1)) + B1 * (q(k - 1) + q(k)); };
+    if (F) {
+      if (m == 1) return edge1<T>(q, d, 1, 1);
+      if (m == n1) return edge1<T>(q, d, n1 - 1, -1);
+      if (m == 2) { const double g_in = d(2) / d(1); return (3. * (g_in * q(1) + q(2)) - (g_in * edge1<T>(q, d, 1, 1) + std4(3))) / (2. + 2. * g_in); }
+      if (m == n1 - 1) { const double g_in = d(n1 - 2) / d(n1 - 1); return (3. * (q(n1 - 2) + g_in * q(n1 - 1)) - (g_in * edge1<T>(q, d, n1 - 1, -1) + std4(n1 - 2))) / (2. + 2. * g_in); }
+    }
+    return std4(m);
+  }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = T(0.);
-    if (orect[0].has(i, j)) o[0] = B2 * (a.template in<0>(i - 2, j) + a.template in<0>(i + 1, j)) + B1 * (a.template in<0>(i - 1, j) + a.template in<0>(i, j));
-    if (orect[1].has(i, j)) o[1] = B2 * (a.template in<0>(i, j - 2) + a.template in<0>(i, j + 1)) + B1 * (a.template in<0>(i, j - 1) + a.template in<0>(i, j));
+    const bool F = c.g.face;
+    if (orect[0].has(i, j)) { LineX<A, 0> q{a, c.g, j, 0}; MetX d{c.m.dxa, c, tile, j}; o[0] = line<T>(F, i, c.g.nx + 1, q, d); }
+    if (orect[1].has(i, j)) { LineY<A, 0> q{a, c.g, i, 0}; MetY d{c.m.dya, c, tile, i}; o[1] = line<T>(F, j, c.g.ny + 1, q, d); }
   }
 };
+// (B) corner values: 4-point average of qx/qy, the face-edge values and the 3-way extrapolated face corners
 struct A2bB {
-  STAGE_COMMON("A2bB", 2, 1)   // in: qx qy   out: qout
-  HD static constexpr Box box(int M) { return M == 0 ? Box{0, 0, -2, 1, 0, 0} : Box{-2, 1, 0, 0, 0, 0}; }
+  STAGE_COMMON("A2bB", 3, 1)   // in: qx qy q   out: qout
+  HD static constexpr Box box(int M) { return M == 0 ? Box{0, 0, -3, 2, 0, 0} : M == 1 ? Box{-3, 2, 0, 0, 0, 0} : Box{-2, 1, -2, 1, 0, 0}; }
+  template <class T, class A>
+  HD T edge_x(const A& a, const Ctx& c, int tile, int i, int j) const {   // qout(1|npx, j): :179-187, :211-219
+    const int ii = i - 1;     // cells ii, ii+1 straddle the edge
+    auto q2 = [&](int jj) -> T { return (IN(2, ii, jj) * MET(dxa, ii + 1, jj) + IN(2, ii + 1, jj) * MET(dxa, ii, jj)) / (MET(dxa, ii, jj) + MET(dxa, ii + 1, jj)); };
+    const double w = c.m.edge[((size_t)tile * 4 + (i == 1 ? 0 : 1)) * c.g.pj + (j + c.g.ng - 1)];
+    return w * q2(j - 1) + (1. - w) * q2(j);
+  }
+  template <class T, class A>
+  HD T edge_y(const A& a, const Ctx& c, int tile, int i, int j) const {   // qout(i, 1|npy): :294-302, :326-334
+    const int jj = j - 1;
+    auto q1 = [&](int ii) -> T { return (IN(2, ii, jj) * MET(dya, ii, jj + 1) + IN(2, ii, jj + 1) * MET(dya, ii, jj)) / (MET(dya, ii, jj) + MET(dya, ii, jj + 1)); };
+    const double w = c.m.edge[((size_t)tile * 4 + (j == 1 ? 2 : 3)) * c.g.pj + (i + c.g.ng - 1)];
+    return w * q1(i - 1) + (1. - w) * q1(i);
+  }
+  template <class T, class A>
+  HD T qxx(const A& a, const Ctx& c, int tile, int i, int j) const {
+    const int npy = c.g.ny + 1; const double c1 = 2. / 3., c2 = -(1. / 6.);
+    auto s = [&](int jj) -> T { return A2 * (IN(0, i, jj - 2) + IN(0, i, jj + 1)) + A1 * (IN(0, i, jj - 1) + IN(0, i, jj)); };
+    if (c.g.face && j == 2) return c1 * (IN(0, i, 1) + IN(0, i, 2)) + c2 * (edge_y<T>(a, c, tile, i, 1) + s(3));
+    if (c.g.face && j == npy - 1) return c1 * (IN(0, i, npy - 2) + IN(0, i, npy - 1)) + c2 * (edge_y<T>(a, c, tile, i, npy) + s(npy - 2));
+    return s(j);
+  }
+  template <class T, class A>
+  HD T qyy(const A& a, const Ctx& c, int tile, int i, int j) const {
+    const int npx = c.g.nx + 1; const double c1 = 2. / 3., c2 = -(1. / 6.);
+    auto s = [&](int ii) -> T { return A2 * (IN(1, ii - 2, j) + IN(1, ii + 1, j)) + A1 * (IN(1, ii - 1, j) + IN(1, ii, j)); };
+    if (c.g.face && i == 2) return c1 * (IN(1, 1, j) + IN(1, 2, j)) + c2 * (edge_x<T>(a, c, tile, 1, j) + s(3));
+    if (c.g.face && i == npx - 1) return c1 * (IN(1, npx - 2, j) + IN(1, npx - 1, j)) + c2 * (edge_x<T>(a, c, tile, npx, j) + s(npx - 2));
+    return s(i);
+  }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    T qxx = A2 * (a.template in<0>(i, j - 2) + a.template in<0>(i, j + 1)) + A1 * (a.template in<0>(i, j - 1) + a.template in<0>(i, j));
-    T qyy = A2 * (a.template in<1>(i - 2, j) + a.template in<1>(i + 1, j)) + A1 * (a.template in<1>(i - 1, j) + a.template in<1>(i, j));
-    o[0] = 0.5 * (qxx + qyy);
+    const bool F = c.g.face; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
+    if (F && (i == 1 || i == npx) && (j == 1 || j == npy)) {   // :101-139: mean of three extrapolations
+      const int cn = (j == 1) ? (i == 1 ? 0 : 1) : (i == 1 ? 3 : 2);
+      const double* ec = c.m.ecorner + ((size_t)tile * 4 + cn) * 3;
+      const int si = (i == 1) ? 1 : -1, sj = (j == 1) ? 1 : -1;           // direction into the face
+      const int ci = (i == 1) ? 1 : npx - 1, cj = (j == 1) ? 1 : npy - 1;   // the face cell at the corner
+      T r1 = IN(2, ci, cj) + ec[0] * (IN(2, ci, cj) - IN(2, ci + si, cj + sj));
+      T q2a, q2b, q3a, q3b;   // the cells across the two edges and their diagonal successors (order of the reference)
+      if (cn == 0)      { q2a = IN(2, 0, 1); q2b = IN(2, -1, 2); q3a = IN(2, 1, 0); q3b = IN(2, 2, -1); }
+      else if (cn == 1) { q2a = IN(2, npx - 1, 0); q2b = IN(2, npx - 2, -1); q3a = IN(2, npx, 1); q3b = IN(2, npx + 1, 2); }
+      else if (cn == 2) { q2a = IN(2, npx, npy - 1); q2b = IN(2, npx + 1, npy - 2); q3a = IN(2, npx - 1, npy); q3b = IN(2, npx - 2, npy + 1); }
+      else              { q2a = IN(2, 0, npy - 1); q2b = IN(2, -1, npy - 2); q3a = IN(2, 1, npy); q3b = IN(2, 2, npy + 1); }
+      T r2 = q2a + ec[1] * (q2a - q2b), r3 = q3a + ec[2] * (q3a - q3b);
+      o[0] = (r1 + r2 + r3) * (1. / 3.);
+      return;
+    }
+    if (F && (i == 1 || i == npx)) { o[0] = edge_x<T>(a, c, tile, i, j); return; }
+    if (F && (j == 1 || j == npy)) { o[0] = edge_y<T>(a, c, tile, i, j); return; }
+    o[0] = 0.5 * (qxx<T>(a, c, tile, i, j) + qyy<T>(a, c, tile, i, j));
   }
 };
 struct DdC {   // Smagorinsky-type coefficient and damping term added to KE (:7938-7956, :8023-8070)
@@ -528,7 +804,7 @@ struct DdC {   // Smagorinsky-type coefficient and damping term added to KE (:79
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     const LevelParams& l = c.lev[k - 1];
     const double absdt = dt >= 0. ? dt : -dt;
-    T ke = a.template in<0>(i, j), dcv = a.template in<1>(i, j);
+    T ke = IN(0, i, j), dcv = IN(1, i, j);
     if (l.nord == 0) {
       T x = dcv * dt;
       T abs2 = (val(x) >= 0.) ? x : -x;
@@ -537,12 +813,9 @@ struct DdC {   // Smagorinsky-type coefficient and damping term added to KE (:79
       T mx = (l.d2_divg < val(y1)) ? y1 : T(l.d2_divg);
       o[0] = ke + (c.m.da_min_c * mx) * dcv;
     } else {
-      T delpc = a.template in<2>(i, j);
+      T delpc = IN(2, i, j);
       T vs = T(0.);
-      if (!(dddmp < 1.e-5)) {
-        T vb = a.template in<3>(i, j);
-        vs = absdt * dsqrt(delpc * delpc + vb * vb);
-      }
+      if (!(dddmp < 1.e-5)) { T vb = IN(3, i, j); vs = absdt * dsqrt(delpc * delpc + vb * vb); }
       T y2 = (0.20 > dddmp * val(vs)) ? dddmp * vs : T(0.20);
       T mx = (l.d2_divg < val(y2)) ? y2 : T(l.d2_divg);
       const double pw = c.m.da_min_c * d4_bg;
@@ -557,103 +830,92 @@ struct Del6A {
   STAGE_BASE("Del6A", 1, 1)   // in: wk   out: d2b
   HD static constexpr bool uses(int, int di, int dj, int) { return di == 0 || dj == 0; }
   HD static constexpr unsigned wants(int) { return 0x1u; }
+  static constexpr int NALIAS = 2;
+  HD static constexpr int alias_box(int M) { return M; }
+  HD bool alias(const Ctx& c, int, int i, int j, int n, int& ai, int& aj) const { return corner_alias(c.g, n + 1, i, j, ai, aj); }
   HD static constexpr Box box(int) { return Box{-1, 1, -1, 1, 0, 0}; }
   template <class T, class A>
-  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    T q0 = a.template in<0>(i, j);
-    T fxa = MET(del6_v, i, j) * (a.template in<0>(i - 1, j) - q0);
-    T fxb = MET(del6_v, i + 1, j) * (q0 - a.template in<0>(i + 1, j));
-    T fya = MET(del6_u, i, j) * (a.template in<0>(i, j - 1) - q0);
-    T fyb = MET(del6_u, i, j + 1) * (q0 - a.template in<0>(i, j + 1));
-    o[0] = (fxa - fxb + (fya - fyb)) * MET(rarea, i, j);
-  }
+  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const { o[0] = lap_corner<0, T>(a, c, tile, i, j); }
 };
 // momentum update (sw_core_tlm.F90:3555-3564) + vorticity-damping fluxes, trajectory and
 // perturbation coefficients kept apart (sw_core_tlm.F90:2436-2452, :2502-2530)
 struct DswUpdateUV {
   STAGE_BASE("DswUpdateUV", 7, 2)   // in: u v ke2 fxv fyv wk d2b   out: u_n v_n
+  STAGE_NO_ALIAS
   HD static constexpr bool uses(int M, int di, int dj, int) { return M == 2 ? !(di == 1 && dj == 1) : (M == 5 || M == 6) ? !(di == -1 && dj == -1) : true; }
   HD static constexpr unsigned wants(int M) { return (M == 0 || M == 4) ? 0x1u : (M == 1 || M == 3) ? 0x2u : 0x3u; }
-  HD static constexpr Box box(int M) {
-    return M == 2 ? Box{0, 1, 0, 1, 0, 0} : (M == 5 || M == 6) ? Box{-1, 0, -1, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0};
-  }
+  HD static constexpr Box box(int M) { return M == 2 ? Box{0, 1, 0, 1, 0, 0} : (M == 5 || M == 6) ? Box{-1, 0, -1, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
   HD static double pw(double x, int n) { double r = x; for (int m = 0; m < n; ++m) r *= x; return r; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     const LevelParams& l = c.lev[k - 1];
     const bool dt_ = l.damp_vt > 1.e-5, dp_ = l.damp_vt_pert > 1.e-5;
     const double d4t = dt_ ? pw(l.damp_vt * c.m.da_min_c, l.nord_v) : 0., d4p = dp_ ? pw(l.damp_vt_pert * c.m.da_min_c, l.nord_v_pert) : 0.;
-    T ke = a.template in<2>(i, j);
+    T ke = IN(2, i, j);
     o[0] = o[1] = T(0.);
     if ((a.want & 0x1u) && orect[0].has(i, j)) {
       T e0 = T(0.), e1 = T(0.);
-      if ((dt_ && l.nord_v == 0) || (dp_ && l.nord_v_pert == 0)) e0 = MET(del6_u, i, j) * (a.template in<5>(i, j - 1) - a.template in<5>(i, j));
-      if ((dt_ && l.nord_v == 1) || (dp_ && l.nord_v_pert == 1)) e1 = MET(del6_u, i, j) * (a.template in<6>(i, j) - a.template in<6>(i, j - 1));
+      if ((dt_ && l.nord_v == 0) || (dp_ && l.nord_v_pert == 0)) e0 = MET(del6_u, i, j) * (IN(5, i, j - 1) - IN(5, i, j));
+      if ((dt_ && l.nord_v == 1) || (dp_ && l.nord_v_pert == 1)) e1 = MET(del6_u, i, j) * (IN(6, i, j) - IN(6, i, j - 1));
       T vt_t = d4t * (l.nord_v == 0 ? e0 : e1), vt_p = d4p * (l.nord_v_pert == 0 ? e0 : e1);
-      o[0] = a.template in<0>(i, j) * MET(dx, i, j) + (ke - a.template in<2>(i + 1, j)) + a.template in<4>(i, j) + combine(vt_t, vt_p);
+      o[0] = IN(0, i, j) * MET(dx, i, j) + (ke - IN(2, i + 1, j)) + IN(4, i, j) + combine(vt_t, vt_p);
     }
     if ((a.want & 0x2u) && orect[1].has(i, j)) {
       T e0 = T(0.), e1 = T(0.);
-      if ((dt_ && l.nord_v == 0) || (dp_ && l.nord_v_pert == 0)) e0 = MET(del6_v, i, j) * (a.template in<5>(i - 1, j) - a.template in<5>(i, j));
-      if ((dt_ && l.nord_v == 1) || (dp_ && l.nord_v_pert == 1)) e1 = MET(del6_v, i, j) * (a.template in<6>(i, j) - a.template in<6>(i - 1, j));
+      if ((dt_ && l.nord_v == 0) || (dp_ && l.nord_v_pert == 0)) e0 = MET(del6_v, i, j) * (IN(5, i - 1, j) - IN(5, i, j));
+      if ((dt_ && l.nord_v == 1) || (dp_ && l.nord_v_pert == 1)) e1 = MET(del6_v, i, j) * (IN(6, i, j) - IN(6, i - 1, j));
       T ut_t = d4t * (l.nord_v == 0 ? e0 : e1), ut_p = d4p * (l.nord_v_pert == 0 ? e0 : e1);
-      o[1] = a.template in<1>(i, j) * MET(dy, i, j) + (ke - a.template in<2>(i, j + 1)) - a.template in<3>(i, j) - combine(ut_t, ut_p);
+      o[1] = IN(1, i, j) * MET(dy, i, j) + (ke - IN(2, i, j + 1)) - IN(3, i, j) - combine(ut_t, ut_p);
     }
   }
 };
 
 // ===================================================================== tracer_2d (fv_tracer2d_tlm.F90:1148-1446)
-// accumulated Courant numbers -> area fluxes (:1226-1247)
-struct TrFlux {
+struct TrFlux {   // accumulated Courant numbers -> area fluxes (:1226-1247)
   STAGE_COMMON("TrFlux", 2, 2)   // in: cx cy   out: xfx yfx
   HD static constexpr Box box(int) { return Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = T(0.);
     if (orect[0].has(i, j)) {
-      T cx = a.template in<0>(i, j);
+      T cx = IN(0, i, j);
       o[0] = (val(cx) > 0.) ? cx * MET(dxa, i - 1, j) * MET(dy, i, j) * SSG(3, i - 1, j) : cx * MET(dxa, i, j) * MET(dy, i, j) * SSG(1, i, j);
     }
     if (orect[1].has(i, j)) {
-      T cy = a.template in<1>(i, j);
+      T cy = IN(1, i, j);
       o[1] = (val(cy) > 0.) ? cy * MET(dya, i, j - 1) * MET(dx, i, j) * SSG(4, i, j - 1) : cy * MET(dya, i, j) * MET(dx, i, j) * SSG(2, i, j);
     }
   }
 };
-// dp2 and the flux-form areas (:1375-1392)
-struct TrDp2Ra {
+struct TrDp2Ra {   // dp2 and the flux-form areas (:1375-1392)
   STAGE_COMMON("TrDp2Ra", 5, 3)   // in: dp1 mfx mfy xfx yfx   out: dp2 ra_x ra_y
   HD static constexpr Box box(int M) { return M == 0 ? Box{0, 0, 0, 0, 0, 0} : (M == 1 || M == 3) ? Box{0, 1, 0, 0, 0, 0} : Box{0, 0, 0, 1, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = o[2] = T(0.);
     const double ar = MET(area, i, j);
-    if (orect[0].has(i, j))
-      o[0] = a.template in<0>(i, j) + (a.template in<1>(i, j) - a.template in<1>(i + 1, j) + (a.template in<2>(i, j) - a.template in<2>(i, j + 1))) * MET(rarea, i, j);
-    if (orect[1].has(i, j)) o[1] = ar + (a.template in<3>(i, j) - a.template in<3>(i + 1, j));
-    if (orect[2].has(i, j)) o[2] = ar + (a.template in<4>(i, j) - a.template in<4>(i, j + 1));
+    if (orect[0].has(i, j)) o[0] = IN(0, i, j) + (IN(1, i, j) - IN(1, i + 1, j) + (IN(2, i, j) - IN(2, i, j + 1))) * MET(rarea, i, j);
+    if (orect[1].has(i, j)) o[1] = ar + (IN(3, i, j) - IN(3, i + 1, j));
+    if (orect[2].has(i, j)) o[2] = ar + (IN(4, i, j) - IN(4, i, j + 1));
   }
 };
-// q update (:1423-1430)
-struct TrUpdate {
+struct TrUpdate {   // q update (:1423-1430)
   STAGE_COMMON("TrUpdate", 5, 1)   // in: q dp1 dp2 fx fy   out: q_o
   HD static constexpr Box box(int M) { return M == 3 ? Box{0, 1, 0, 0, 0, 0} : M == 4 ? Box{0, 0, 0, 1, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    o[0] = (a.template in<0>(i, j) * a.template in<1>(i, j) +
-            (a.template in<3>(i, j) - a.template in<3>(i + 1, j) + (a.template in<4>(i, j) - a.template in<4>(i, j + 1))) * MET(rarea, i, j)) /
-           a.template in<2>(i, j);
+    o[0] = (IN(0, i, j) * IN(1, i, j) + (IN(3, i, j) - IN(3, i + 1, j) + (IN(4, i, j) - IN(4, i, j + 1))) * MET(rarea, i, j)) / IN(2, i, j);
   }
 };
-// pt <-> virtual potential temperature at the ends of fv_dynamics (fv_dynamics_tlm.F90:1395-1403)
+// pt <-> virtual potential temperature at the start of fv_dynamics (fv_dynamics_tlm.F90:1395-1403)
 struct DynPtIn {
   STAGE_COMMON("DynPtIn", 3, 1)   // in: pt(T) qv pkz   out: pt(theta_v)
   double zvir; int has_q;
   HD static constexpr Box box(int) { return Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    T d = has_q ? zvir * a.template in<1>(i, j) : T(0.);
-    o[0] = a.template in<0>(i, j) * (1. + d) / a.template in<2>(i, j);
+    T d = has_q ? zvir * IN(1, i, j) : T(0.);
+    o[0] = IN(0, i, j) * (1. + d) / IN(2, i, j);
   }
 };
 
@@ -661,6 +923,7 @@ struct DynPtIn {
 // constant top value (:4068-4072).
 struct OneGradP {
   STAGE_BASE("OneGradP", 4, 2)   // in: u v pk_b gz_b (npz+1)   out: u_n v_n
+  STAGE_NO_ALIAS
   double dt, ptk;
   HD static constexpr bool uses(int M, int di, int dj, int) { return M < 2 || !(di == 1 && dj == 1); }
   HD static constexpr unsigned wants(int M) { return M == 0 ? 0x1u : M == 1 ? 0x2u : 0x3u; }
@@ -670,18 +933,18 @@ struct OneGradP {
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     T p00 = pk<T>(a, i, j, k, 0), p01 = pk<T>(a, i, j, k, 1);
-    T g00 = a.template in<3>(i, j, 0), g01 = a.template in<3>(i, j, 1);
+    T g00 = IN(3, i, j, 0), g01 = IN(3, i, j, 1);
     T wk0 = p01 - p00;
     o[0] = o[1] = T(0.);
     if ((a.want & 0x1u) && orect[0].has(i, j)) {
       T p10 = pk<T>(a, i + 1, j, k, 0), p11 = pk<T>(a, i + 1, j, k, 1);
-      T g10 = a.template in<3>(i + 1, j, 0), g11 = a.template in<3>(i + 1, j, 1);
-      o[0] = MET(rdx, i, j) * (a.template in<0>(i, j) + dt / (wk0 + (p11 - p10)) * ((g01 - g10) * (p11 - p00) + (g00 - g11) * (p01 - p10)));
+      T g10 = IN(3, i + 1, j, 0), g11 = IN(3, i + 1, j, 1);
+      o[0] = MET(rdx, i, j) * (IN(0, i, j) + dt / (wk0 + (p11 - p10)) * ((g01 - g10) * (p11 - p00) + (g00 - g11) * (p01 - p10)));
     }
     if ((a.want & 0x2u) && orect[1].has(i, j)) {
       T p10 = pk<T>(a, i, j + 1, k, 0), p11 = pk<T>(a, i, j + 1, k, 1);
-      T g10 = a.template in<3>(i, j + 1, 0), g11 = a.template in<3>(i, j + 1, 1);
-      o[1] = MET(rdy, i, j) * (a.template in<1>(i, j) + dt / (wk0 + (p11 - p10)) * ((g01 - g10) * (p11 - p00) + (g00 - g11) * (p01 - p10)));
+      T g10 = IN(3, i, j + 1, 0), g11 = IN(3, i, j + 1, 1);
+      o[1] = MET(rdy, i, j) * (IN(1, i, j) + dt / (wk0 + (p11 - p10)) * ((g01 - g10) * (p11 - p00) + (g00 - g11) * (p01 - p10)));
     }
   }
 };

@@ -49,10 +49,13 @@ typedef struct fv3lm_options {
 
 typedef struct fv3lm_dims {
   int nx, ny, npz;      /* cells per tile edge (npx-1, npy-1), levels */
-  int ntile;            /* tiles resident on this GPU: 1 = doubly-periodic tile (interior-rank code path) */
+  int ntile;            /* tiles resident on this GPU */
   int nq;               /* tracers (qv, ql, qi, o3: DYN/fv3jedi_lm_dynamics_mod.F90:158-167) */
   int n_split, k_split; /* acoustic / remap sub-steps (fv_flags_type) */
-  int pad_;
+  int face;             /* 0: one doubly-periodic tile with no cube edge in it (the code path of an MPI rank in the middle of a
+                           face: every `is .EQ. 1` / `j .EQ. npy` / sw_corner branch of the reference off); ntile must be 1.
+                           1: every resident tile is a whole cube face (is = 1, ie = npx-1; all edge and corner branches on);
+                           needs fv3lm_set_face_data and, for anything that exchanges halos, fv3lm_set_exchange. */
   double dt;            /* create(self,dt,...) src/fv3jedi_lm_mod.F90:44 */
 } fv3lm_dims;
 
@@ -67,6 +70,21 @@ const char* fv3lm_metric_names(void);
  * side: uploads metric terms once, resolves the per-level scheme table, allocates device state. */
 int fv3lm_create(fv3lm_handle** h, const fv3lm_dims* dims, const fv3lm_options* opt, const double* const* metrics,
                  double da_min, double da_min_c, const double* phis, const double* ak, const double* bk);
+/* Face mode only.  edge: the a2b_ord4 edge weights edge_w, edge_e, edge_s, edge_n of fv_grid_type
+ * (NLM/fv_arrays_nlm.F90:150-151) as [ntile][4][pj], entry (j - jsd) / (i - isd) of each; ecorner: the
+ * extrap_corner factors x1/(x2-x1) of a2b_ord4's four corners (a2b_edge_tlm.F90:101-139, :1478-1487) as
+ * [ntile][4: sw se ne nw][3], in the order the reference evaluates them. */
+int fv3lm_set_face_data(fv3lm_handle* h, const double* edge, const double* ecorner);
+/* Halo exchange between the resident faces: replaces the FMS calls mpp_update_domains / mpp_get_boundary that the
+ * reference issues from DYN_CORE_TLM (dyn_core_tlm.F90:1744-1790, :1960-1990, :2280-2300, :2418-2434) and
+ * FV_DYNAMICS_TLM (fv_dynamics_tlm.F90:646-651, :708-712).  One table per kind of exchange:
+ *   0 cell-centred scalar (delp, pt, q)        1 D-grid wind pair (u, v)        2 C-grid wind pair (uc, vc)
+ *   3 corner scalar (divg_d)                   4 shared edge rows of (u, v): u(:,npy), v(npx,:)  (mpp_get_boundary)
+ * rows[nrows][7] = dst_field(0|1), dst_tile, dst_index, src_field(0|1), src_tile, src_index, sign(+1|-1): plane
+ * element dst_index of the halo takes sign * element src_index of the neighbour face (indices into the padded
+ * plane, tiles 0-based among the resident ones; field 0/1 = first/second component of a pair). */
+int fv3lm_set_exchange(fv3lm_handle* h, int kind, const int* rows, int nrows);
+int fv3lm_halo(fv3lm_handle* h, int kind, const char* field0, const char* field1, int mode);   /* one exchange (tests) */
 int fv3lm_destroy(fv3lm_handle* h);     /* %delete, DYN/fv3jedi_lm_dynamics_mod.F90:693-713 */
 const char* fv3lm_last_error(void);
 

@@ -150,6 +150,20 @@ void* orc_create(int nx, int ny, int npz, int nq, const double* const* metrics, 
 }
 void orc_destroy(void* h) { delete (OrcHandle*)h; }
 
+// Switch the tile to "whole cube face" mode (is=1, ie=npx-1, all edges and corners) and load the a2b_ord4
+// edge weights (edge[4][pj]: w, e, s, n, indexed by padded-plane position) and extrap_corner coefficients.
+void orc_set_face(void* hv, const double* edge, const double* ecorner) {
+  OrcHandle* h = (OrcHandle*)hv;
+  const int n = h->bd.nx, pj = h->bd.pj();
+  h->bd.set_face(n);
+  std::vector<double>* dst[4] = {&h->g.edge_w, &h->g.edge_e, &h->g.edge_s, &h->g.edge_n};
+  for (int e = 0; e < 4; ++e) {
+    dst[e]->assign(n + 3, 0.0);
+    for (int i = 1; i <= n + 1; ++i) (*dst[e])[i] = edge[e * pj + (i + h->bd.ng - 1)];
+  }
+  for (int c = 0; c < 4; ++c) for (int k = 0; k < 3; ++k) h->g.ecorner[c][k] = ecorner[c * 3 + k];
+}
+
 // Per-level parameters as the reference would hand them to d_sw; returns 0 if traj/pert hord split.
 int orc_level_params(void* hv, int k, int* ip, double* rp) {
   OrcHandle* h = (OrcHandle*)hv; LevelParams lp;
