@@ -25,17 +25,28 @@ def build_emul():
 
 
 class Case:
-    def __init__(self, nx=12, ny=12, npz=8, n_split=2, k_split=1, dt=1800.0, backend="emul", seed=20250114, oracle=True, nq=0, **optkw):
+    def __init__(self, nx=12, ny=12, npz=8, n_split=2, k_split=1, dt=1800.0, backend="emul", seed=20250114, oracle=True, nq=0,
+                 face=None, **optkw):
+        """face=None: the doubly-periodic tile with no cube edge.  face=t (0..5): one whole face of a C<nx> cube with
+        the real gnomonic metrics of that face and arbitrary smooth halo data (kernel-group tests)."""
         self.nx, self.ny, self.npz = nx, ny, npz
         self.opt = fv3.default_options(**optkw)
-        self.metrics, self.da_min, self.da_min_c = fv3.synthetic_tile_metrics(nx, ny)
+        self.face = face
+        if face is None:
+            self.metrics, self.da_min, self.da_min_c = fv3.synthetic_tile_metrics(nx, ny)
+        else:
+            from fv3_jedi_linearmodel_amd import cube
+            assert nx == ny
+            m6, self.da_min, self.da_min_c, edge, ecorner, _ = cube.cubed_sphere_metrics(nx)
+            self.metrics = {k: np.ascontiguousarray(v[face:face + 1]) for k, v in m6.items()}
+            self.edge, self.ecorner = np.ascontiguousarray(edge[face:face + 1]), np.ascontiguousarray(ecorner[face:face + 1])
         self.traj, self.phis, self.ak, self.bk = G.synthetic_state(nx, ny, npz, self.opt, seed=seed)
         self.pert = G.synthetic_pert(nx, ny, npz, seed=seed + 1)
         for d in (self.traj, self.pert):
             for k in d:
                 d[k] = G.halo_fill_periodic(d[k], nx, ny)
         self.phis = G.halo_fill_periodic(self.phis, nx, ny)
-        self.dims = fv3.Dims(nx=nx, ny=ny, npz=npz, ntile=1, nq=nq, n_split=n_split, k_split=k_split, dt=dt)
+        self.dims = fv3.Dims(nx=nx, ny=ny, npz=npz, ntile=1, nq=nq, n_split=n_split, k_split=k_split, face=0 if face is None else 1, dt=dt)
         self.dt_ac = dt / n_split / k_split
         self.nq = nq
         rng = np.random.default_rng(seed + 7)
@@ -44,6 +55,8 @@ class Case:
         self.qtraj = [G.halo_fill_periodic(np.abs(1e-3 * (n + 1) + _smooth_field(rng, shp, nx, ny, 3e-4)), nx, ny) for n in range(nq)]
         self.qpert = [G.halo_fill_periodic(_smooth_field(rng, shp, nx, ny, 1e-4), nx, ny) for n in range(nq)]
         self.oracle = Oracle(nx, ny, npz, nq, self.metrics, self.opt, self.da_min, self.da_min_c, self.phis, self.ak, self.bk) if oracle else None
+        if self.oracle is not None and face is not None:
+            self.oracle.set_face(self.edge[0], self.ecorner[0])
         if backend == "none":        # oracle only (bench.py's cpu_baseline leg)
             self.lib = self.dy = None
             return
@@ -53,6 +66,8 @@ class Case:
         else:
             self.lib = fv3.load_hip_library()
         self.dy = Dycore(self.lib, self.dims, self.opt, self.metrics, self.da_min, self.da_min_c, self.phis, self.ak, self.bk)
+        if face is not None:
+            self.dy.set_face_data(self.edge, self.ecorner)
         if backend == "emul":
             self.lib.L.fv3lm_emul_check_boxes(self.dy.h, 1)
 

@@ -43,6 +43,18 @@ def masked(c, arr, rkey):
     return out
 
 
+def drop_face_corners(c, name, arr):
+    """ua/va at the four corner-halo cells of a face: the reference overwrites them in place with the rotated
+    neighbour values while d2a2c_vect runs (sw_core_tlm.F90:6662-6677, :6745-6760) and nothing reads them
+    afterwards; the product reads those views through an index map and leaves the stored value alone."""
+    if getattr(c, "face", None) is None or name not in ("ua", "va"):
+        return arr
+    out = arr.copy()
+    for (i, j) in ((0, 0), (c.nx + 1, 0), (0, c.ny + 1), (c.nx + 1, c.ny + 1)):
+        out[..., j + 2, i + 2] = 0.0
+    return out
+
+
 def make_inputs(c, group, seed=7):
     """Physically plausible inputs of a group = outputs of the preceding groups run by the oracle
     (NL+TL), halo-filled where the reference would have exchanged them."""
@@ -97,7 +109,8 @@ def check_group(c, group, mode, tol):
             if n is None:
                 continue
             r = c.rect(*rects(c)[rk])
-            e1, e2 = relerr(c.dy.get(n, 0)[0][r], a[r]), relerr(c.dy.get(n, 1)[0][r], b[r])
+            D = lambda x: drop_face_corners(c, n, x)
+            e1, e2 = relerr(D(c.dy.get(n, 0)[0])[r], D(a)[r]), relerr(D(c.dy.get(n, 1)[0])[r], D(b)[r])
             assert e1 < tol, (group, n, "traj", e1)
             assert e2 < tol, (group, n, "tl", e2)
             worst = max(worst, e1, e2)
@@ -110,7 +123,7 @@ def check_group(c, group, mode, tol):
         if n is None:
             seeds.append(np.zeros((c.npz, c.ny + 7, c.nx + 7)))
         else:
-            seeds.append(masked(c, rng.standard_normal((nks[n], c.ny + 7, c.nx + 7)), rk))
+            seeds.append(drop_face_corners(c, n, masked(c, rng.standard_normal((nks[n], c.ny + 7, c.nx + 7)), rk)))
     _, iad = fn(AD, *scal(), i_t, None, seeds)
     for n in ins:
         c.dy.put(n, T[n][None], 0)

@@ -11,7 +11,8 @@ NL, TL, AD = 0, 1, 2
 
 
 def build_oracle():
-    if not os.path.exists(ORACLE_SO):
+    srcs = [os.path.join(ROOT, "oracle", f) for f in os.listdir(os.path.join(ROOT, "oracle")) if f.endswith((".hpp", ".cpp"))]
+    if not os.path.exists(ORACLE_SO) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
     return ORACLE_SO
 
@@ -40,6 +41,13 @@ class Oracle:
         L.orc_create.argtypes = [C.c_int] * 4 + [C.POINTER(_dp), C.POINTER(C.c_int), _dp, _dp, _dp, _dp]
         self.h = C.c_void_p(L.orc_create(nx, ny, npz, nq, mp, iopt, ropt, _ptr(self._keep[1]), _ptr(self._keep[2]),
                                          _ptr(self._keep[3])))
+
+    def set_face(self, edge, ecorner):
+        """switch the oracle tile to a whole cube face: a2b edge weights [4,pj], extrap_corner factors [4,3]"""
+        e = np.ascontiguousarray(edge, dtype=np.float64); c = np.ascontiguousarray(ecorner, dtype=np.float64)
+        self.L.orc_set_face.argtypes = [C.c_void_p, _dp, _dp]
+        self.L.orc_set_face.restype = None
+        self.L.orc_set_face(self.h, _ptr(e), _ptr(c))
 
     def level_params(self, k):
         ip = (C.c_int * 10)(); rp = (C.c_double * 6)()
