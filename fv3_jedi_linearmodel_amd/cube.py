@@ -118,6 +118,51 @@ def exchange_table(n, fields):
     return np.array(rows, dtype=np.int32)
 
 
+def boundary_table(n):
+    """mpp_get_boundary of the D-grid winds (dyn_core_tlm.F90:2418-2431): the shared edge rows u(1:n, npy) and
+    v(npx, 1:n) of every face take the neighbour's value of the same physical edge (its u(:,1) or v(1,:), swapped and
+    sign-changed where the contact is rotated).  Same row format as exchange_table, fields [u, v]."""
+    fields = [("yedge", "1"), ("xedge", "2")]
+    rows = []
+    eps = 1.0e-6
+    for tile in range(1, 7):
+        for fi, pts in ((0, [(i, n + 1, i - 0.5, n + eps) for i in range(1, n + 1)]), (1, [(n + 1, j, n + eps, j - 0.5) for j in range(1, n + 1)])):
+            kind, dirn = fields[fi]
+            for (i, j, x, y) in pts:
+                tb, xb, yb, R = _fold(tile, x, y, n)
+                comp = 0 if dirn == "1" else 1
+                col = R[:, comp]
+                cb = int(np.argmax(np.abs(col))); sign = int(col[cb])
+                kb = kind if R[0, 0] != 0 else {"yedge": "xedge", "xedge": "yedge"}[kind]
+                sf = fields.index((kb, "1" if cb == 0 else "2"))
+                oxb, oyb = LOC[kb]
+                ib, jb = int(round(xb - oxb)) + 1, int(round(yb - oyb)) + 1
+                assert abs(ib - 1 + oxb - xb) < 1e-4 and abs(jb - 1 + oyb - yb) < 1e-4
+                assert (ib == 1 and kb == "xedge") or (jb == 1 and kb == "yedge"), (tile, i, j, tb, ib, jb, kb)
+                rows.append((fi, tile - 1, plane_index(i, j, n), sf, tb - 1, plane_index(ib, jb, n), sign))
+    return np.array(rows, dtype=np.int32)
+
+
+EXCHANGE_FIELDS = {"cell": [("center", "s")], "dvec": [("yedge", "1"), ("xedge", "2")], "cvec": [("xedge", "1"), ("yedge", "2")],
+                   "corner": [("corner", "s")]}
+
+
+def all_tables(n):
+    """the five exchange tables of include/fv3lm.h fv3lm_set_exchange, keyed by kind name"""
+    t = {k: exchange_table(n, f) for k, f in EXCHANGE_FIELDS.items()}
+    t["dedge"] = boundary_table(n)
+    return t
+
+
+def apply_table(tab, f0, f1=None):
+    """numpy reference of one exchange: fields [6, nk, pj, pi] updated in place"""
+    fl = [f0.reshape(6, f0.shape[1], -1)] + ([f1.reshape(6, f1.shape[1], -1)] if f1 is not None else [])
+    vals = [None] * len(tab)
+    src = [fl[r[3]][r[4], :, r[5]] * r[6] for r in tab]
+    for r, v in zip(tab, src):
+        fl[r[0]][r[1], :, r[2]] = v
+
+
 def adjoint_table(tab):
     """CSR form of the transposed exchange: for every source element the halo elements that copy it.
     Returns (src_keys[ns,3] = field, tile, index; ptr[ns+1]; dst[nnz,4] = field, tile, index, sign)."""
@@ -296,3 +341,56 @@ def cubed_sphere_metrics(n, radius=6371.0e3, omega=7.292e-5):
                          ec(G(t, 1, npx), C(t, 1, npx), C(t, 2, npx + 1))]
     out = {k: np.ascontiguousarray(v) for k, v in m.items()}
     return out, da_min, da_min_c, edge, ecorner, dict(corners=P, centers=ctr)
+
+
+def cube_fields(n, npz, geo, seed, kind="traj", opt=None):
+    """Smooth global fields sampled on all six faces (halo included, so they are exchange-consistent):
+    u, v (D-grid covariant winds), pt, delp as [6, npz, pj, pi]; kind="pert" gives zero-mean perturbations."""
+    from .grid import hybrid_levels
+    rng = np.random.default_rng(seed)
+    P, ctr = geo["corners"], geo["centers"]
+    pj = n + 2 * NG + 1
+    nm = 4
+    def scalar(pts, amp):
+        f = np.zeros(pts.shape[:-1])
+        for _ in range(nm):
+            k = rng.standard_normal(3) * 2.0; ph = rng.uniform(0, 2 * np.pi)
+            f += amp / nm * np.sin(pts @ k + ph)
+        return f
+    def vector(amp):
+        cs = [(rng.standard_normal(3), rng.standard_normal(3) * 1.5, rng.uniform(0, 2 * np.pi)) for _ in range(nm)]
+        def V(pts):
+            out = np.zeros(pts.shape)
+            for c, k, ph in cs:
+                out += amp / nm * np.cross(c, pts) * np.cos(pts @ k + ph)[..., None]
+            return out
+        return V
+    ctrp = np.zeros((6, pj, pj, 3)); ctrp[:, :-1, :-1] = ctr; ctrp[:, -1, :] = ctrp[:, -2, :]; ctrp[:, :, -1] = ctrp[:, :, -2]
+    mid_y = np.zeros((6, pj, pj, 3)); tan_y = np.zeros((6, pj, pj, 3))     # south edge of cell (i,j): u point
+    mid_y[:, :, :-1] = _norm(P[:, :, :-1] + P[:, :, 1:]); tan_y[:, :, :-1] = _tangent(mid_y[:, :, :-1], P[:, :, :-1], P[:, :, 1:])
+    mid_x = np.zeros((6, pj, pj, 3)); tan_x = np.zeros((6, pj, pj, 3))     # west edge: v point
+    mid_x[:, :-1, :] = _norm(P[:, :-1, :] + P[:, 1:, :]); tan_x[:, :-1, :] = _tangent(mid_x[:, :-1, :], P[:, :-1, :], P[:, 1:, :])
+    mid_y[:, :, -1] = mid_y[:, :, -2]; mid_x[:, -1, :] = mid_x[:, -2, :]
+    out = {n_: np.zeros((6, npz, pj, pj)) for n_ in ("u", "v", "pt", "delp")}
+    if kind == "traj":
+        ak, bk = hybrid_levels(npz, opt.ptop)
+        ps = 1.0e5 + scalar(ctrp, 800.0)
+        V0 = vector(25.0)
+        for k in range(npz):
+            out["delp"][:, k] = (ak[k + 1] - ak[k]) + (bk[k + 1] - bk[k]) * ps
+        pe = np.concatenate([np.full((6, 1, pj, pj), opt.ptop), opt.ptop + np.cumsum(out["delp"], axis=1)], axis=1)
+        pmid = 0.5 * (pe[:, 1:] + pe[:, :-1])
+        for k in range(npz):
+            T = 288.0 * (np.maximum(pmid[:, k], 2.0e4) / 1.0e5) ** 0.19 + scalar(ctrp, 2.0)
+            out["pt"][:, k] = T / pmid[:, k] ** opt.akap
+            Vk = vector(6.0)
+            fac = 0.6 + 0.8 * k / max(1, npz - 1)
+            out["u"][:, k] = np.einsum("...i,...i", fac * V0(mid_y) + Vk(mid_y), tan_y)
+            out["v"][:, k] = np.einsum("...i,...i", fac * V0(mid_x) + Vk(mid_x), tan_x)
+        phis = 9.80 * 400.0 * (1.0 + scalar(ctrp, 1.0))
+        return out, phis, ak, bk
+    for k in range(npz):
+        out["delp"][:, k] = scalar(ctrp, 10.0); out["pt"][:, k] = scalar(ctrp, 0.02)
+        Vk = vector(1.0)
+        out["u"][:, k] = np.einsum("...i,...i", Vk(mid_y), tan_y); out["v"][:, k] = np.einsum("...i,...i", Vk(mid_x), tan_x)
+    return out

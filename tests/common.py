@@ -91,3 +91,56 @@ class Case:
 def relerr(a, b):
     s = np.max(np.abs(b))
     return float(np.max(np.abs(a - b)) / (s if s > 0 else 1.0))
+
+
+class CubeCase:
+    """All six faces of a C<n> cube resident in one product instance (ntile = 6, face mode), exchange tables from
+    cube.py, smooth global fields as state.  oracle=True adds the six-face oracle (tests/oracle.py CubeOracle)."""
+
+    def __init__(self, n=12, npz=6, n_split=2, k_split=1, dt=1800.0, backend="emul", seed=20250114, nq=0, oracle=False, **optkw):
+        from fv3_jedi_linearmodel_amd import cube
+        self.n = self.nx = self.ny = n
+        self.npz, self.nq = npz, nq
+        self.opt = fv3.default_options(**optkw)
+        self.metrics, self.da_min, self.da_min_c, self.edge, self.ecorner, self.geo = cube.cubed_sphere_metrics(n)
+        self.tables = cube.all_tables(n)
+        self.traj, self.phis, self.ak, self.bk = cube.cube_fields(n, npz, self.geo, seed, "traj", self.opt)
+        self.pert = cube.cube_fields(n, npz, self.geo, seed + 1, "pert")
+        rng = np.random.default_rng(seed + 7)
+        qs = [cube.cube_fields(n, npz, self.geo, seed + 11 + m, "pert") for m in range(nq)]
+        self.qtraj = [1e-3 * (m + 1) + 1e-2 * np.abs(qs[m]["pt"]) for m in range(nq)]
+        self.qpert = [1e-3 * qs[m]["delp"] / 10.0 for m in range(nq)]
+        self.dims = fv3.Dims(nx=n, ny=n, npz=npz, ntile=6, nq=nq, n_split=n_split, k_split=k_split, face=1, dt=dt)
+        self.dt_ac = dt / n_split / k_split
+        self.face = "cube"
+        self.oracle = None
+        if oracle:
+            from oracle import CubeOracle
+            self.oracle = CubeOracle(n, npz, nq, self.metrics, self.opt, self.da_min, self.da_min_c, self.phis, self.ak, self.bk,
+                                     self.edge, self.ecorner, self.tables)
+        if backend == "none":
+            self.lib = self.dy = None
+            return
+        if backend == "emul":
+            self.lib = Fv3LmLibrary(build_emul())
+            self.lib.L.fv3lm_emul_check_boxes.argtypes = [__import__("ctypes").c_void_p, __import__("ctypes").c_int]
+        else:
+            self.lib = fv3.load_hip_library()
+        self.dy = Dycore(self.lib, self.dims, self.opt, self.metrics, self.da_min, self.da_min_c, self.phis, self.ak, self.bk)
+        self.dy.set_face_data(self.edge, self.ecorner)
+        for k, t in self.tables.items():
+            self.dy.set_exchange(k, t)
+
+    def put_state(self, traj=None, pert=None):
+        traj = traj or self.traj
+        for n in ("u", "v", "delp", "pt"):
+            self.dy.put(n, traj[n], 0)
+            if pert is not None:
+                self.dy.put(n, pert[n], 1)
+        for m in range(self.nq):
+            self.dy.put("q%d" % (m + 1), self.qtraj[m], 0)
+            if pert is not None:
+                self.dy.put("q%d" % (m + 1), self.qpert[m], 1)
+
+    def rect(self, i0, i1, j0, j1):
+        return (Ellipsis, slice(j0 + 2, j1 + 3), slice(i0 + 2, i1 + 3))
