@@ -8,6 +8,7 @@
 #include "dyn_core.hpp"
 #include "fv_dynamics.hpp"
 #include "fv_pressure.hpp"
+#include "cube.hpp"
 #include <memory>
 #include <string>
 
@@ -329,6 +330,67 @@ void orc_fv_dynamics(void* hv, int mode, int nq, double bdt, int n_split, int k_
     fv_dynamics(s, h->phis, npz, bdt, n_split, k_split, h->o, h->c, h->ptop, h->ak, h->bk, h->g, h->bd);
     y[0] = s.u; y[1] = s.v; y[2] = s.pt; y[3] = s.delp;
     for (int n = 0; n < nq; ++n) y[4 + n] = s.q[n];
+  });
+}
+
+// ---- six-face cube: handles of the six faces (each after orc_set_face) + the exchange tables of cube.py
+struct OrcCube { OrcHandle* f[6]; CubeTables X; std::vector<Grid> G; std::vector<Arr2<double>> phis; };
+void* orc_cube_create(void** faces, const int* const* tables, const int* nrows) {
+  OrcCube* c = new OrcCube;
+  for (int t = 0; t < 6; ++t) { c->f[t] = (OrcHandle*)faces[t]; c->G.push_back(c->f[t]->g); c->phis.push_back(c->f[t]->phis); }
+  for (int k = 0; k < X_NKIND; ++k) c->X.rows[k].assign(tables[k], tables[k] + 7 * (size_t)nrows[k]);
+  return c;
+}
+void orc_cube_destroy(void* cv) { delete (OrcCube*)cv; }
+// every field is [6][nk][pj][pi]; one IO per (field, tile), field-major
+static std::vector<IO> mkio6(int n, double** traj, double** pert, const int* nk, size_t np) {
+  std::vector<IO> v((size_t)n * 6);
+  for (int i = 0; i < n; ++i)
+    for (int t = 0; t < 6; ++t) {
+      IO& io = v[(size_t)i * 6 + t];
+      io.traj = traj[i] + (size_t)t * nk[i] * np; io.pert = pert ? pert[i] + (size_t)t * nk[i] * np : nullptr; io.nk = nk[i];
+    }
+  return v;
+}
+// dyn_core on the cube.  in: u, v, pt, delp   out: u, v, pt, delp, mfx, mfy, cx, cy, pe, peln, pk, pkz
+void orc_cube_dyn_core(void* cv, int mode, double bdt, int n_split, double** in_t, double** in_p, double** out_t, double** out_p) {
+  OrcCube* c = (OrcCube*)cv; OrcHandle* h = c->f[0]; const int npz = h->npz;
+  const size_t np = (size_t)h->bd.pi() * h->bd.pj();
+  std::vector<int> nk(4, npz); int nko[12] = {npz, npz, npz, npz, npz, npz, npz, npz, npz + 1, npz + 1, npz + 1, npz};
+  auto in = mkio6(4, in_t, in_p, nk.data(), np); auto out = mkio6(12, out_t, out_p, nko, np);
+  drive(mode, h->bd, in, out, [&](auto& x, auto& y) {
+    using T = typename std::decay<decltype(x[0].p[0].d[0])>::type;
+    std::vector<DynState<T>> S(6);
+    for (int t = 0; t < 6; ++t) { S[t].init(h->bd, npz, 0); S[t].u = x[0 * 6 + t]; S[t].v = x[1 * 6 + t]; S[t].pt = x[2 * 6 + t]; S[t].delp = x[3 * 6 + t]; }
+    dyn_core_cube(S, c->phis, npz, bdt, n_split, h->o, h->c, h->ptop, c->G, h->bd, c->X);
+    for (int t = 0; t < 6; ++t) {
+      Arr3<T>* o[12] = {&S[t].u, &S[t].v, &S[t].pt, &S[t].delp, &S[t].mfx, &S[t].mfy, &S[t].cx, &S[t].cy, &S[t].pe, &S[t].peln, &S[t].pk, &S[t].pkz};
+      for (int n = 0; n < 12; ++n) y[n * 6 + t] = *o[n];
+    }
+  });
+}
+// fv_dynamics on the cube.  in: u, v, pt(=T), delp, pe, peln, pk (npz+1), pkz, q[nq]   out: u, v, pt(=T), delp, q[nq]
+void orc_cube_fv_dynamics(void* cv, int mode, int nq, double bdt, int n_split, int k_split, double** in_t, double** in_p,
+                          double** out_t, double** out_p) {
+  OrcCube* c = (OrcCube*)cv; OrcHandle* h = c->f[0]; const int npz = h->npz;
+  const size_t np = (size_t)h->bd.pi() * h->bd.pj();
+  std::vector<int> nk(8 + nq, npz), nko(4 + nq, npz);
+  nk[4] = nk[5] = nk[6] = npz + 1;
+  auto in = mkio6(8 + nq, in_t, in_p, nk.data(), np); auto out = mkio6(4 + nq, out_t, out_p, nko.data(), np);
+  drive(mode, h->bd, in, out, [&](auto& x, auto& y) {
+    using T = typename std::decay<decltype(x[0].p[0].d[0])>::type;
+    std::vector<DynState<T>> S(6);
+    for (int t = 0; t < 6; ++t) {
+      DynState<T>& s = S[t]; s.init(h->bd, npz, nq);
+      s.u = x[0 * 6 + t]; s.v = x[1 * 6 + t]; s.pt = x[2 * 6 + t]; s.delp = x[3 * 6 + t]; s.pe = x[4 * 6 + t]; s.peln = x[5 * 6 + t];
+      s.pk = x[6 * 6 + t]; s.pkz = x[7 * 6 + t];
+      for (int n = 0; n < nq; ++n) s.q[n] = x[(8 + n) * 6 + t];
+    }
+    fv_dynamics_cube(S, c->phis, npz, bdt, n_split, k_split, h->o, h->c, h->ptop, h->ak, h->bk, c->G, h->bd, c->X);
+    for (int t = 0; t < 6; ++t) {
+      y[0 * 6 + t] = S[t].u; y[1 * 6 + t] = S[t].v; y[2 * 6 + t] = S[t].pt; y[3 * 6 + t] = S[t].delp;
+      for (int n = 0; n < nq; ++n) y[(4 + n) * 6 + t] = S[t].q[n];
+    }
   });
 }
 

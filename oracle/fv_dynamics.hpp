@@ -83,7 +83,7 @@ void map_col(int km, const std::vector<T>& pe1, const std::vector<T>& q1, int kn
 // tracer_2d, fv_tracer2d_tlm.F90:1148-1446 (q_split = 0, nord_tr/trdm = 0).  dp1 = delp before dyn_core.
 template <class T>
 void tracer_2d(std::vector<Arr3<T>>& q, Arr3<T>& dp1, Arr3<T>& mfx, Arr3<T>& mfy, Arr3<T>& cx, Arr3<T>& cy, int npz,
-               int hord, const Grid& g, const Bounds& bd) {
+               int hord, const Grid& g, const Bounds& bd, int* nsplt_out = nullptr) {
   const int is = bd.is, ie = bd.ie, js = bd.js, je = bd.je, isd = bd.isd, ied = bd.ied, jsd = bd.jsd, jed = bd.jed;
   const int nq = (int)q.size();
   Arr3<T> xfx(bd, npz), yfx(bd, npz);
@@ -111,6 +111,7 @@ void tracer_2d(std::vector<Arr3<T>>& q, Arr3<T>& dp1, Arr3<T>& mfx, Arr3<T>& mfy
   double c_global = cmax[1];
   for (int k = 2; k <= npz; ++k) if (!(cmax[k] < c_global)) c_global = cmax[k];
   const int nsplt = int(1. + c_global);
+  if (nsplt_out) *nsplt_out = nsplt;
   if (nsplt != 1)
     for (int k = 1; k <= npz; ++k) {
       ksplt[k] = int(1. + cmax[k]);

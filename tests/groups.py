@@ -47,7 +47,15 @@ def drop_face_corners(c, name, arr):
     """ua/va at the four corner-halo cells of a face: the reference overwrites them in place with the rotated
     neighbour values while d2a2c_vect runs (sw_core_tlm.F90:6662-6677, :6745-6760) and nothing reads them
     afterwards; the product reads those views through an index map and leaves the stored value alone."""
-    if getattr(c, "face", None) is None or name not in ("ua", "va"):
+    if getattr(c, "face", None) is None:
+        return arr
+    if name in ("pe_c", "pkc", "gz", "pe", "pk", "gzd"):    # geopk: corner-halo columns hold no exchanged data, product skips them
+        out = arr.copy()
+        for js in (slice(0, 3), slice(c.ny + 3, None)):
+            for isl in (slice(0, 3), slice(c.nx + 3, None)):
+                out[..., js, isl] = 0.0
+        return out
+    if name not in ("ua", "va"):
         return arr
     out = arr.copy()
     for (i, j) in ((0, 0), (c.nx + 1, 0), (0, c.ny + 1), (c.nx + 1, c.ny + 1)):
@@ -381,4 +389,145 @@ def dot_product_step(c, seed=13):
         c.dy.put(n, dy[n][None], 1)
     c.dy.step_ad()
     rhs = sum(float(np.sum(c.dy.get(n, 1)[0] * dx[n])) for n in names)
+    return lhs, rhs
+
+
+# ------------------------------------------------------------------------------ six-face cube (CubeCase)
+CUBE_DC_OUT = [("u", "U"), ("v", "V"), ("pt", "A"), ("delp", "A"), ("mfx", "V"), ("mfy", "U"), ("cx", "CX"), ("cy", "CY"),
+               ("pe", "A"), ("peln", "A"), ("pk", "A"), ("pkz", "A")]
+
+
+def cube_check_dyn_core(c, mode, tol):
+    """fv3lm_dyn_core with six resident faces vs oracle/cube.hpp dyn_core_cube (state compared on the compute
+    domain: after the last acoustic step only the shared edge rows of u, v are exchanged, dyn_core_tlm.F90:2418-2431)."""
+    ins = ["u", "v", "pt", "delp"]
+    i_t = [c.traj[n] for n in ins]; i_p = [c.pert[n] for n in ins]
+    bdt, ns = c.dims.dt / c.dims.k_split, c.dims.n_split
+    if mode == TL:
+        ot, op = c.oracle.dyn_core(TL, bdt, ns, i_t, i_p)
+        c.put_state(pert=c.pert)
+        c.dy.dyn_core(TL)
+        worst = 0.0
+        for (n, rk), a, b in zip(CUBE_DC_OUT, ot, op):
+            r = c.rect(*rects(c)[rk])
+            e1, e2 = relerr(c.dy.get(n, 0)[r], a[r]), relerr(c.dy.get(n, 1)[r], b[r])
+            assert e1 < tol, (n, "traj", e1)
+            assert e2 < tol, (n, "tl", e2)
+            worst = max(worst, e1, e2)
+        return worst
+    rng = np.random.default_rng(5)
+    seeds = [masked(c, rng.standard_normal(c.dy.shape(n)), rk) for n, rk in CUBE_DC_OUT]
+    _, iad = c.oracle.dyn_core(AD, bdt, ns, i_t, None, seeds)
+    c.put_state()
+    c.dy.dyn_core(NL)
+    for (n, rk), s in zip(CUBE_DC_OUT, seeds):
+        c.dy.put(n, s, 1)
+    c.dy.dyn_core(AD)
+    worst = 0.0
+    for n, a in zip(ins, iad):
+        e = relerr(c.dy.get(n, 1), a)
+        assert e < tol, (n, "ad", e)
+        worst = max(worst, e)
+    return worst
+
+
+def cube_dot_product(c, seed=3):
+    rng = np.random.default_rng(seed)
+    ins = ["u", "v", "pt", "delp"]
+    outs = [("u", "U"), ("v", "V"), ("pt", "A"), ("delp", "A")]
+    c.put_state(pert=c.pert)
+    c.dy.dyn_core(TL)
+    Mdx = {n: c.dy.get(n, 1) for n, _ in outs}
+    dy = {n: masked(c, rng.standard_normal(Mdx[n].shape), rk) for n, rk in outs}
+    lhs = sum(float(np.sum(Mdx[n] * dy[n])) for n, _ in outs)
+    c.put_state()
+    c.dy.dyn_core(NL)
+    for n in ("mfx", "mfy", "cx", "cy", "pe", "peln", "pk", "pkz"):
+        c.dy.put(n, np.zeros(c.dy.shape(n)), 1)
+    for n, _ in outs:
+        c.dy.put(n, dy[n], 1)
+    c.dy.dyn_core(AD)
+    rhs = sum(float(np.sum(c.dy.get(n, 1) * c.pert[n])) for n in ins)
+    return lhs, rhs
+
+
+def cube_step_state(c):
+    """as step_state, six faces"""
+    k = c.opt.akap
+    delp = c.traj["delp"]
+    pe = np.concatenate([np.full_like(delp[:, :1], c.opt.ptop), c.opt.ptop + np.cumsum(delp, axis=1)], axis=1)
+    peln = np.log(pe); pk = np.exp(k * peln)
+    pkz = (pk[:, 1:] - pk[:, :-1]) / (k * (peln[:, 1:] - peln[:, :-1]))
+    qv = c.qtraj[0] if c.nq else 0.0
+    T = dict(u=c.traj["u"], v=c.traj["v"], pt=c.traj["pt"] * pkz / (1.0 + c.opt.zvir * qv), delp=delp, pe=pe, peln=peln, pk=pk, pkz=pkz)
+    P = dict(u=c.pert["u"], v=c.pert["v"], pt=20.0 * c.pert["pt"], delp=c.pert["delp"])
+    pe_p = np.concatenate([np.zeros_like(delp[:, :1]), np.cumsum(P["delp"], axis=1)], axis=1)
+    peln_p = pe_p / pe; pk_p = k * peln_p * pk
+    den = k * (peln[:, 1:] - peln[:, :-1])
+    pkz_p = ((pk_p[:, 1:] - pk_p[:, :-1]) * den - (pk[:, 1:] - pk[:, :-1]) * k * (peln_p[:, 1:] - peln_p[:, :-1])) / den ** 2
+    P.update(pe=pe_p, peln=peln_p, pk=pk_p, pkz=pkz_p)
+    for n in range(c.nq):
+        T["q%d" % (n + 1)], P["q%d" % (n + 1)] = c.qtraj[n], c.qpert[n]
+    return T, P
+
+
+def cube_check_fv_dynamics(c, mode, tol):
+    T, P = cube_step_state(c)
+    nq = c.nq
+    ins_n = ["u", "v", "pt", "delp", "pe", "peln", "pk", "pkz"] + ["q%d" % (n + 1) for n in range(nq)]
+    outs = [("u", "U"), ("v", "V"), ("pt", "A"), ("delp", "A")] + [("q%d" % (n + 1), "A") for n in range(nq)]
+    i_t = [T[n] for n in ins_n]; i_p = [P[n] for n in ins_n]
+    for n in ins_n:
+        c.dy.put(n, T[n], 0)
+    if mode == TL:
+        ot, op = c.oracle.fv_dynamics(TL, nq, c.dims.dt, c.dims.n_split, c.dims.k_split, i_t, i_p)
+        for n in ins_n:
+            c.dy.put(n, P[n], 1)
+        c.dy.fv_dynamics(TL)
+        worst = 0.0
+        for (n, rk), a, b in zip(outs, ot, op):
+            r = c.rect(*rects(c)[rk])
+            e1, e2 = relerr(c.dy.get(n, 0)[r], a[r]), relerr(c.dy.get(n, 1)[r], b[r])
+            assert e1 < tol, (n, "traj", e1)
+            assert e2 < tol, (n, "tl", e2)
+            worst = max(worst, e1, e2)
+        return worst
+    rng = np.random.default_rng(41)
+    seeds = [masked(c, rng.standard_normal(T["u"].shape), rk) for n, rk in outs]
+    _, iad = c.oracle.fv_dynamics(AD, nq, c.dims.dt, c.dims.n_split, c.dims.k_split, i_t, None, seeds)
+    c.dy.fv_dynamics(NL)
+    for n in ins_n:
+        c.dy.put(n, np.zeros(c.dy.shape(n)), 1)
+    for (n, rk), s in zip(outs, seeds):
+        c.dy.put(n, s, 1)
+    c.dy.fv_dynamics(AD)
+    worst = 0.0
+    for n, a in zip(ins_n, iad):
+        if n in ("pe", "peln", "pk"):
+            continue
+        e = relerr(c.dy.get(n, 1), a)
+        assert e < tol, (n, "ad", e)
+        worst = max(worst, e)
+    return worst
+
+
+def cube_dot_product_step(c, seed=13):
+    T, P = cube_step_state(c)
+    names = ["u", "v", "pt", "delp"] + ["q%d" % (n + 1) for n in range(c.nq)]
+    rk = {"u": "U", "v": "V"}
+    rng = np.random.default_rng(seed)
+    dx = {n: masked(c, P[n], rk.get(n, "A")) for n in names}
+    for n in names:
+        c.dy.put(n, T[n], 0); c.dy.put(n, dx[n], 1)
+    c.dy.step_tl()
+    Mdx = {n: c.dy.get(n, 1) for n in names}
+    dy = {n: masked(c, rng.standard_normal(Mdx[n].shape) * (1.0 / max(1e-30, np.abs(Mdx[n]).max())), rk.get(n, "A")) for n in names}
+    lhs = sum(float(np.sum(masked(c, Mdx[n], rk.get(n, "A")) * dy[n])) for n in names)
+    for n in names:
+        c.dy.put(n, T[n], 0)
+    c.dy.step_nl()
+    for n in names:
+        c.dy.put(n, dy[n], 1)
+    c.dy.step_ad()
+    rhs = sum(float(np.sum(c.dy.get(n, 1) * dx[n])) for n in names)
     return lhs, rhs

@@ -121,3 +121,50 @@ class Oracle:
     def fv_dynamics(self, mode, nq, bdt, n_split, k_split, ins, ins_p=None, outs_p=None):
         return self._call("orc_fv_dynamics", mode, [C.c_int(nq), C.c_double(bdt), C.c_int(n_split), C.c_int(k_split)],
                           ins, ins_p, [self.npz] * (4 + nq), outs_p)
+
+
+class CubeOracle:
+    """Six-face oracle: one Oracle per face (face mode) + the exchange tables (oracle/cube.hpp)."""
+    KINDS = ["cell", "dvec", "cvec", "corner", "dedge"]
+
+    def __init__(self, n, npz, nq, metrics, opt, da_min, da_min_c, phis, ak, bk, edge, ecorner, tables):
+        self.n, self.npz, self.nq = n, npz, nq
+        self.pj = self.pi = n + 7
+        self.faces = []
+        for t in range(6):
+            o = Oracle(n, n, npz, nq, {k: v[t:t + 1] for k, v in metrics.items()}, opt, da_min, da_min_c, phis[t:t + 1], ak, bk)
+            o.set_face(edge[t], ecorner[t])
+            self.faces.append(o)
+        L = self.L = self.faces[0].L
+        self._tabs = [np.ascontiguousarray(tables[k], dtype=np.int32) for k in self.KINDS]
+        ip = C.POINTER(C.c_int)
+        tp = (ip * 5)(*[t.ctypes.data_as(ip) for t in self._tabs])
+        nr = (C.c_int * 5)(*[t.shape[0] for t in self._tabs])
+        fh = (C.c_void_p * 6)(*[o.h for o in self.faces])
+        L.orc_cube_create.restype = C.c_void_p
+        L.orc_cube_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(ip), C.POINTER(C.c_int)]
+        self.h = C.c_void_p(L.orc_cube_create(fh, tp, nr))
+
+    def _call(self, fname, mode, scalars, ins, ins_p, out_nk, outs_p=None):
+        """fields are [6, nk, pj, pi]; same conventions as Oracle._call"""
+        fn = getattr(self.L, fname)
+        ins = [np.ascontiguousarray(a, dtype=np.float64) for a in ins]
+        outs = [np.zeros((6, nk, self.pj, self.pi)) for nk in out_nk]
+        it = (_dp * len(ins))(*[_ptr(a) for a in ins]); ot = (_dp * len(outs))(*[_ptr(a) for a in outs])
+        if mode == NL:
+            ip = C.POINTER(_dp)(); op = C.POINTER(_dp)(); ipa = opa = None
+        else:
+            ipa = [np.ascontiguousarray(a, dtype=np.float64) for a in ins_p] if mode == TL else [np.zeros_like(a) for a in ins]
+            opa = [np.zeros_like(o) for o in outs] if mode == TL else [np.ascontiguousarray(a, dtype=np.float64) for a in outs_p]
+            ip = (_dp * len(ins))(*[_ptr(a) for a in ipa]); op = (_dp * len(outs))(*[_ptr(a) for a in opa])
+        fn.restype = None
+        fn(self.h, C.c_int(mode), *scalars, it, ip, ot, op)
+        return (outs, None) if mode == NL else (outs, opa) if mode == TL else (outs, ipa)
+
+    def dyn_core(self, mode, bdt, n_split, ins, ins_p=None, outs_p=None):
+        n = self.npz
+        return self._call("orc_cube_dyn_core", mode, [C.c_double(bdt), C.c_int(n_split)], ins, ins_p, [n] * 8 + [n + 1, n + 1, n + 1, n], outs_p)
+
+    def fv_dynamics(self, mode, nq, bdt, n_split, k_split, ins, ins_p=None, outs_p=None):
+        return self._call("orc_cube_fv_dynamics", mode, [C.c_int(nq), C.c_double(bdt), C.c_int(n_split), C.c_int(k_split)], ins, ins_p,
+                          [self.npz] * (4 + nq), outs_p)

@@ -1,0 +1,44 @@
+"""CPU (-m "not gpu") tests of the six-face path: DYN_CORE and the full fv_dynamics sweep on a C8 cube (all six faces
+resident, table-driven exchange) — host-emulation build of the HIP sources vs the six-face oracle (oracle/cube.hpp),
+tangent and adjoint, plus the dot-product identity.  The same checks run through the HIP library in test_gpu_parity.py."""
+import numpy as np
+import pytest
+from common import CubeCase, relerr
+from oracle import NL, TL, AD
+from groups import cube_check_dyn_core, cube_dot_product, cube_check_fv_dynamics, cube_dot_product_step
+
+
+@pytest.fixture(scope="module")
+def ccase():
+    return CubeCase(n=8, npz=5, n_split=2, backend="emul", oracle=True, hord_ks_traj=0, hord_ks_pert=0)
+
+
+def test_cube_dyn_core_tl(ccase):
+    cube_check_dyn_core(ccase, TL, 1e-10)
+
+
+def test_cube_dyn_core_ad(ccase):
+    cube_check_dyn_core(ccase, AD, 1e-10)
+
+
+def test_cube_dot_product(ccase):
+    lhs, rhs = cube_dot_product(ccase)
+    assert abs(lhs - rhs) <= 1e-12 * abs(lhs), (lhs, rhs)
+
+
+@pytest.fixture(scope="module")
+def ccase_q():
+    return CubeCase(n=8, npz=6, n_split=2, k_split=2, backend="emul", oracle=True, nq=2)
+
+
+def test_cube_fv_dynamics_tl(ccase_q):
+    cube_check_fv_dynamics(ccase_q, TL, 1e-10)
+
+
+def test_cube_fv_dynamics_ad(ccase_q):
+    cube_check_fv_dynamics(ccase_q, AD, 1e-10)
+
+
+def test_cube_step_dot_product(ccase_q):
+    lhs, rhs = cube_dot_product_step(ccase_q)
+    assert abs(lhs - rhs) <= 1e-11 * abs(lhs), (lhs, rhs)
