@@ -7,9 +7,10 @@
 A "step" is one pass of the hot path over the resident synthetic state: one step_tl (tangent linear)
 plus one step_ad (nonlinear forward sweep with stage checkpoints + backward sweep), i.e. what the
 reference's %step_tl and %step_ad do for the dynamics (DYN/fv3jedi_lm_dynamics_mod.F90:347,460).
-Workload at N=1: one C192 L127 hydrostatic face (36,864 columns), k_split=2, n_split=6, dt=450 s,
-4 tracers, doubly-periodic tile (the 6-face cube exchange is not built yet — DESIGN.md §8); with N
-ranks every rank owns one such tile (weak scaling, no data-path collective).
+Workload at N=1 (BASELINE.json configs[3] held by one GPU): the six faces of a C192 L127 hydrostatic cubed
+sphere (221,184 columns), k_split=2, n_split=6, dt=450 s, 4 tracers, all faces resident on the GPU with
+the table-driven face exchange (--tiles cube, default).  --tiles periodic runs one doubly-periodic C192
+tile (36,864 columns) per rank instead (the kernel-level workload of round 1's first measurements).
 Extra objects on the JSON line: "roofline" (dominant kernel, HIP events on the library's own stream),
 "contract" (whole step against BASELINE.md §3's algorithmic bytes) and "cpu_baseline" (the oracle
 port timed on one host core on a bounded sample).
@@ -68,6 +69,7 @@ def main():
     ap.add_argument("--n_split", type=int, default=6)
     ap.add_argument("--dt", type=float, default=450.0)
     ap.add_argument("--nq", type=int, default=4)
+    ap.add_argument("--tiles", choices=["cube", "periodic"], default="cube")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-out", default="")
     args = ap.parse_args()
@@ -83,16 +85,25 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     import ctypes as C
     import fv3_jedi_linearmodel_amd as fv3
-    from common import Case
-    from groups import step_state
+    from common import Case, CubeCase
+    from groups import step_state, cube_step_state
     lib = fv3.load_hip_library()
     lib.L.fv3lm_set_device(C.c_int(local))
-    c = Case(nx=args.nx, ny=args.nx, npz=args.npz, n_split=args.n_split, k_split=args.k_split, dt=args.dt, backend="hip",
-             oracle=False, nq=args.nq, seed=20250114 + rank)
-    T, P = step_state(c)
+    cube_mode = args.tiles == "cube"
+    if cube_mode and world > 1:
+        raise SystemExit("bench.py: --tiles cube shards the six faces over ranks through the RCCL exchange, which is not built yet; "
+                         "use --tiles periodic for N > 1")
+    if cube_mode:
+        c = CubeCase(n=args.nx, npz=args.npz, n_split=args.n_split, k_split=args.k_split, dt=args.dt, backend="hip", nq=args.nq)
+        T, P = cube_step_state(c)
+    else:
+        c = Case(nx=args.nx, ny=args.nx, npz=args.npz, n_split=args.n_split, k_split=args.k_split, dt=args.dt, backend="hip",
+                 oracle=False, nq=args.nq, seed=20250114 + rank)
+        T, P = step_state(c)
+        T = {k: v[None] for k, v in T.items()}; P = {k: v[None] for k, v in P.items()}
     names = ["u", "v", "pt", "delp"] + ["q%d" % (n + 1) for n in range(c.nq)]
     for n in names:
-        c.dy.put(n, T[n][None], 0); c.dy.put(n, P[n][None], 1)
+        c.dy.put(n, T[n], 0); c.dy.put(n, P[n], 1)
     c.dy.state_save()
 
     def one_step():
@@ -119,7 +130,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
-    cols_rank = args.nx * args.nx
+    cols_rank = args.nx * args.nx * (6 if cube_mode else 1)
     value = world * cols_rank / (elapsed / args.steps)
 
     # roofline leg: per-kernel HIP-event durations on the library's stream over one more step
@@ -137,9 +148,10 @@ def main():
             "metric": "column-updates/s per TL+AD dyn step", "value": value, "unit": "column-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C%dL%d hydrostatic TL+AD, 1 doubly-periodic tile (one cube face, %d columns) per GPU, "
+            "config": {"workload": "C%dL%d hydrostatic TL+AD, %s (%d columns per GPU), "
                                    "k_split=%d n_split=%d dt=%gs nq=%d, hord=2 (1 in the sponge), kord=17, nord=1"
-                                   % (args.nx, args.npz, cols_rank, args.k_split, args.n_split, args.dt, args.nq),
+                                   % (args.nx, args.npz, "six cube faces resident on one GPU, table-driven face exchange" if cube_mode
+                                      else "1 doubly-periodic tile per GPU", cols_rank, args.k_split, args.n_split, args.dt, args.nq),
                        "columns_per_gpu": cols_rank, "launches_per_step": sum(v[0] for v in prof.values())},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,

@@ -107,9 +107,9 @@ class CubeCase:
         self.traj, self.phis, self.ak, self.bk = cube.cube_fields(n, npz, self.geo, seed, "traj", self.opt)
         self.pert = cube.cube_fields(n, npz, self.geo, seed + 1, "pert")
         rng = np.random.default_rng(seed + 7)
-        qs = [cube.cube_fields(n, npz, self.geo, seed + 11 + m, "pert") for m in range(nq)]
-        self.qtraj = [1e-3 * (m + 1) + 1e-2 * np.abs(qs[m]["pt"]) for m in range(nq)]
-        self.qpert = [1e-3 * qs[m]["delp"] / 10.0 for m in range(nq)]
+        aux = cube.cube_fields(n, npz, self.geo, seed + 11, "pert") if nq else None
+        self.qtraj = [1e-3 * (m + 1) + 1e-2 * np.abs(aux["pt"] if m % 2 == 0 else 2e-3 * aux["delp"]) * (1.0 + 0.25 * m) for m in range(nq)]
+        self.qpert = [1e-4 * (aux["delp"] if m % 2 == 0 else 500.0 * aux["pt"]) * (1.0 + 0.5 * m) for m in range(nq)]
         self.dims = fv3.Dims(nx=n, ny=n, npz=npz, ntile=6, nq=nq, n_split=n_split, k_split=k_split, face=1, dt=dt)
         self.dt_ac = dt / n_split / k_split
         self.face = "cube"

@@ -98,3 +98,94 @@ def test_dot_product_step_c48l72():
     c = Case(nx=48, ny=48, npz=72, n_split=6, k_split=1, dt=900.0, backend="hip", oracle=False, nq=4)
     lhs, rhs = dot_product_step(c)
     assert abs(lhs - rhs) <= 1e-12 * abs(lhs), (lhs, rhs)
+
+
+# ------------------------------------------------------------------ cube faces (edge / corner branches, exchange)
+FACE_OPTS = {"default": {}, "hord2": dict(hord_ks_traj=0, hord_ks_pert=0),
+             "nord0_hord333": dict(nord=0, nord_pert=0, hord_mt=333, hord_vt=333, hord_tm=333, hord_dp=333, hord_mt_pert=333, hord_vt_pert=333,
+                                   hord_tm_pert=333, hord_dp_pert=333, hord_ks_traj=0, hord_ks_pert=0)}
+
+
+@pytest.fixture(scope="module", params=list(FACE_OPTS))
+def fcase(request):
+    from common import Case
+    return Case(nx=12, ny=12, npz=6, n_split=2, dt=1800.0, backend="hip", face=2, **FACE_OPTS[request.param])
+
+
+@pytest.mark.parametrize("group", GROUPS)
+def test_face_group_tl(fcase, group):
+    from groups import check_group
+    check_group(fcase, group, TL, 1e-12)
+
+
+@pytest.mark.parametrize("group", GROUPS)
+def test_face_group_ad(fcase, group):
+    from groups import check_group
+    check_group(fcase, group, AD, 1e-11)
+
+
+def test_face_tracer():
+    from common import Case
+    from groups import check_tracer
+    c = Case(nx=12, ny=12, npz=6, n_split=2, dt=1800.0, backend="hip", face=4, nq=2, hord_ks_traj=0, hord_ks_pert=0)
+    check_tracer(c, TL, 1e-11)
+    check_tracer(c, AD, 1e-10)
+
+
+@pytest.fixture(scope="module")
+def cube_case():
+    from common import CubeCase
+    return CubeCase(n=8, npz=5, n_split=2, backend="hip", oracle=True, hord_ks_traj=0, hord_ks_pert=0)
+
+
+KINDS = [("cell", "delp", ""), ("dvec", "u", "v"), ("cvec", "uc", "vc"), ("corner", "divgd", ""), ("dedge", "u_o", "v_o")]
+
+
+@pytest.mark.parametrize("kind,f0,f1", KINDS)
+def test_cube_exchange(cube_case, kind, f0, f1):
+    """device exchange == table applied in numpy (bit-exact: pure data motion), and <E x, y> = <x, E^T y>"""
+    from fv3_jedi_linearmodel_amd import cube
+    c = cube_case; rng = np.random.default_rng(3)
+    shp = c.dy.shape(f0); names = [f0] + ([f1] if f1 else [])
+    x = [rng.standard_normal(shp) for _ in names]; y = [rng.standard_normal(shp) for _ in names]
+    for n, a in zip(names, x):
+        c.dy.put(n, a, 0); c.dy.put(n, a, 1)
+    c.dy.halo(kind, f0, f1, 1)
+    ref = [a.copy() for a in x]
+    cube.apply_table(c.tables[kind], ref[0], ref[1] if f1 else None)
+    for n, r in zip(names, ref):
+        assert np.array_equal(c.dy.get(n, 0), r) and np.array_equal(c.dy.get(n, 1), r)
+    Ex = [c.dy.get(n, 1) for n in names]
+    for n, a in zip(names, y):
+        c.dy.put(n, a, 1)
+    c.dy.halo(kind, f0, f1, 2)
+    Ety = [c.dy.get(n, 1) for n in names]
+    lhs = sum(float(np.sum(p * q)) for p, q in zip(Ex, y)); rhs = sum(float(np.sum(p * q)) for p, q in zip(x, Ety))
+    assert abs(lhs - rhs) <= 1e-13 * abs(lhs)
+
+
+def test_cube_dyn_core(cube_case):
+    from groups import cube_check_dyn_core, cube_dot_product
+    cube_check_dyn_core(cube_case, TL, 1e-10)
+    cube_check_dyn_core(cube_case, AD, 1e-10)
+    lhs, rhs = cube_dot_product(cube_case)
+    assert abs(lhs - rhs) <= 1e-12 * abs(lhs), (lhs, rhs)
+
+
+def test_cube_fv_dynamics():
+    from common import CubeCase
+    from groups import cube_check_fv_dynamics, cube_dot_product_step
+    c = CubeCase(n=8, npz=6, n_split=2, k_split=2, backend="hip", oracle=True, nq=2)
+    cube_check_fv_dynamics(c, TL, 1e-10)
+    cube_check_fv_dynamics(c, AD, 1e-10)
+    lhs, rhs = cube_dot_product_step(c)
+    assert abs(lhs - rhs) <= 1e-11 * abs(lhs), (lhs, rhs)
+
+
+def test_cube_step_dot_product_c48l72():
+    """Six faces of a C48 L72 cube resident on one GPU (BASELINE config 2 resolution): step_tl / step_ad identity."""
+    from common import CubeCase
+    from groups import cube_dot_product_step
+    c = CubeCase(n=48, npz=72, n_split=6, k_split=2, dt=900.0, backend="hip", nq=2)
+    lhs, rhs = cube_dot_product_step(c)
+    assert abs(lhs - rhs) <= 1e-11 * abs(lhs), (lhs, rhs)
