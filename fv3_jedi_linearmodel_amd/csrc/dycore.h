@@ -144,6 +144,7 @@ struct Dycore {
   Fld W(const char* n, int nk) { Fld x = work.take((size_t)g.ntile * nk * g.plane, nk); F[n] = x; return x; }
 
   Rect R(int i0, int i1, int j0, int j1) const { return Rect{i0, i1, j0, j1}; }
+  static Rect empty_in(const Rect& r) { return Rect{r.i0 + 1, r.i0, r.j0 + 1, r.j0}; }   // contains nothing, leaves the union with r alone
 
   template <class St>
   void add(Program& P, const char* group, const St& s) {
@@ -211,12 +212,28 @@ struct Dycore {
   void build_a2b(Program& P, const char* grp, const std::string& pre, Fld q, Fld qb, int nk) {
     const int is = 1, ie = g.nx, js = 1, je = g.ny;
     Fld qx = W((pre + "_qx").c_str(), nk), qy = W((pre + "_qy").c_str(), nk);
-    A2bA a; a.in[0] = q; a.out[0] = qx; a.out[1] = qy; a.k1 = nk;
-    if (g.face) { a.orect[0] = R(is, ie + 1, js, je); a.orect[1] = R(is, ie, js, je + 1); }
-    else { a.orect[0] = R(is, ie + 1, js - 2, je + 2); a.orect[1] = R(is - 2, ie + 2, js, je + 1); }
-    add(P, grp, a);
-    A2bB b; b.in[0] = qx; b.in[1] = qy; b.in[2] = g.face ? q : Fld{}; b.out[0] = qb; b.orect[0] = R(is, ie + 1, js, je + 1); b.k1 = nk;
-    add(P, grp, b);
+    const int npx = g.nx + 1, npy = g.ny + 1;
+    A2bA_<false> a; a.in[0] = q; a.out[0] = qx; a.out[1] = qy; a.k1 = nk;
+    A2bB_<false> b; b.in[0] = qx; b.in[1] = qy; b.in[2] = Fld{}; b.out[0] = qb; b.k1 = nk;
+    if (!g.face) {
+      a.orect[0] = R(is, ie + 1, js - 2, je + 2); a.orect[1] = R(is - 2, ie + 2, js, je + 1); add(P, grp, a);
+      b.orect[0] = R(is, ie + 1, js, je + 1); add(P, grp, b);
+      return;
+    }
+    // face: the 4-point formulas away from the edges, the edge formulas on strips two points wide (column strips run
+    // with the wave along j, exec.h strip_tr)
+    a.orect[0] = R(3, npx - 2, 1, npy - 1); a.orect[1] = R(1, npx - 1, 3, npy - 2); add(P, grp, a);
+    A2bA_<true> ae; ae.in[0] = q; ae.out[0] = qx; ae.out[1] = qy; ae.k1 = nk;
+    for (int e = 0; e < 4; ++e) {
+      const Rect r = e == 0 ? R(1, 2, 1, npy - 1) : e == 1 ? R(npx - 1, npx, 1, npy - 1) : e == 2 ? R(1, npx - 1, 1, 2) : R(1, npx - 1, npy - 1, npy);
+      ae.orect[e < 2 ? 0 : 1] = r; ae.orect[e < 2 ? 1 : 0] = empty_in(r); add(P, grp, ae);
+    }
+    b.orect[0] = R(3, npx - 2, 3, npy - 2); add(P, grp, b);
+    A2bB_<true> be; be.in[0] = qx; be.in[1] = qy; be.in[2] = q; be.out[0] = qb; be.k1 = nk;
+    for (int e = 0; e < 4; ++e) {
+      be.orect[0] = e == 0 ? R(1, npx, 1, 2) : e == 1 ? R(1, npx, npy - 1, npy) : e == 2 ? R(1, 2, 3, npy - 2) : R(npx - 1, npx, 3, npy - 2);
+      add(P, grp, be);
+    }
   }
 
   void build_acoustic();
@@ -281,7 +298,7 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
   ctx.g = g; ctx.lev = lev_dev; ctx.nlev = npz;
   n3 = np * npz; n3p = np * (npz + 1);
   state.init(n3 * (20 + 3 * (size_t)nq) + n3p * 8);
-  work.init(n3 * 110 + n3p * 14);
+  work.init(n3 * (g.face ? 116 : 110) + n3p * 14);
   build_acoustic();
   ckpt = (double*)dev_alloc((size_t)n_split * k_split * 4 * n3 * 8);
   return true;
@@ -337,9 +354,20 @@ inline void Dycore::build_acoustic() {
     s.k1 = npz; add(P, "c_sw", s); }
   Fld uc0 = W("uc0", npz), utf = W("utf", npz), vc0 = W("vc0", npz), vtf = W("vtf", npz);
   const Fld none{};
-  { CswInterpC s; s.in[0] = utmp; s.in[1] = vtmp; s.in[2] = u; s.in[3] = v; s.in[4] = g.face ? ua : none; s.in[5] = g.face ? va : none; s.out[0] = uc0; s.out[1] = utf; s.out[2] = vc0; s.out[3] = vtf;
-    s.orect[0] = s.orect[1] = R(is - 1, ie + 2, js - 1, je + 1); s.orect[2] = s.orect[3] = R(is - 1, ie + 1, js - 1, je + 2);
-    s.dt2 = dt2; s.k1 = npz; add(P, "c_sw", s); }
+  { CswInterpC_<false> s; s.in[0] = utmp; s.in[1] = vtmp; s.in[2] = u; s.in[3] = v; s.out[0] = uc0; s.out[1] = utf; s.out[2] = vc0; s.out[3] = vtf;
+    s.dt2 = dt2; s.k1 = npz;
+    if (!g.face) {
+      s.orect[0] = s.orect[1] = R(is - 1, ie + 2, js - 1, je + 1); s.orect[2] = s.orect[3] = R(is - 1, ie + 1, js - 1, je + 2); add(P, "c_sw", s);
+    } else {   // 4-point interpolation away from the edges; one-sided / edge formulas and corner views on 3-wide strips
+      const int npx = g.nx + 1, npy = g.ny + 1;
+      s.orect[0] = s.orect[1] = R(3, npx - 2, js - 1, je + 1); s.orect[2] = s.orect[3] = R(is - 1, ie + 1, 3, npy - 2); add(P, "c_sw", s);
+      CswInterpC_<true> e; for (int n = 0; n < 4; ++n) { e.in[n] = s.in[n]; e.out[n] = s.out[n]; }
+      e.in[4] = ua; e.in[5] = va; e.dt2 = dt2; e.k1 = npz;
+      for (int m = 0; m < 4; ++m) {
+        const Rect r = m == 0 ? R(0, 2, js - 1, je + 1) : m == 1 ? R(npx - 1, npx + 1, js - 1, je + 1) : m == 2 ? R(is - 1, ie + 1, 0, 2) : R(is - 1, ie + 1, npy - 1, npy + 1);
+        e.orect[0] = e.orect[1] = m < 2 ? r : empty_in(r); e.orect[2] = e.orect[3] = m < 2 ? empty_in(r) : r; add(P, "c_sw", e);
+      }
+    } }
   Fld divgd = W("divgd", npz);
   if (opt.nord > 0) {
     CswDivg s; s.in[0] = u; s.in[1] = v; s.in[2] = ua; s.in[3] = va; s.out[0] = divgd; s.orect[0] = R(is, ie + 1, js, je + 1); s.k1 = npz;
@@ -374,7 +402,14 @@ inline void Dycore::build_acoustic() {
     Fld ut_a = W("ut_a", npz), vt_a = W("vt_a", npz);
     { DswWindsA s; s.in[0] = uc; s.in[1] = vc; s.out[0] = ut_a; s.out[1] = vt_a; s.orect[0] = R(is - 1, ie + 2, jsd, jed); s.orect[1] = R(isd, ied, js - 1, je + 2);
       s.dt = dt; s.k1 = npz; add(P, "d_sw", s); }
-    DswWindsB s; s.in[0] = ut_a; s.in[1] = vt_a; s.in[2] = uc; s.in[3] = vc; s.out[0] = ut; s.out[1] = crx; s.out[2] = xfx; s.out[3] = vt; s.out[4] = cry; s.out[5] = yfx;
+    Fld ut_e = W("ut_e", npz), vt_e = W("vt_e", npz);
+    const int npx = g.nx + 1, npy = g.ny + 1;
+    DswWindsE se; se.in[0] = ut_a; se.in[1] = vt_a; se.in[2] = uc; se.in[3] = vc; se.out[0] = ut_e; se.out[1] = vt_e; se.k1 = npz;
+    for (int e = 0; e < 4; ++e) {
+      const Rect r = e == 0 ? R(is - 1, ie + 2, 0, 1) : e == 1 ? R(is - 1, ie + 2, npy - 1, npy) : e == 2 ? R(0, 1, js - 1, je + 2) : R(npx - 1, npx, js - 1, je + 2);
+      se.orect[e < 2 ? 0 : 1] = r; se.orect[e < 2 ? 1 : 0] = empty_in(r); add(P, "d_sw", se);
+    }
+    DswWindsC s; s.in[0] = ut_a; s.in[1] = vt_a; s.in[2] = ut_e; s.in[3] = vt_e; s.out[0] = ut; s.out[1] = crx; s.out[2] = xfx; s.out[3] = vt; s.out[4] = cry; s.out[5] = yfx;
     s.orect[0] = R(is - 1, ie + 2, jsd, jed); s.orect[1] = s.orect[2] = R(is, ie + 1, jsd, jed);
     s.orect[3] = R(isd, ied, js - 1, je + 2); s.orect[4] = s.orect[5] = R(isd, ied, js, je + 1); s.dt = dt; s.k1 = npz; add(P, "d_sw", s);
   }

@@ -140,56 +140,38 @@ HD bool d2a2c_yalias(const Geom& g, int i, int j, int& ai, int& aj) {
 
 constexpr double EC1 = -2. / 14., EC2 = 11. / 14., EC3 = 5. / 14.;   // c1,c2,c3 tp_core_tlm.F90:62-64
 
-// PPM edge value al(m) on a line with cell index m (absolute), q(m') accessor by absolute index, metric
-// dxa/dya by absolute index; n1 = npx (or npy) of the face.  Standard 4-point value away from edges.
+// PPM edge value al(m) = sum_d w[d] * q(m-2+d), d = 0..3, on a line with absolute cell index m; metric dxa/dya
+// (or dx/dy for xtp_u/ytp_v) by absolute index, n1 = npx (or npy) of the face.  Away from a face edge the weights
+// are (p2, p1, p1, p2); within one cell of it they are the one-sided / two-sided extrapolations of
+// tp_core_tlm.F90:2402-2429 (sw_core_tlm.F90:7381-7460 for the winds) — all of which happen to use the same four
+// cells, so every lane of a wave runs the same loads and multiply-adds and only the weights differ.
+template <class D>
+HD void ppm_w(bool face, int m, int n1, const D& da, double* w) {
+  w[0] = w[3] = -1. / 12.; w[1] = w[2] = 7. / 12.;
+  if (face) {
+    if (m == 0 || m == n1 - 1) { w[0] = EC1; w[1] = EC2; w[2] = EC3; w[3] = 0.; }
+    else if (m == 2 || m == n1 + 1) { w[0] = 0.; w[1] = EC3; w[2] = EC2; w[3] = EC1; }
+    else if (m == 1 || m == n1) {
+      const double a = da(m - 2), b = da(m - 1), c = da(m), d = da(m + 1);
+      w[0] = -0.5 * b / (a + b); w[1] = 0.5 * (2. * b + a) / (a + b); w[2] = 0.5 * (2. * c + d) / (c + d); w[3] = -0.5 * c / (c + d);
+    }
+  }
+}
 template <class T, class Q, class D>
 HD T ppm_al(bool face, int m, int n1, const Q& q, const D& da) {
-  if (face) {
-    if (m == 0) return EC1 * q(-2) + EC2 * q(-1) + EC3 * q(0);
-    if (m == 1) return 0.5 * (((2. * da(0) + da(-1)) * q(0) - da(0) * q(-1)) / (da(-1) + da(0)) +
-                              ((2. * da(1) + da(2)) * q(1) - da(1) * q(2)) / (da(1) + da(2)));
-    if (m == 2) return EC3 * q(1) + EC2 * q(2) + EC1 * q(3);
-    if (m == n1 - 1) return EC1 * q(n1 - 3) + EC2 * q(n1 - 2) + EC3 * q(n1 - 1);
-    if (m == n1) return 0.5 * (((2. * da(n1 - 1) + da(n1 - 2)) * q(n1 - 1) - da(n1 - 1) * q(n1 - 2)) / (da(n1 - 2) + da(n1 - 1)) +
-                               ((2. * da(n1) + da(n1 + 1)) * q(n1) - da(n1) * q(n1 + 1)) / (da(n1) + da(n1 + 1)));
-    if (m == n1 + 1) return EC3 * q(n1) + EC2 * q(n1 + 1) + EC1 * q(n1 + 2);
-  }
-  return (7. / 12.) * (q(m - 1) + q(m)) + (-1. / 12.) * (q(m - 2) + q(m + 1));
+  double w[4];
+  ppm_w(face, m, n1, da, w);
+  return w[0] * q(m - 2) + w[1] * q(m - 1) + w[2] * q(m) + w[3] * q(m + 1);
 }
 
-// xtp_u / ytp_v slopes bl(m), br(m) of cell m on a line (sw_core_tlm.F90:7363-7460, :7585-7690).
-// row_edge: this line lies on a face edge in the other direction (j == 1 or j == npy for xtp_u).
+// xtp_u / ytp_v slopes bl(m), br(m) of cell m on a line (sw_core_tlm.F90:7363-7460, :7585-7690): the same edge
+// values with the D-grid metric.  row_edge: the line itself lies on a face edge of the other direction
+// (j == 1 or j == npy for xtp_u), where the two cells next to the corner get zero slopes.
 template <class T, class Q, class D>
 HD void uv_blbr(bool face, int m, int n1, bool row_edge, const Q& q, const D& dd, T& bl, T& br) {
-  auto al = [&](int k) -> T { return (7. / 12.) * (q(k - 1) + q(k)) + (-1. / 12.) * (q(k - 2) + q(k + 1)); };
-  if (face && (m <= 2 || m >= n1 - 2)) {
-    if (row_edge && (m == 0 || m == 1 || m == n1 - 1 || m == n1)) { bl = T(0.); br = T(0.); return; }
-    if (m == 0) {
-      bl = EC1 * q(-2) + EC2 * q(-1) + EC3 * q(0) - q(0);
-      T xt = 0.5 * (((2. * dd(0) + dd(-1)) * q(0) - dd(0) * q(-1)) / (dd(0) + dd(-1)) + ((2. * dd(1) + dd(2)) * q(1) - dd(1) * q(2)) / (dd(1) + dd(2)));
-      br = xt - q(0); return;
-    }
-    if (m == 1) {
-      T xt = 0.5 * (((2. * dd(0) + dd(-1)) * q(0) - dd(0) * q(-1)) / (dd(0) + dd(-1)) + ((2. * dd(1) + dd(2)) * q(1) - dd(1) * q(2)) / (dd(1) + dd(2)));
-      bl = xt - q(1);
-      br = EC3 * q(1) + EC2 * q(2) + EC1 * q(3) - q(1); return;
-    }
-    if (m == 2) { bl = EC3 * q(1) + EC2 * q(2) + EC1 * q(3) - q(2); br = al(3) - q(2); return; }
-    if (m == n1 - 2) { bl = al(n1 - 2) - q(n1 - 2); br = EC1 * q(n1 - 3) + EC2 * q(n1 - 2) + EC3 * q(n1 - 1) - q(n1 - 2); return; }
-    if (m == n1 - 1) {
-      bl = EC1 * q(n1 - 3) + EC2 * q(n1 - 2) + EC3 * q(n1 - 1) - q(n1 - 1);
-      T xt = 0.5 * (((2. * dd(n1 - 1) + dd(n1 - 2)) * q(n1 - 1) - dd(n1 - 1) * q(n1 - 2)) / (dd(n1 - 1) + dd(n1 - 2)) +
-                    ((2. * dd(n1) + dd(n1 + 1)) * q(n1) - dd(n1) * q(n1 + 1)) / (dd(n1) + dd(n1 + 1)));
-      br = xt - q(n1 - 1); return;
-    }
-    if (m == n1) {
-      T xt = 0.5 * (((2. * dd(n1 - 1) + dd(n1 - 2)) * q(n1 - 1) - dd(n1 - 1) * q(n1 - 2)) / (dd(n1 - 1) + dd(n1 - 2)) +
-                    ((2. * dd(n1) + dd(n1 + 1)) * q(n1) - dd(n1) * q(n1 + 1)) / (dd(n1) + dd(n1 + 1)));
-      bl = xt - q(n1);
-      br = EC3 * q(n1) + EC2 * q(n1 + 1) + EC1 * q(n1 + 2) - q(n1); return;
-    }
-  }
-  bl = al(m) - q(m); br = al(m + 1) - q(m);
+  if (face && row_edge && (m == 0 || m == 1 || m == n1 - 1 || m == n1)) { bl = T(0.); br = T(0.); return; }
+  bl = ppm_al<T>(face, m, n1, q, dd) - q(m);
+  br = ppm_al<T>(face, m + 1, n1, q, dd) - q(m);
 }
 
 // edge_interpolate4, sw_core_tlm.F90:6822-6832

@@ -226,19 +226,24 @@ inline double stage_bytes(const S& s, const Ctx& c, const Rect& R, int mode) {
 #ifndef FV3LM_HOST_EMUL
 // ---- HIP kernels ---------------------------------------------------------------------------
 constexpr int BX = 64, BY = 4;
+// tr: narrow column strips (face-edge stages) run with the 64 lanes of a wave along j instead of i
+HD void thread_point(const Rect& R, int tr, int bx, int by, int tx, int ty, int& i, int& j) {
+  if (tr) { j = R.j0 + bx * BX + tx; i = R.i0 + by * BY + ty; }
+  else { i = R.i0 + bx * BX + tx; j = R.j0 + by * BY + ty; }
+}
 template <class S>
-__global__ void __launch_bounds__(BX* BY) k_stage_nl(S s, Ctx c, Rect R) {
-  const int i = R.i0 + blockIdx.x * BX + threadIdx.x, j = R.j0 + blockIdx.y * BY + threadIdx.y;
+__global__ void __launch_bounds__(BX* BY) k_stage_nl(S s, Ctx c, Rect R, int tr) {
+  int i, j; thread_point(R, tr, blockIdx.x, blockIdx.y, threadIdx.x, threadIdx.y, i, j);
   if (i <= R.i1 && j <= R.j1) body_nl(s, c, i, j, blockIdx.z);
 }
 template <class S>
-__global__ void __launch_bounds__(BX* BY) k_stage_tl(S s, Ctx c, Rect R) {
-  const int i = R.i0 + blockIdx.x * BX + threadIdx.x, j = R.j0 + blockIdx.y * BY + threadIdx.y;
+__global__ void __launch_bounds__(BX* BY) k_stage_tl(S s, Ctx c, Rect R, int tr) {
+  int i, j; thread_point(R, tr, blockIdx.x, blockIdx.y, threadIdx.x, threadIdx.y, i, j);
   if (i <= R.i1 && j <= R.j1) body_tl(s, c, i, j, blockIdx.z);
 }
 template <class S>
-__global__ void __launch_bounds__(BX* BY) k_stage_ad(S s, Ctx c, Rect R, Rect Q, int nkmax) {
-  const int i = Q.i0 + blockIdx.x * BX + threadIdx.x, j = Q.j0 + blockIdx.y * BY + threadIdx.y;
+__global__ void __launch_bounds__(BX* BY) k_stage_ad(S s, Ctx c, Rect R, Rect Q, int nkmax, int tr) {
+  int i, j; thread_point(Q, tr, blockIdx.x, blockIdx.y, threadIdx.x, threadIdx.y, i, j);
   if (i <= Q.i1 && j <= Q.j1) AdLoop<S, 0>::run(s, c, R, i, j, blockIdx.z, nkmax);
 }
 template <class S>
@@ -248,14 +253,16 @@ __global__ void __launch_bounds__(64) k_stage_ad_alias(S s, Ctx c, Rect R) {
   corner_block_point(c.g, blockIdx.x, threadIdx.x, i, j);
   AdAliasLoop<S, 0>::run(s, c, R, i, j, blockIdx.y);
 }
-inline dim3 grid_for(const Rect& R, int nz) {
+inline int strip_tr(const Rect& R) { return (R.i1 - R.i0 + 1 <= 2 * BY && R.j1 - R.j0 + 1 >= BX / 2) ? 1 : 0; }
+inline dim3 grid_for(const Rect& R, int nz, int tr = 0) {
+  if (tr) return dim3((R.j1 - R.j0 + BX) / BX, (R.i1 - R.i0 + BY) / BY, nz);
   return dim3((R.i1 - R.i0 + BX) / BX, (R.j1 - R.j0 + BY) / BY, nz);
 }
 template <class S>
 void run_nl(Exec& ex, const S& s, const Ctx& c) {
   Rect R = rect_union(s.orect, S::NOUT);
   ex.mark_begin(S::name(), ".nl", stage_bytes(s, c, R, MODE_NL));
-  hipLaunchKernelGGL(k_stage_nl<S>, grid_for(R, c.g.ntile * (s.k1 - s.k0 + 1)), dim3(BX, BY), 0, ex.stream, s, c, R);
+  hipLaunchKernelGGL(k_stage_nl<S>, grid_for(R, c.g.ntile * (s.k1 - s.k0 + 1), strip_tr(R)), dim3(BX, BY), 0, ex.stream, s, c, R, strip_tr(R));
   ex.mark_end();
   ex.launches++;
 }
@@ -263,7 +270,7 @@ template <class S>
 void run_tl(Exec& ex, const S& s, const Ctx& c) {
   Rect R = rect_union(s.orect, S::NOUT);
   ex.mark_begin(S::name(), ".tl", stage_bytes(s, c, R, MODE_TL));
-  hipLaunchKernelGGL(k_stage_tl<S>, grid_for(R, c.g.ntile * (s.k1 - s.k0 + 1)), dim3(BX, BY), 0, ex.stream, s, c, R);
+  hipLaunchKernelGGL(k_stage_tl<S>, grid_for(R, c.g.ntile * (s.k1 - s.k0 + 1), strip_tr(R)), dim3(BX, BY), 0, ex.stream, s, c, R, strip_tr(R));
   ex.mark_end();
   ex.launches++;
 }
@@ -274,7 +281,7 @@ void run_ad(Exec& ex, const S& s, const Ctx& c) {
   int nkmax = 0;
   for (int m = 0; m < S::NIN; ++m) if (s.in[m].nk > nkmax) nkmax = s.in[m].nk;
   ex.mark_begin(S::name(), ".ad", stage_bytes(s, c, R, MODE_AD));
-  hipLaunchKernelGGL(k_stage_ad<S>, grid_for(Q, c.g.ntile * nkmax), dim3(BX, BY), 0, ex.stream, s, c, R, Q, nkmax);
+  hipLaunchKernelGGL(k_stage_ad<S>, grid_for(Q, c.g.ntile * nkmax, strip_tr(Q)), dim3(BX, BY), 0, ex.stream, s, c, R, Q, nkmax, strip_tr(Q));
   ex.mark_end();
   ex.launches++;
   if constexpr (S::NALIAS > 0) if (c.g.face) {

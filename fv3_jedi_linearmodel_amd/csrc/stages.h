@@ -105,15 +105,17 @@ struct CswInterpA {
 
 // d2a2c_vect C: A-grid -> C-grid + contravariant flux-form winds (:6617-6803, :713-733).  The corner
 // fixes of utmp/vtmp/ua/va (:6617-6640, :6662-6677, :6726-6760) are read through d2a2c_xview/yview.
-struct CswInterpC {
-  STAGE_BASE("CswInterpC", 6, 4)   // in: utmp vtmp u v ua va   out: uc0 utf vc0 vtf
+template <bool EDGE>
+struct CswInterpC_ {
+  STAGE_BASE(EDGE ? "CswInterpCe" : "CswInterpC", 6, 4)   // in: utmp vtmp u v ua va   out: uc0 utf vc0 vtf
   double dt2;
   HD static constexpr bool uses(int, int, int, int) { return true; }
   HD static constexpr unsigned wants(int M) { return (M == 0 || M == 4) ? 0x3u : (M == 1 || M == 5) ? 0xCu : M == 2 ? 0x8u : 0x2u; }
   HD static constexpr Box box(int M) { return (M == 0 || M == 4) ? Box{-2, 1, 0, 0, 0, 0} : (M == 1 || M == 5) ? Box{0, 0, -2, 1, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
-  static constexpr int NALIAS = 1;
+  static constexpr int NALIAS = EDGE ? 1 : 0;
   HD static constexpr int alias_box(int M) { return M == 0 ? 1 : M == 1 ? 0 : M == 4 ? 5 : M == 5 ? 4 : M; }
   HD bool alias(const Ctx& c, int M, int i, int j, int, int& ai, int& aj) const {
+    if (!EDGE) return false;
     if (M == 1 || M == 5) return d2a2c_xalias(c.g, i, j, ai, aj);
     if (M == 0 || M == 4) return d2a2c_yalias(c.g, i, j, ai, aj);
     return false;
@@ -121,19 +123,19 @@ struct CswInterpC {
   template <int MU, int MV, class T, class A>
   HD T rx(const A& a, const Ctx& c, int i, int j) const {   // utmp / ua as the x-direction pass sees them
     int oi, oj; double sg;
-    if (c.g.face && d2a2c_xview(c.g, i, j, oi, oj, sg)) return sg * IN(MV, oi, oj);
+    if (EDGE && d2a2c_xview(c.g, i, j, oi, oj, sg)) return sg * IN(MV, oi, oj);
     return IN(MU, i, j);
   }
   template <int MV, int MU, class T, class A>
   HD T ry(const A& a, const Ctx& c, int i, int j) const {   // vtmp / va as the y-direction pass sees them
     int oi, oj; double sg;
-    if (c.g.face && d2a2c_yview(c.g, i, j, oi, oj, sg)) return sg * IN(MU, oi, oj);
+    if (EDGE && d2a2c_yview(c.g, i, j, oi, oj, sg)) return sg * IN(MU, oi, oj);
     return IN(MV, i, j);
   }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = o[2] = o[3] = T(0.);
-    const bool F = c.g.face; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
+    constexpr bool F = EDGE; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
     if ((a.want & 0x3u) && orect[0].has(i, j)) {
       T uc, ut;
       if (F && (i == 1 || i == npx)) {
@@ -382,12 +384,11 @@ struct DswWindsA {
     }
   }
 };
-// Pass B: rows/columns next to an edge from the pass-A winds (:2752-2766, :2777-2793, :2804-2819,
-// :2831-2846), the 2x2 systems at the four corners (:2856-2919, which also only read pass-A values),
-// then Courant numbers and area fluxes of the final winds.
-struct DswWindsB {
-  STAGE_COMMON("DswWindsB", 4, 6)   // in: ut_a vt_a uc vc   out: ut crx xfx vt cry yfx
-  double dt;
+// Pass B, on the strips next to the face edges only: the two ut rows next to a south/north edge and the two vt
+// columns next to a west/east edge from the pass-A winds (:2752-2766, :2777-2793, :2804-2819, :2831-2846), and the
+// 2x2 systems at the four corners (:2856-2919), which also only read pass-A values.  Everything else is pass A.
+struct DswWindsE {
+  STAGE_COMMON("DswWindsE", 4, 2)   // in: ut_a vt_a uc vc   out: ut_e (row strips) vt_e (column strips)
   HD static constexpr Box box(int M) { return M < 2 ? Box{-1, 1, -1, 1, 0, 0} : M == 2 ? Box{0, 1, -1, 0, 0, 0} : Box{-1, 0, 0, 1, 0, 0}; }
   // the four vt around ut(i,j) / the four ut around vt(i,j), one of them (ei,ej) left out
   template <class T, class A>
@@ -404,32 +405,44 @@ struct DswWindsB {
   }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    for (int n = 0; n < 6; ++n) o[n] = T(0.);
+    o[0] = o[1] = T(0.);
     const int npx = c.g.nx + 1, npy = c.g.ny + 1;
     constexpr int NONE = -1000;
-    if (orect[0].has(i, j)) {
-      T ut;
-      const bool erow = (j == 0 || j == 1 || j == npy - 1 || j == npy);
-      if (erow && (i == 2 || i == npx - 1)) {          // corner system: the unknown vt(qi,qj) eliminated
+    if (orect[0].has(i, j)) {      // rows j in {0,1} or {npy-1,npy}
+      if (i == 2 || i == npx - 1) {          // corner system: the unknown vt(qi,qj) eliminated
         const int qi = (i == 2) ? 1 : npx - 1, qj = (j == 0) ? 0 : (j == 1) ? 2 : (j == npy - 1) ? npy - 1 : npy + 1;
         const double cu = MET(cosa_u, i, j), cv = MET(cosa_v, qi, qj);
-        ut = (IN(2, i, j) - 0.25 * cu * (vt4<T>(a, i, j, qi, qj) + IN(3, qi, qj) - 0.25 * cv * ut4<T>(a, qi, qj, i, j))) * (1. / (1. - 0.0625 * cu * cv));
-      } else if (erow && i >= 3 && i <= npx - 2) {
-        ut = IN(2, i, j) - 0.25 * MET(cosa_u, i, j) * vt4<T>(a, i, j, NONE, NONE);
-      } else ut = IN(0, i, j);
+        o[0] = (IN(2, i, j) - 0.25 * cu * (vt4<T>(a, i, j, qi, qj) + IN(3, qi, qj) - 0.25 * cv * ut4<T>(a, qi, qj, i, j))) * (1. / (1. - 0.0625 * cu * cv));
+      } else if (i >= 3 && i <= npx - 2) o[0] = IN(2, i, j) - 0.25 * MET(cosa_u, i, j) * vt4<T>(a, i, j, NONE, NONE);
+      else o[0] = IN(0, i, j);
+    }
+    if (orect[1].has(i, j)) {      // columns i in {0,1} or {npx-1,npx}
+      if (j == 2 || j == npy - 1) {
+        const int qj = (j == 2) ? 1 : npy - 1, qi = (i == 0) ? 0 : (i == 1) ? 2 : (i == npx - 1) ? npx - 1 : npx + 1;
+        const double cv = MET(cosa_v, i, j), cu = MET(cosa_u, qi, qj);
+        o[1] = (IN(3, i, j) - 0.25 * cv * (ut4<T>(a, i, j, qi, qj) + IN(2, qi, qj) - 0.25 * cu * vt4<T>(a, qi, qj, i, j))) * (1. / (1. - 0.0625 * cu * cv));
+      } else if (j >= 3 && j <= npy - 2) o[1] = IN(3, i, j) - 0.25 * MET(cosa_v, i, j) * ut4<T>(a, i, j, NONE, NONE);
+      else o[1] = IN(1, i, j);
+    }
+  }
+};
+// Pass C (pointwise): final winds = strip values where there are any, pass A elsewhere; Courant numbers and area
+// fluxes (:2932-2968).
+struct DswWindsC {
+  STAGE_COMMON("DswWindsC", 4, 6)   // in: ut_a vt_a ut_e vt_e   out: ut crx xfx vt cry yfx
+  double dt;
+  HD static constexpr Box box(int) { return Box{0, 0, 0, 0, 0, 0}; }
+  template <class T, class A>
+  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+    for (int n = 0; n < 6; ++n) o[n] = T(0.);
+    const int npx = c.g.nx + 1, npy = c.g.ny + 1;
+    if (orect[0].has(i, j)) {
+      T ut = (j == 0 || j == 1 || j == npy - 1 || j == npy) ? IN(2, i, j) : IN(0, i, j);
       o[0] = ut;
       if (orect[1].has(i, j)) winds_to_flux_x<T>(c, tile, i, j, dt, ut, o[1], o[2]);
     }
     if (orect[3].has(i, j)) {
-      T vt;
-      const bool ecol = (i == 0 || i == 1 || i == npx - 1 || i == npx);
-      if (ecol && (j == 2 || j == npy - 1)) {
-        const int qj = (j == 2) ? 1 : npy - 1, qi = (i == 0) ? 0 : (i == 1) ? 2 : (i == npx - 1) ? npx - 1 : npx + 1;
-        const double cv = MET(cosa_v, i, j), cu = MET(cosa_u, qi, qj);
-        vt = (IN(3, i, j) - 0.25 * cv * (ut4<T>(a, i, j, qi, qj) + IN(2, qi, qj) - 0.25 * cu * vt4<T>(a, qi, qj, i, j))) * (1. / (1. - 0.0625 * cu * cv));
-      } else if (ecol && j >= 3 && j <= npy - 2) {
-        vt = IN(3, i, j) - 0.25 * MET(cosa_v, i, j) * ut4<T>(a, i, j, NONE, NONE);
-      } else vt = IN(1, i, j);
+      T vt = (i == 0 || i == 1 || i == npx - 1 || i == npx) ? IN(3, i, j) : IN(1, i, j);
       o[3] = vt;
       if (orect[4].has(i, j)) winds_to_flux_y<T>(c, tile, i, j, dt, vt, o[4], o[5]);
     }
@@ -709,12 +722,13 @@ struct DdB {   // :7924-7937 (nord=0: delpc) / :7990-8006 (nord>0: new divg_d); 
   }
 };
 // a2b_ord4 (a2b_edge_tlm.F90:48-542): (A) the x- and y-interpolated edge-centred values qx, qy
-struct A2bA {
-  STAGE_BASE("A2bA", 1, 2)   // in: q   out: qx qy
+template <bool EDGE>
+struct A2bA_ {
+  STAGE_BASE(EDGE ? "A2bAe" : "A2bA", 1, 2)   // in: q   out: qx qy
   STAGE_NO_ALIAS
   HD static constexpr bool uses(int, int di, int dj, int) { return di == 0 || dj == 0; }
   HD static constexpr unsigned wants(int) { return 0x3u; }
-  HD static constexpr Box box(int) { return Box{-3, 2, -3, 2, 0, 0}; }
+  HD static constexpr Box box(int) { return EDGE ? Box{-3, 2, -3, 2, 0, 0} : Box{-2, 1, -2, 1, 0, 0}; }
   template <class T, class Q, class D>
   HD static T edge1(const Q& q, const D& d, int e, int s) {   // qx(1) / qx(npx): e = face cell at the edge, s = +1 (west) / -1 (east); :197-203
     const double g_in = d(e + s) / d(e), g_ou = d(e - 2 * s) / d(e - s);
@@ -734,15 +748,19 @@ struct A2bA {
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = T(0.);
-    const bool F = c.g.face;
+    constexpr bool F = EDGE;
     if (orect[0].has(i, j)) { LineX<A, 0> q{a, c.g, j, 0}; MetX d{c.m.dxa, c, tile, j}; o[0] = line<T>(F, i, c.g.nx + 1, q, d); }
     if (orect[1].has(i, j)) { LineY<A, 0> q{a, c.g, i, 0}; MetY d{c.m.dya, c, tile, i}; o[1] = line<T>(F, j, c.g.ny + 1, q, d); }
   }
 };
 // (B) corner values: 4-point average of qx/qy, the face-edge values and the 3-way extrapolated face corners
-struct A2bB {
-  STAGE_COMMON("A2bB", 3, 1)   // in: qx qy q   out: qout
-  HD static constexpr Box box(int M) { return M == 0 ? Box{0, 0, -3, 2, 0, 0} : M == 1 ? Box{-3, 2, 0, 0, 0, 0} : Box{-2, 1, -2, 1, 0, 0}; }
+template <bool EDGE>
+struct A2bB_ {
+  STAGE_COMMON(EDGE ? "A2bBe" : "A2bB", 3, 1)   // in: qx qy q   out: qout
+  HD static constexpr Box box(int M) {
+    return EDGE ? (M == 0 ? Box{0, 0, -3, 2, 0, 0} : M == 1 ? Box{-3, 2, 0, 0, 0, 0} : Box{-2, 1, -2, 1, 0, 0})
+                : (M == 0 ? Box{0, 0, -2, 1, 0, 0} : M == 1 ? Box{-2, 1, 0, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0});
+  }
   template <class T, class A>
   HD T edge_x(const A& a, const Ctx& c, int tile, int i, int j) const {   // qout(1|npx, j): :179-187, :211-219
     const int ii = i - 1;     // cells ii, ii+1 straddle the edge
@@ -761,21 +779,21 @@ struct A2bB {
   HD T qxx(const A& a, const Ctx& c, int tile, int i, int j) const {
     const int npy = c.g.ny + 1; const double c1 = 2. / 3., c2 = -(1. / 6.);
     auto s = [&](int jj) -> T { return A2 * (IN(0, i, jj - 2) + IN(0, i, jj + 1)) + A1 * (IN(0, i, jj - 1) + IN(0, i, jj)); };
-    if (c.g.face && j == 2) return c1 * (IN(0, i, 1) + IN(0, i, 2)) + c2 * (edge_y<T>(a, c, tile, i, 1) + s(3));
-    if (c.g.face && j == npy - 1) return c1 * (IN(0, i, npy - 2) + IN(0, i, npy - 1)) + c2 * (edge_y<T>(a, c, tile, i, npy) + s(npy - 2));
+    if (EDGE && j == 2) return c1 * (IN(0, i, 1) + IN(0, i, 2)) + c2 * (edge_y<T>(a, c, tile, i, 1) + s(3));
+    if (EDGE && j == npy - 1) return c1 * (IN(0, i, npy - 2) + IN(0, i, npy - 1)) + c2 * (edge_y<T>(a, c, tile, i, npy) + s(npy - 2));
     return s(j);
   }
   template <class T, class A>
   HD T qyy(const A& a, const Ctx& c, int tile, int i, int j) const {
     const int npx = c.g.nx + 1; const double c1 = 2. / 3., c2 = -(1. / 6.);
     auto s = [&](int ii) -> T { return A2 * (IN(1, ii - 2, j) + IN(1, ii + 1, j)) + A1 * (IN(1, ii - 1, j) + IN(1, ii, j)); };
-    if (c.g.face && i == 2) return c1 * (IN(1, 1, j) + IN(1, 2, j)) + c2 * (edge_x<T>(a, c, tile, 1, j) + s(3));
-    if (c.g.face && i == npx - 1) return c1 * (IN(1, npx - 2, j) + IN(1, npx - 1, j)) + c2 * (edge_x<T>(a, c, tile, npx, j) + s(npx - 2));
+    if (EDGE && i == 2) return c1 * (IN(1, 1, j) + IN(1, 2, j)) + c2 * (edge_x<T>(a, c, tile, 1, j) + s(3));
+    if (EDGE && i == npx - 1) return c1 * (IN(1, npx - 2, j) + IN(1, npx - 1, j)) + c2 * (edge_x<T>(a, c, tile, npx, j) + s(npx - 2));
     return s(i);
   }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    const bool F = c.g.face; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
+    constexpr bool F = EDGE; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
     if (F && (i == 1 || i == npx) && (j == 1 || j == npy)) {   // :101-139: mean of three extrapolations
       const int cn = (j == 1) ? (i == 1 ? 0 : 1) : (i == 1 ? 3 : 2);
       const double* ec = c.m.ecorner + ((size_t)tile * 4 + cn) * 3;
