@@ -56,6 +56,47 @@ def load_hip_library():
     return Fv3LmLibrary(LIB_PATH)
 
 
+TRANSPORT_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_dp), C.POINTER(C.c_long), C.POINTER(_dp), C.POINTER(C.c_long))
+
+
+def rccl_library_path():
+    """The RCCL this process already uses: torch's bundled copy if torch is imported, else the ROCm one."""
+    import sys
+    if "torch" in sys.modules:
+        p = os.path.join(os.path.dirname(sys.modules["torch"].__file__), "lib", "librccl.so")
+        if os.path.exists(p):
+            return p
+    return "/opt/rocm/lib/librccl.so"
+
+
+def comm_init_rccl(lib, rank, world, broadcast_bytes):
+    """One RCCL communicator over all ranks for the face exchange.  broadcast_bytes(buf: bytearray|None) -> bytes must hand
+    rank 0's 128-byte unique id to every rank (e.g. through torch.distributed)."""
+    path = rccl_library_path().encode()
+    uid = C.create_string_buffer(128)
+    if rank == 0:
+        lib.L.fv3lm_comm_unique_id.argtypes = [C.c_char_p, C.c_void_p]
+        if lib.L.fv3lm_comm_unique_id(path, uid) != 0:
+            raise Fv3LmError(lib.err())
+    data = broadcast_bytes(bytes(uid.raw) if rank == 0 else None)
+    lib.L.fv3lm_comm_init.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+    if lib.L.fv3lm_comm_init(path, data, world, rank) != 0:
+        raise Fv3LmError(lib.err())
+
+
+def set_transport_callback(lib, fn):
+    """fn(peers, sendbufs, recvbufs): lists of numpy views (host memory in the emulation build).  Test transports (gloo)."""
+    def tramp(user, npeers, peers, sb, sc, rb, rc):
+        P = [peers[i] for i in range(npeers)]
+        S = [np.ctypeslib.as_array(sb[i], shape=(sc[i],)) if sc[i] else np.zeros(0) for i in range(npeers)]
+        R = [np.ctypeslib.as_array(rb[i], shape=(rc[i],)) if rc[i] else np.zeros(0) for i in range(npeers)]
+        fn(P, S, R)
+    cb = TRANSPORT_FN(tramp)
+    lib._transport_cb = cb          # keep alive
+    lib.L.fv3lm_set_transport_callback.argtypes = [TRANSPORT_FN, C.c_void_p]
+    lib.L.fv3lm_set_transport_callback(cb, None)
+
+
 def _ptr(a):
     assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(_dp)
@@ -201,6 +242,20 @@ class Dycore:
         assert r.ndim == 2 and r.shape[1] == 7
         self.lib.L.fv3lm_set_exchange.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
         self._chk(self.lib.L.fv3lm_set_exchange(self.h, self.HALO_KINDS[kind], r.ctypes.data_as(C.POINTER(C.c_int)), r.shape[0]))
+
+    def set_exchange_split(self, kind, table, rank, world):
+        """Install one exchange kind for this rank's faces: local rows + per-peer send/receive lists (cube.split_table)."""
+        from . import cube
+        local, peers, send, recv = cube.split_table(table, rank, world)
+        self.set_exchange(kind, local)
+        ip = C.POINTER(C.c_int)
+        pe = np.array(peers, dtype=np.int32)
+        ns = np.array([send[p].shape[0] for p in peers], dtype=np.int32); nr = np.array([recv[p].shape[0] for p in peers], dtype=np.int32)
+        sr = np.ascontiguousarray(np.concatenate([send[p] for p in peers], axis=0) if peers else np.zeros((0, 3), np.int32))
+        rr = np.ascontiguousarray(np.concatenate([recv[p] for p in peers], axis=0) if peers else np.zeros((0, 4), np.int32))
+        self.lib.L.fv3lm_set_exchange_remote.argtypes = [C.c_void_p, C.c_int, C.c_int, ip, ip, ip, ip, ip]
+        P = lambda a: a.ctypes.data_as(ip)
+        self._chk(self.lib.L.fv3lm_set_exchange_remote(self.h, self.HALO_KINDS[kind], len(peers), P(pe), P(ns), P(sr), P(nr), P(rr)))
 
     def halo(self, kind, name0, name1="", mode=0):
         self.lib.L.fv3lm_halo.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int]

@@ -131,6 +131,7 @@ struct Dycore {
   size_t n3 = 0, n3p = 0;             // doubles per npz / npz+1 field
   std::string err;
   ExTable xt[H_NKIND];                // cube-face exchange tables (face mode), set by set_exchange
+  ExRemote xr[H_NKIND];               // ... and the part of each exchange that crosses ranks (set_exchange_remote)
   double *edge_dev = nullptr, *ecorner_dev = nullptr;
   bool last_acoustic = false;         // the acoustic step being run is the last of its dyn_core call
   bool halo_missing = false;          // an exchange was needed before its table was set
@@ -155,8 +156,10 @@ struct Dycore {
   // table-driven exchange (exchange.h).
   void halo(int mode, int kind, const Fld& f0, const Fld& f1 = Fld{}) {
     if (!g.face) { run_halo(ex, mode, g, f0); if (f1.t) run_halo(ex, mode, g, f1); return; }
-    if (xt[kind].n == 0) { halo_missing = true; return; }
+    if (xt[kind].n == 0 && !xr[kind].active) { halo_missing = true; return; }
+    // forward: local rows and remote rows write disjoint halo elements; adjoint: both add into the sources, one after the other
     run_exchange(ex, mode, g, xt[kind], f0, f1);
+    if (!run_exchange_remote(ex, mode, g, xr[kind], f0, f1, err)) halo_missing = true;
   }
   // when: 0 every acoustic step, 1 all but the last, 2 the last only (face mode; the periodic wrap does
   // both jobs at once and ignores it)
@@ -170,6 +173,7 @@ struct Dycore {
   }
   bool set_face_data(const double* edge, const double* ecorner);
   bool set_exchange(int kind, const int* rows, int n);
+  bool set_exchange_remote(int kind, int npeers, const int* peers, const int* nsend, const int* send_rows, const int* nrecv, const int* recv_rows);
   void add_accum(Program& P, const char* group, Fld acc, Fld x, Rect r) {
     Geom gg = g;
     P.push_back(Op{group, [acc, x, r, gg](Exec& e, int mode) { run_accum(e, mode, gg, acc, x, r); }, true});
@@ -324,10 +328,47 @@ inline bool Dycore::set_exchange(int kind, const int* rows, int n) {
   return true;
 }
 
+inline bool Dycore::set_exchange_remote(int kind, int npeers, const int* peers, const int* nsend, const int* send_rows, const int* nrecv,
+                                        const int* recv_rows) {
+  if (!g.face) { err = "set_exchange_remote: handle was not created with face = 1"; return false; }
+  if (kind < 0 || kind >= H_NKIND || npeers < 0) { err = "set_exchange_remote: bad kind"; return false; }
+  ExRemote& x = xr[kind];
+  dev_free(x.send_rows); dev_free(x.recv_rows); dev_free(x.asrc); dev_free(x.aptr); dev_free(x.apos); dev_free(x.sendbuf); dev_free(x.recvbuf);
+  x = ExRemote{};
+  for (int p = 0; p < npeers; ++p) {
+    x.peer.push_back(peers[p]); x.nsend.push_back(nsend[p]); x.nrecv.push_back(nrecv[p]);
+    x.soff.push_back(x.nsend_tot); x.roff.push_back(x.nrecv_tot);
+    x.nsend_tot += nsend[p]; x.nrecv_tot += nrecv[p];
+  }
+  for (int r = 0; r < x.nsend_tot; ++r) { const int* w = send_rows + 3 * (size_t)r; if ((w[0] | 1) != 1 || w[1] < 0 || w[1] >= g.ntile || w[2] < 0 || w[2] >= g.plane) { err = "send row out of range"; return false; } }
+  for (int r = 0; r < x.nrecv_tot; ++r) { const int* w = recv_rows + 4 * (size_t)r; if ((w[0] | 1) != 1 || w[1] < 0 || w[1] >= g.ntile || w[2] < 0 || w[2] >= g.plane || (w[3] != 1 && w[3] != -1)) { err = "recv row out of range"; return false; } }
+  // adjoint grouping: send rows by source element
+  std::vector<int> order(x.nsend_tot);
+  for (int r = 0; r < x.nsend_tot; ++r) order[r] = r;
+  auto key = [&](int r) { const int* w = send_rows + 3 * (size_t)r; return ((long long)w[0] << 48) | ((long long)w[1] << 32) | (long long)w[2]; };
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key(a) < key(b); });
+  std::vector<int> asrc, aptr, apos; long long last = -1;
+  for (int m = 0; m < x.nsend_tot; ++m) {
+    const int r = order[m]; const int* w = send_rows + 3 * (size_t)r;
+    if (key(r) != last) { last = key(r); aptr.push_back(m); asrc.push_back(w[0]); asrc.push_back(w[1]); asrc.push_back(w[2]); }
+    apos.push_back(r);
+  }
+  aptr.push_back(x.nsend_tot);
+  x.ns = (int)aptr.size() - 1;
+  auto up = [&](const int* h, size_t n) { int* d = (int*)dev_alloc(n * 4 + 4); if (n) h2d(ex, d, h, n * 4); return d; };
+  x.send_rows = up(send_rows, (size_t)x.nsend_tot * 3); x.recv_rows = up(recv_rows, (size_t)x.nrecv_tot * 4);
+  x.asrc = up(asrc.data(), asrc.size()); x.aptr = up(aptr.data(), aptr.size()); x.apos = up(apos.data(), apos.size());
+  x.cap = (size_t)std::max(x.nsend_tot, x.nrecv_tot) * (g.npz + 1) * 2;
+  x.sendbuf = (double*)dev_alloc(x.cap * 8); x.recvbuf = (double*)dev_alloc(x.cap * 8);
+  x.active = npeers > 0;
+  return true;
+}
+
 inline void Dycore::destroy() {
   for (double* p : metric_dev) dev_free(p);
   dev_free(lev_dev); dev_free(hs_dev); dev_free(ckpt); dev_free(edge_dev); dev_free(ecorner_dev);
   for (ExTable& t : xt) { dev_free(t.rows); dev_free(t.src); dev_free(t.ptr); dev_free(t.dst); }
+  for (ExRemote& x : xr) { dev_free(x.send_rows); dev_free(x.recv_rows); dev_free(x.asrc); dev_free(x.aptr); dev_free(x.apos); dev_free(x.sendbuf); dev_free(x.recvbuf); }
   state.destroy(); work.destroy();
 #ifndef FV3LM_HOST_EMUL
   if (ex.stream) (void)hipStreamDestroy(ex.stream);

@@ -76,6 +76,45 @@ int fv3lm_set_exchange(fv3lm_handle* h, int kind, const int* rows, int nrows) {
   if (!rows && nrows > 0) return fail("fv3lm_set_exchange: null table");
   return h->d.set_exchange(kind, rows, nrows) ? 0 : fail(h->d.err);
 }
+int fv3lm_set_exchange_remote(fv3lm_handle* h, int kind, int npeers, const int* peers, const int* nsend, const int* send_rows, const int* nrecv,
+                              const int* recv_rows) {
+  return h->d.set_exchange_remote(kind, npeers, peers, nsend, send_rows, nrecv, recv_rows) ? 0 : fail(h->d.err);
+}
+// Transport between ranks.  Product: RCCL point-to-point on the library stream (library path = the RCCL the process already
+// uses, e.g. torch's; the 128-byte unique id comes from rank 0 and is distributed by the host).  Callback: host-emulation tests.
+int fv3lm_comm_unique_id(const char* rccl_path, void* id128) {
+#ifndef FV3LM_HOST_EMUL
+  std::string e; Transport& T = transport();
+  if (!T.load(rccl_path, e)) return fail(e);
+  ncclUniqueId id;
+  if (T.pGetUniqueId(&id) != ncclSuccess) return fail("ncclGetUniqueId failed");
+  std::memcpy(id128, &id, sizeof id);
+  return 0;
+#else
+  (void)rccl_path; (void)id128; return fail("host emulation has no RCCL; use fv3lm_set_transport_callback");
+#endif
+}
+int fv3lm_comm_init(const char* rccl_path, const void* id128, int nranks, int rank) {
+#ifndef FV3LM_HOST_EMUL
+  std::string e; Transport& T = transport();
+  if (!T.load(rccl_path, e)) return fail(e);
+  ncclUniqueId id; std::memcpy(&id, id128, sizeof id);
+  if (T.pCommInitRank(&T.comm, nranks, id, rank) != ncclSuccess) return fail("ncclCommInitRank failed");
+  T.rank = rank; T.nranks = nranks;
+  return 0;
+#else
+  (void)rccl_path; (void)id128; (void)nranks; (void)rank; return fail("host emulation has no RCCL; use fv3lm_set_transport_callback");
+#endif
+}
+int fv3lm_comm_destroy(void) {
+#ifndef FV3LM_HOST_EMUL
+  Transport& T = transport();
+  if (T.comm && T.pCommDestroy) T.pCommDestroy(T.comm);
+  T.comm = nullptr;
+#endif
+  return 0;
+}
+int fv3lm_set_transport_callback(fv3lm_transport_fn fn, void* user) { transport().cb = fn; transport().user = user; return 0; }
 int fv3lm_halo(fv3lm_handle* h, int kind, const char* name0, const char* name1, int mode) {
   if (mode < 0 || mode > 2 || kind < 0 || kind >= H_NKIND) return fail("bad mode or kind");
   Fld f0, f1{};

@@ -394,3 +394,43 @@ def cube_fields(n, npz, geo, seed, kind="traj", opt=None):
         Vk = vector(1.0)
         out["u"][:, k] = np.einsum("...i,...i", Vk(mid_y), tan_y); out["v"][:, k] = np.einsum("...i,...i", Vk(mid_x), tan_x)
     return out
+
+
+# --------------------------------------------------------------------------------- faces over ranks
+def faces_of(rank, world):
+    """Faces (0-based) owned by `rank` when the six faces are dealt over `world` ranks in contiguous blocks
+    (6/3/2+1 faces per GPU at 1/2/4 GPUs, one each at 6, ranks >= 6 idle: SURVEY.md §8e)."""
+    if world >= 6:
+        return [rank] if rank < 6 else []
+    base, extra = divmod(6, world)
+    start = rank * base + min(rank, extra)
+    return list(range(start, start + base + (1 if rank < extra else 0)))
+
+
+def face_owner(world):
+    own = {}
+    for r in range(world):
+        for f in faces_of(r, world):
+            own[f] = r
+    return own
+
+
+def split_table(tab, rank, world):
+    """One exchange table of the whole cube -> what `rank` needs: (local rows [n,7] with local tile numbers,
+    peers, {peer: send rows [m,3] = field, local tile, index}, {peer: recv rows [m,4] = field, local tile, index, sign}).
+    Both ends walk the global table in the same order, so message layouts agree without negotiation."""
+    own = face_owner(world)
+    mine = faces_of(rank, world)
+    loc = {f: n for n, f in enumerate(mine)}
+    local, send, recv = [], {}, {}
+    for r in tab:
+        do, so = own[int(r[1])], own[int(r[4])]
+        if do == rank and so == rank:
+            local.append((r[0], loc[int(r[1])], r[2], r[3], loc[int(r[4])], r[5], r[6]))
+        elif do == rank:
+            recv.setdefault(so, []).append((r[0], loc[int(r[1])], r[2], r[6]))
+        elif so == rank:
+            send.setdefault(do, []).append((r[3], loc[int(r[4])], r[5]))
+    peers = sorted(set(send) | set(recv))
+    A = lambda l, w: np.array(l, dtype=np.int32).reshape(-1, w)
+    return A(local, 7), peers, {p: A(send.get(p, []), 3) for p in peers}, {p: A(recv.get(p, []), 4) for p in peers}

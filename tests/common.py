@@ -97,7 +97,10 @@ class CubeCase:
     """All six faces of a C<n> cube resident in one product instance (ntile = 6, face mode), exchange tables from
     cube.py, smooth global fields as state.  oracle=True adds the six-face oracle (tests/oracle.py CubeOracle)."""
 
-    def __init__(self, n=12, npz=6, n_split=2, k_split=1, dt=1800.0, backend="emul", seed=20250114, nq=0, oracle=False, **optkw):
+    def __init__(self, n=12, npz=6, n_split=2, k_split=1, dt=1800.0, backend="emul", seed=20250114, nq=0, oracle=False, rank=0, world=1,
+                 **optkw):
+        """rank/world: this process holds only cube.faces_of(rank, world) (one process per GPU); state and metrics are the
+        corresponding slices of the same global fields, so results can be compared with a single-process run."""
         from fv3_jedi_linearmodel_amd import cube
         self.n = self.nx = self.ny = n
         self.npz, self.nq = npz, nq
@@ -110,7 +113,14 @@ class CubeCase:
         aux = cube.cube_fields(n, npz, self.geo, seed + 11, "pert") if nq else None
         self.qtraj = [1e-3 * (m + 1) + 1e-2 * np.abs(aux["pt"] if m % 2 == 0 else 2e-3 * aux["delp"]) * (1.0 + 0.25 * m) for m in range(nq)]
         self.qpert = [1e-4 * (aux["delp"] if m % 2 == 0 else 500.0 * aux["pt"]) * (1.0 + 0.5 * m) for m in range(nq)]
-        self.dims = fv3.Dims(nx=n, ny=n, npz=npz, ntile=6, nq=nq, n_split=n_split, k_split=k_split, face=1, dt=dt)
+        self.faces = cube.faces_of(rank, world)
+        if world > 1:
+            F = self.faces
+            self.metrics = {k: np.ascontiguousarray(v[F]) for k, v in self.metrics.items()}
+            self.edge, self.ecorner, self.phis = np.ascontiguousarray(self.edge[F]), np.ascontiguousarray(self.ecorner[F]), np.ascontiguousarray(self.phis[F])
+            self.traj = {k: np.ascontiguousarray(v[F]) for k, v in self.traj.items()}; self.pert = {k: np.ascontiguousarray(v[F]) for k, v in self.pert.items()}
+            self.qtraj = [np.ascontiguousarray(v[F]) for v in self.qtraj]; self.qpert = [np.ascontiguousarray(v[F]) for v in self.qpert]
+        self.dims = fv3.Dims(nx=n, ny=n, npz=npz, ntile=len(self.faces), nq=nq, n_split=n_split, k_split=k_split, face=1, dt=dt)
         self.dt_ac = dt / n_split / k_split
         self.face = "cube"
         self.oracle = None
@@ -129,7 +139,10 @@ class CubeCase:
         self.dy = Dycore(self.lib, self.dims, self.opt, self.metrics, self.da_min, self.da_min_c, self.phis, self.ak, self.bk)
         self.dy.set_face_data(self.edge, self.ecorner)
         for k, t in self.tables.items():
-            self.dy.set_exchange(k, t)
+            if world > 1:
+                self.dy.set_exchange_split(k, t, rank, world)
+            else:
+                self.dy.set_exchange(k, t)
 
     def put_state(self, traj=None, pert=None):
         traj = traj or self.traj
