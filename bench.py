@@ -90,32 +90,48 @@ def main():
     lib = fv3.load_hip_library()
     lib.L.fv3lm_set_device(C.c_int(local))
     cube_mode = args.tiles == "cube"
-    if cube_mode and world > 1:
-        raise SystemExit("bench.py: --tiles cube shards the six faces over ranks through the RCCL exchange, which is not built yet; "
-                         "use --tiles periodic for N > 1")
+    active = True
     if cube_mode:
-        c = CubeCase(n=args.nx, npz=args.npz, n_split=args.n_split, k_split=args.k_split, dt=args.dt, backend="hip", nq=args.nq)
-        T, P = cube_step_state(c)
+        from fv3_jedi_linearmodel_amd import cube
+        from fv3_jedi_linearmodel_amd._lib import comm_init_rccl
+        if world > 1:      # one RCCL communicator for the face exchange; rank 0's unique id travels through torch.distributed
+            def bcast(data):
+                t = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    t.copy_(torch.tensor(list(data), dtype=torch.uint8))
+                dist.broadcast(t, src=0)
+                return bytes(t.cpu().tolist())
+            comm_init_rccl(lib, rank, world, bcast)
+        active = len(cube.faces_of(rank, world)) > 0     # ranks beyond the sixth have no face
+        if active:
+            c = CubeCase(n=args.nx, npz=args.npz, n_split=args.n_split, k_split=args.k_split, dt=args.dt, backend="hip", nq=args.nq,
+                         rank=rank, world=world)
+            T, P = cube_step_state(c)
     else:
         c = Case(nx=args.nx, ny=args.nx, npz=args.npz, n_split=args.n_split, k_split=args.k_split, dt=args.dt, backend="hip",
                  oracle=False, nq=args.nq, seed=20250114 + rank)
         T, P = step_state(c)
         T = {k: v[None] for k, v in T.items()}; P = {k: v[None] for k, v in P.items()}
-    names = ["u", "v", "pt", "delp"] + ["q%d" % (n + 1) for n in range(c.nq)]
-    for n in names:
-        c.dy.put(n, T[n], 0); c.dy.put(n, P[n], 1)
-    c.dy.state_save()
+    if active:
+        names = ["u", "v", "pt", "delp"] + ["q%d" % (n + 1) for n in range(c.nq)]
+        for n in names:
+            c.dy.put(n, T[n], 0); c.dy.put(n, P[n], 1)
+        c.dy.state_save()
 
     def one_step():
+        if not active:
+            return
         c.dy.state_restore(); c.dy.step_tl()
         c.dy.state_restore(); c.dy.step_nl(); c.dy.step_ad()
 
     def barrier():
-        c.dy.sync()
+        if active:
+            c.dy.sync()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        c.dy.sync()
+        if active:
+            c.dy.sync()
 
     for _ in range(args.warmup):
         one_step()
@@ -130,13 +146,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
-    cols_rank = args.nx * args.nx * (6 if cube_mode else 1)
-    value = world * cols_rank / (elapsed / args.steps)
+    if cube_mode:      # the cube is fixed: strong scaling, faces dealt over ranks
+        cols_rank = args.nx * args.nx * len(cube.faces_of(0, world))
+        value = 6 * args.nx * args.nx / (elapsed / args.steps)
+    else:
+        cols_rank = args.nx * args.nx
+        value = world * cols_rank / (elapsed / args.steps)
 
     # roofline leg: per-kernel HIP-event durations on the library's stream over one more step
-    c.dy.profile_begin()
-    one_step()
-    prof = c.dy.profile_end()
+    if active:
+        c.dy.profile_begin()
+        one_step()
+        prof = c.dy.profile_end()
     if rank == 0:
         dom = max(prof.items(), key=lambda kv: kv[1][1])
         cnt, ms, by = dom[1]
@@ -147,10 +168,12 @@ def main():
         out = {
             "metric": "column-updates/s per TL+AD dyn step", "value": value, "unit": "column-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if cube_mode else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C%dL%d hydrostatic TL+AD, %s (%d columns per GPU), "
                                    "k_split=%d n_split=%d dt=%gs nq=%d, hord=2 (1 in the sponge), kord=17, nord=1"
-                                   % (args.nx, args.npz, "six cube faces resident on one GPU, table-driven face exchange" if cube_mode
+                                   % (args.nx, args.npz, ("six cube faces dealt over %d GPU(s) (%s faces per rank), table-driven face exchange%s"
+                                                           % (world, "/".join(str(len(cube.faces_of(r, world))) for r in range(world)),
+                                                              ", RCCL point-to-point between ranks" if world > 1 else "")) if cube_mode
                                       else "1 doubly-periodic tile per GPU", cols_rank, args.k_split, args.n_split, args.dt, args.nq),
                        "columns_per_gpu": cols_rank, "launches_per_step": sum(v[0] for v in prof.values())},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -189,3 +189,12 @@ def test_cube_step_dot_product_c48l72():
     c = CubeCase(n=48, npz=72, n_split=6, k_split=2, dt=900.0, backend="hip", nq=2)
     lhs, rhs = cube_dot_product_step(c)
     assert abs(lhs - rhs) <= 1e-11 * abs(lhs), (lhs, rhs)
+
+
+def test_rccl_single_rank_comm():
+    """The RCCL binding used for faces on other GPUs (dlopen of the process's RCCL, unique id, communicator): one rank."""
+    import fv3_jedi_linearmodel_amd as fv3
+    from fv3_jedi_linearmodel_amd._lib import comm_init_rccl
+    lib = fv3.load_hip_library()
+    comm_init_rccl(lib, 0, 1, lambda data: data)
+    assert lib.L.fv3lm_comm_destroy() == 0
