@@ -227,23 +227,32 @@ inline double stage_bytes(const S& s, const Ctx& c, const Rect& R, int mode) {
 // ---- HIP kernels ---------------------------------------------------------------------------
 constexpr int BX = 64, BY = 4;
 // tr: narrow column strips (face-edge stages) run with the 64 lanes of a wave along j instead of i
+// XCD-aware block order.  Workgroups go to the 8 XCDs round-robin by linear id, so with the plain (x, y) order the
+// blocks above and below a block — which re-read 2/3 of its stencil rows — sit on other XCDs and their private L2s
+// never see the reuse (rocprofv3 FETCH_SIZE showed 1.6-1.9x the compulsory reads for the y-stencil kernels).  Here
+// the blocks of one residue class mod 8 (one XCD within a plane) take a contiguous band of rows instead.
+HD void xcd_block(int gx, int gy, int& bx, int& by) {
+  const int n = gx * gy, l = bx + gx * by, q = n / 8, r = n % 8, res = l % 8;
+  const int logical = (res < r ? res * (q + 1) : r * (q + 1) + (res - r) * q) + l / 8;
+  bx = logical % gx; by = logical / gx;
+}
 HD void thread_point(const Rect& R, int tr, int bx, int by, int tx, int ty, int& i, int& j) {
   if (tr) { j = R.j0 + bx * BX + tx; i = R.i0 + by * BY + ty; }
   else { i = R.i0 + bx * BX + tx; j = R.j0 + by * BY + ty; }
 }
 template <class S>
 __global__ void __launch_bounds__(BX* BY) k_stage_nl(S s, Ctx c, Rect R, int tr) {
-  int i, j; thread_point(R, tr, blockIdx.x, blockIdx.y, threadIdx.x, threadIdx.y, i, j);
+  int i, j, bx = blockIdx.x, by = blockIdx.y; xcd_block(gridDim.x, gridDim.y, bx, by); thread_point(R, tr, bx, by, threadIdx.x, threadIdx.y, i, j);
   if (i <= R.i1 && j <= R.j1) body_nl(s, c, i, j, blockIdx.z);
 }
 template <class S>
 __global__ void __launch_bounds__(BX* BY) k_stage_tl(S s, Ctx c, Rect R, int tr) {
-  int i, j; thread_point(R, tr, blockIdx.x, blockIdx.y, threadIdx.x, threadIdx.y, i, j);
+  int i, j, bx = blockIdx.x, by = blockIdx.y; xcd_block(gridDim.x, gridDim.y, bx, by); thread_point(R, tr, bx, by, threadIdx.x, threadIdx.y, i, j);
   if (i <= R.i1 && j <= R.j1) body_tl(s, c, i, j, blockIdx.z);
 }
 template <class S>
 __global__ void __launch_bounds__(BX* BY) k_stage_ad(S s, Ctx c, Rect R, Rect Q, int nkmax, int tr) {
-  int i, j; thread_point(Q, tr, blockIdx.x, blockIdx.y, threadIdx.x, threadIdx.y, i, j);
+  int i, j, bx = blockIdx.x, by = blockIdx.y; xcd_block(gridDim.x, gridDim.y, bx, by); thread_point(Q, tr, bx, by, threadIdx.x, threadIdx.y, i, j);
   if (i <= Q.i1 && j <= Q.j1) AdLoop<S, 0>::run(s, c, R, i, j, blockIdx.z, nkmax);
 }
 template <class S>
