@@ -185,20 +185,34 @@ struct Dycore {
     const int is = 1, ie = g.nx, js = 1, je = g.ny, isd = g.isd(), ied = g.ied(), jsd = g.jsd(), jed = g.jed(), npz = g.npz;
     Fld fy2 = W((pre + "_fy2").c_str(), npz), q_i = W((pre + "_qi").c_str(), npz), fxo = W((pre + "_fxo").c_str(), npz);
     Fld fx2 = W((pre + "_fx2").c_str(), npz), q_j = W((pre + "_qj").c_str(), npz), fyo = W((pre + "_fyo").c_str(), npz);
-    TpPpmY a; a.in[0] = q; a.in[1] = cry; a.out[0] = fy2; a.orect[0] = R(isd, ied, js, je + 1); a.k1 = npz; a.hsel = hsel;
-    a.cdir = g.face ? 2 : 0;
-    add(P, grp, a);
+    // the four 1-D PPM sweeps; on a face each is a bulk launch (4-point edge values everywhere) plus two strips three flux
+    // points wide next to the face edges (one-sided edge values, corner views of the inner sweeps)
+    auto ppm_y = [&](Fld qq, Fld out, Rect r, int cdir) {
+      TpPpmY_<false> a; a.in[0] = qq; a.in[1] = cry; a.out[0] = out; a.k1 = npz; a.hsel = hsel;
+      if (!g.face) { a.orect[0] = r; add(P, grp, a); return; }
+      const int npy = g.ny + 1;
+      a.orect[0] = R(r.i0, r.i1, 4, npy - 3); add(P, grp, a);
+      TpPpmY_<true> e; e.in[0] = qq; e.in[1] = cry; e.out[0] = out; e.k1 = npz; e.hsel = hsel; e.cdir = cdir;
+      e.orect[0] = R(r.i0, r.i1, r.j0, 3); add(P, grp, e);
+      e.orect[0] = R(r.i0, r.i1, npy - 2, r.j1); add(P, grp, e);
+    };
+    auto ppm_x = [&](Fld qq, Fld out, Rect r, int cdir) {
+      TpPpmX_<false> a; a.in[0] = qq; a.in[1] = crx; a.out[0] = out; a.k1 = npz; a.hsel = hsel;
+      if (!g.face) { a.orect[0] = r; add(P, grp, a); return; }
+      const int npx = g.nx + 1;
+      a.orect[0] = R(4, npx - 3, r.j0, r.j1); add(P, grp, a);
+      TpPpmX_<true> e; e.in[0] = qq; e.in[1] = crx; e.out[0] = out; e.k1 = npz; e.hsel = hsel; e.cdir = cdir;
+      e.orect[0] = R(r.i0, 3, r.j0, r.j1); add(P, grp, e);
+      e.orect[0] = R(npx - 2, r.i1, r.j0, r.j1); add(P, grp, e);
+    };
+    ppm_y(q, fy2, R(isd, ied, js, je + 1), 2);
     TpQi b; b.in[0] = q; b.in[1] = fy2; b.in[2] = yfx; b.in[3] = ray; b.out[0] = q_i; b.orect[0] = R(isd, ied, js, je); b.k1 = npz;
     add(P, grp, b);
-    TpPpmX c_; c_.in[0] = q_i; c_.in[1] = crx; c_.out[0] = fxo; c_.orect[0] = R(is, ie + 1, js, je); c_.k1 = npz; c_.hsel = hsel;
-    add(P, grp, c_);
-    TpPpmX d; d.in[0] = q; d.in[1] = crx; d.out[0] = fx2; d.orect[0] = R(is, ie + 1, jsd, jed); d.k1 = npz; d.hsel = hsel;
-    d.cdir = g.face ? 1 : 0;
-    add(P, grp, d);
+    ppm_x(q_i, fxo, R(is, ie + 1, js, je), 0);
+    ppm_x(q, fx2, R(is, ie + 1, jsd, jed), 1);
     TpQj e; e.in[0] = q; e.in[1] = fx2; e.in[2] = xfx; e.in[3] = rax; e.out[0] = q_j; e.orect[0] = R(is, ie, jsd, jed); e.k1 = npz;
     add(P, grp, e);
-    TpPpmY f_; f_.in[0] = q_j; f_.in[1] = cry; f_.out[0] = fyo; f_.orect[0] = R(is, ie, js, je + 1); f_.k1 = npz; f_.hsel = hsel;
-    add(P, grp, f_);
+    ppm_y(q_j, fyo, R(is, ie, js, je + 1), 0);
     Fld d2b{};
     if (dsel != DAMP_NONE) {
       d2b = W((pre + "_d2b").c_str(), npz);

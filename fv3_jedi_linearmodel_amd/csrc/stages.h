@@ -475,34 +475,38 @@ struct LineY { const A& a; const Geom& g; int i, cdir; HD auto operator()(int j)
 struct MetX { const double* p; const Ctx& c; int tile, j; HD double operator()(int i) const { return p[c.mi(tile, i, j)]; } };
 struct MetY { const double* p; const Ctx& c; int tile, i; HD double operator()(int j) const { return p[c.mi(tile, i, j)]; } };
 
-struct TpPpmX {
-  STAGE_BASE("TpPpmX", 2, 1)   // in: q crx   out: flux
+// EDGE = false: no face edge within reach of the outputs (standard 4-point edge values, no corner views) — the bulk
+// launch; EDGE = true: the strips next to the face edges (and the single-tile periodic case never uses it).
+template <bool EDGE>
+struct TpPpmX_ {
+  STAGE_BASE(EDGE ? "TpPpmXe" : "TpPpmX", 2, 1)   // in: q crx   out: flux
   STAGE_DEFAULTS_ON
   int hsel; int cdir = 0;        // cdir = 1: the inner sweep, which covers the halo rows (copy_corners(q,1), :162-171)
   HD static constexpr Box box(int M) { return M == 0 ? Box{-3, 2, 0, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
-  static constexpr int NALIAS = 1;
+  static constexpr int NALIAS = EDGE ? 1 : 0;
   HD static constexpr int alias_box(int M) { return M; }
-  HD bool alias(const Ctx& c, int M, int i, int j, int, int& ai, int& aj) const { return M == 0 && cdir && corner_alias(c.g, cdir, i, j, ai, aj); }
+  HD bool alias(const Ctx& c, int M, int i, int j, int, int& ai, int& aj) const { return EDGE && M == 0 && cdir && corner_alias(c.g, cdir, i, j, ai, aj); }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    LineX<A, 0> q{a, c.g, j, cdir};
+    LineX<A, 0> q{a, c.g, j, EDGE ? cdir : 0};
     MetX da{c.m.dxa, c, tile, j};
-    o[0] = ppm_flux<T>(hord_of(c.lev[k - 1], hsel), c.g.face != 0, i, c.g.nx + 1, q, da, IN(1, i, j));
+    o[0] = ppm_flux<T>(hord_of(c.lev[k - 1], hsel), EDGE, i, c.g.nx + 1, q, da, IN(1, i, j));
   }
 };
-struct TpPpmY {
-  STAGE_BASE("TpPpmY", 2, 1)   // in: q cry   out: flux
+template <bool EDGE>
+struct TpPpmY_ {
+  STAGE_BASE(EDGE ? "TpPpmYe" : "TpPpmY", 2, 1)   // in: q cry   out: flux
   STAGE_DEFAULTS_ON
   int hsel; int cdir = 0;        // cdir = 2: the inner sweep, which covers the halo columns (copy_corners(q,2), :138-147)
   HD static constexpr Box box(int M) { return M == 0 ? Box{0, 0, -3, 2, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
-  static constexpr int NALIAS = 1;
+  static constexpr int NALIAS = EDGE ? 1 : 0;
   HD static constexpr int alias_box(int M) { return M; }
-  HD bool alias(const Ctx& c, int M, int i, int j, int, int& ai, int& aj) const { return M == 0 && cdir && corner_alias(c.g, cdir, i, j, ai, aj); }
+  HD bool alias(const Ctx& c, int M, int i, int j, int, int& ai, int& aj) const { return EDGE && M == 0 && cdir && corner_alias(c.g, cdir, i, j, ai, aj); }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    LineY<A, 0> q{a, c.g, i, cdir};
+    LineY<A, 0> q{a, c.g, i, EDGE ? cdir : 0};
     MetY da{c.m.dya, c, tile, i};
-    o[0] = ppm_flux<T>(hord_of(c.lev[k - 1], hsel), c.g.face != 0, j, c.g.ny + 1, q, da, IN(1, i, j));
+    o[0] = ppm_flux<T>(hord_of(c.lev[k - 1], hsel), EDGE, j, c.g.ny + 1, q, da, IN(1, i, j));
   }
 };
 struct TpQi {   // tp_core_tlm.F90:149-159
