@@ -34,6 +34,25 @@ def algorithmic_bytes(cells, k_split, n_split, nq):
     return 2.75 * b_tl
 
 
+def pmc_traffic(kernel, args, cube_mode, world):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same workload (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs, gfx950 correction 2*FETCH+WRITE; tools/rocprof_summary.py), or None."""
+    if not (cube_mode and world == 1 and args.nx == 192 and args.npz == 127 and args.nq == 4 and args.k_split == 2 and args.n_split == 6):
+        return None, None
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for f in sorted(os.listdir(pdir)):
+        if f.endswith("_pmc_traffic.csv") and "cube_c192l127" in f:
+            best = os.path.join(pdir, f)
+    if best is None:
+        return None, None
+    for line in open(best):
+        w = line.strip().split(",")
+        if w[0] == kernel:
+            return float(w[4]), os.path.relpath(best, ROOT)
+    return None, None
+
+
 def cpu_baseline(args, opt):
     """Oracle port (oracle/liboracle.so, one host core) on a bounded sample of the same workload:
     a 10x10-column tile with the same npz / k_split / n_split / nq."""
@@ -165,6 +184,7 @@ def main():
         cells = cols_rank * args.npz
         b_step = algorithmic_bytes(cells, args.k_split, args.n_split, args.nq)
         contract_gbps = b_step / (ms_per_step * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(dom[0], args, cube_mode, world)
         out = {
             "metric": "column-updates/s per TL+AD dyn step", "value": value, "unit": "column-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -177,7 +197,7 @@ def main():
                                       else "1 doubly-periodic tile per GPU", cols_rank, args.k_split, args.n_split, args.dt, args.nq),
                        "columns_per_gpu": cols_rank, "launches_per_step": sum(v[0] for v in prof.values())},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "launches_per_step": cnt, "avg_launch_ms": ms / cnt, "algorithmic_bytes_per_launch": by / cnt,
                          "share_of_step_time": ms / sum(v[1] for v in prof.values())},
             "contract": {"algorithmic_bytes_per_step": b_step, "achieved_GBps": contract_gbps, "frac": contract_gbps / HBM_PEAK_GBPS,

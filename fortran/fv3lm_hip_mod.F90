@@ -38,7 +38,8 @@ module fv3lm_hip_mod
   end type fv3lm_options
 
   type, bind(C) :: fv3lm_dims
-    integer(c_int) :: nx, ny, npz, ntile, nq, n_split, k_split, pad_
+    integer(c_int) :: nx, ny, npz, ntile, nq, n_split, k_split
+    integer(c_int) :: face   ! 1: every resident tile is a whole cube face (edge/corner branches on); 0: one edge-free periodic tile
     real(c_double) :: dt
   end type fv3lm_dims
 
@@ -56,6 +57,39 @@ module fv3lm_hip_mod
       type(c_ptr), intent(in) :: metrics(*)
       real(c_double), value :: da_min, da_min_c
       real(c_double), intent(in) :: phis(*), ak(*), bk(*)
+      integer(c_int) :: rc
+    end function
+    function c_set_face_data(h, edge, ecorner) bind(C, name="fv3lm_set_face_data") result(rc)
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: edge(*), ecorner(*)
+      integer(c_int) :: rc
+    end function
+    function c_set_exchange(h, kind, rows, nrows) bind(C, name="fv3lm_set_exchange") result(rc)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+      integer(c_int), value :: kind, nrows
+      integer(c_int), intent(in) :: rows(*)
+      integer(c_int) :: rc
+    end function
+    function c_set_exchange_remote(h, kind, npeers, peers, nsend, send_rows, nrecv, recv_rows) &
+        bind(C, name="fv3lm_set_exchange_remote") result(rc)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+      integer(c_int), value :: kind, npeers
+      integer(c_int), intent(in) :: peers(*), nsend(*), send_rows(*), nrecv(*), recv_rows(*)
+      integer(c_int) :: rc
+    end function
+    function c_comm_init(rccl_path, id128, nranks, rank) bind(C, name="fv3lm_comm_init") result(rc)
+      import :: c_char, c_int
+      character(kind=c_char), intent(in) :: rccl_path(*), id128(*)
+      integer(c_int), value :: nranks, rank
+      integer(c_int) :: rc
+    end function
+    function c_comm_unique_id(rccl_path, id128) bind(C, name="fv3lm_comm_unique_id") result(rc)
+      import :: c_char, c_int
+      character(kind=c_char), intent(in) :: rccl_path(*)
+      character(kind=c_char), intent(out) :: id128(*)
       integer(c_int) :: rc
     end function
     function c_destroy(h) bind(C, name="fv3lm_destroy") result(rc)
@@ -129,6 +163,43 @@ contains
     call check(c_create(self%handle, dims, opt, metrics, da_min, da_min_c, phis, ak, bk), 'create')
     self%nx = dims%nx; self%ny = dims%ny; self%npz = dims%npz
   end subroutine fv3lm_hip_create
+
+  !> Face mode: a2b_ord4 edge weights gridstruct%edge_w/e/s/n as (pj, 4, ntile) and the extrap_corner factors (3, 4, ntile).
+  subroutine fv3lm_hip_set_face_data(self, edge, ecorner)
+    type(fv3lm_hip_type), intent(inout) :: self
+    real(c_double), intent(in) :: edge(:, :, :), ecorner(:, :, :)
+    call check(c_set_face_data(self%handle, edge, ecorner), 'set_face_data')
+  end subroutine fv3lm_hip_set_face_data
+
+  !> One halo-exchange table (kind 0..4, include/fv3lm.h): rows(7, n) for the faces resident on this GPU, and the
+  !! per-peer send/receive lists for faces held by other ranks (replaces mpp_update_domains / mpp_get_boundary).
+  subroutine fv3lm_hip_set_exchange(self, kind, rows)
+    type(fv3lm_hip_type), intent(inout) :: self
+    integer(c_int), intent(in) :: kind, rows(:, :)
+    call check(c_set_exchange(self%handle, kind, rows, int(size(rows, 2), c_int)), 'set_exchange')
+  end subroutine fv3lm_hip_set_exchange
+
+  subroutine fv3lm_hip_set_exchange_remote(self, kind, peers, nsend, send_rows, nrecv, recv_rows)
+    type(fv3lm_hip_type), intent(inout) :: self
+    integer(c_int), intent(in) :: kind, peers(:), nsend(:), send_rows(:, :), nrecv(:), recv_rows(:, :)
+    call check(c_set_exchange_remote(self%handle, kind, int(size(peers), c_int), peers, nsend, send_rows, nrecv, recv_rows), &
+               'set_exchange_remote')
+  end subroutine fv3lm_hip_set_exchange_remote
+
+  !> RCCL communicator for the face exchange: rank 0 calls fv3lm_hip_comm_unique_id, the host broadcasts the 128 bytes
+  !! (mpp_broadcast / MPI_Bcast), every rank calls fv3lm_hip_comm_init.
+  subroutine fv3lm_hip_comm_unique_id(rccl_path, id128)
+    character(len=*), intent(in) :: rccl_path
+    character(kind=c_char), intent(out) :: id128(128)
+    call check(c_comm_unique_id(trim(rccl_path)//c_null_char, id128), 'comm_unique_id')
+  end subroutine fv3lm_hip_comm_unique_id
+
+  subroutine fv3lm_hip_comm_init(rccl_path, id128, nranks, rank)
+    character(len=*), intent(in) :: rccl_path
+    character(kind=c_char), intent(in) :: id128(128)
+    integer, intent(in) :: nranks, rank
+    call check(c_comm_init(trim(rccl_path)//c_null_char, id128, int(nranks, c_int), int(rank, c_int)), 'comm_init')
+  end subroutine fv3lm_hip_comm_init
 
   subroutine fv3lm_hip_destroy(self)
     type(fv3lm_hip_type), intent(inout) :: self
