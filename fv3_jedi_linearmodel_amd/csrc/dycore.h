@@ -146,6 +146,30 @@ struct Dycore {
 
   Rect R(int i0, int i1, int j0, int j1) const { return Rect{i0, i1, j0, j1}; }
   static Rect empty_in(const Rect& r) { return Rect{r.i0 + 1, r.i0, r.j0 + 1, r.j0}; }   // contains nothing, leaves the union with r alone
+  static Rect isect(const Rect& a, const Rect& b) { return Rect{std::max(a.i0, b.i0), std::min(a.i1, b.i1), std::max(a.j0, b.j0), std::min(a.j1, b.j1)}; }
+  static bool is_empty(const Rect& r) { return r.i0 > r.i1 || r.j0 > r.j1; }
+  // A stage whose body has face-edge branches (stages.h Edged): on a face, one bulk launch over the outputs more than W points
+  // away from every edge with the branches compiled out, and up to four strip launches (south, north, west, east) with them.
+  // Inputs only the edge formulas read are not handed to the bulk instance.
+  template <class D>
+  void add_face(Program& P, const char* grp, const D& s, int W) {
+    if (!g.face) { add(P, grp, Edged<D, false>(s)); return; }
+    const int lo = 1 + W, hi = g.nx - W, BIG = 1 << 20;
+    const Rect regs[5] = {{lo, hi, lo, hi}, {-BIG, BIG, -BIG, lo - 1}, {-BIG, BIG, hi + 1, BIG}, {-BIG, lo - 1, lo, hi}, {hi + 1, BIG, lo, hi}};
+    for (int r = 0; r < 5; ++r) {
+      D t = s; Rect anchor{1, 0, 1, 0}; bool any = false;
+      for (int n = 0; n < D::NOUT; ++n) {
+        t.orect[n] = isect(s.orect[n], regs[r]);
+        if (!is_empty(t.orect[n]) && !any) { anchor = t.orect[n]; any = true; }
+      }
+      if (!any) continue;
+      for (int n = 0; n < D::NOUT; ++n) if (is_empty(t.orect[n])) t.orect[n] = empty_in(anchor);
+      if (r == 0) {
+        for (int m = 0; m < D::NIN; ++m) if ((edge_only_inputs((const D*)nullptr) >> m) & 1u) { const int nk = t.in[m].nk; t.in[m] = Fld{}; t.in[m].nk = nk; }
+        add(P, grp, Edged<D, false>(t));
+      } else add(P, grp, Edged<D, true>(t));
+    }
+  }
 
   template <class St>
   void add(Program& P, const char* group, const St& s) {
@@ -216,8 +240,8 @@ struct Dycore {
     Fld d2b{};
     if (dsel != DAMP_NONE) {
       d2b = W((pre + "_d2b").c_str(), npz);
-      TpD2 h; h.in[0] = q; h.out[0] = d2b; h.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); h.k1 = npz; h.dsel = dsel; h.use_mass = use_mass;
-      add(P, grp, h);
+      TpD2D h; h.in[0] = q; h.out[0] = d2b; h.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); h.k1 = npz; h.dsel = dsel; h.use_mass = use_mass;
+      add_face(P, grp, h, 1);
     }
     TpFlux t; t.in[0] = fxo; t.in[1] = fx2; t.in[2] = mx; t.in[3] = fyo; t.in[4] = fy2; t.in[5] = my;
     t.in[6] = (dsel != DAMP_NONE) ? q : Fld{}; t.in[7] = d2b; t.in[8] = use_mass ? mass : Fld{};
@@ -402,11 +426,11 @@ inline void Dycore::build_acoustic() {
   Fld pe = S("pe", npz + 1), peln = S("peln", npz + 1), pk = S("pk", npz + 1), pkz = S("pkz", npz);
   // ---- c_sw
   Fld utmp = W("utmp", npz), vtmp = W("vtmp", npz), ua = W("ua", npz), va = W("va", npz);
-  { CswInterpA s; s.in[0] = u; s.in[1] = v; s.out[0] = utmp; s.out[1] = vtmp; s.out[2] = ua; s.out[3] = va;
+  { CswInterpAD s; s.in[0] = u; s.in[1] = v; s.out[0] = utmp; s.out[1] = vtmp; s.out[2] = ua; s.out[3] = va;
     s.orect[0] = R(isd, ied, js - 1, je + 1); s.orect[1] = R(is - 1, ie + 1, jsd, jed);
     s.orect[2] = s.orect[3] = R(is - 1, ie + 1, js - 1, je + 1);
     if (g.face) for (int n = 0; n < 4; ++n) s.orect[n] = R(isd, ied, jsd, jed);   // 2-point bands + corner views reach the whole halo
-    s.k1 = npz; add(P, "c_sw", s); }
+    s.k1 = npz; add_face(P, "c_sw", s, 3); }
   Fld uc0 = W("uc0", npz), utf = W("utf", npz), vc0 = W("vc0", npz), vtf = W("vtf", npz);
   const Fld none{};
   { CswInterpC_<false> s; s.in[0] = utmp; s.in[1] = vtmp; s.in[2] = u; s.in[3] = v; s.out[0] = uc0; s.out[1] = utf; s.out[2] = vc0; s.out[3] = vtf;
@@ -425,18 +449,18 @@ inline void Dycore::build_acoustic() {
     } }
   Fld divgd = W("divgd", npz);
   if (opt.nord > 0) {
-    CswDivg s; s.in[0] = u; s.in[1] = v; s.in[2] = ua; s.in[3] = va; s.out[0] = divgd; s.orect[0] = R(is, ie + 1, js, je + 1); s.k1 = npz;
-    add(P, "c_sw", s);
+    CswDivgD s; s.in[0] = u; s.in[1] = v; s.in[2] = ua; s.in[3] = va; s.out[0] = divgd; s.orect[0] = R(is, ie + 1, js, je + 1); s.k1 = npz;
+    add_face(P, "c_sw", s, 1);
   }
   Fld delpc = W("delpc", npz), ptc = W("ptc", npz);
-  { CswTransport s; s.in[0] = delp; s.in[1] = pt; s.in[2] = utf; s.in[3] = vtf; s.out[0] = delpc; s.out[1] = ptc;
-    s.orect[0] = s.orect[1] = R(is - 1, ie + 1, js - 1, je + 1); s.k1 = npz; add(P, "c_sw", s); }
+  { CswTransportD s; s.in[0] = delp; s.in[1] = pt; s.in[2] = utf; s.in[3] = vtf; s.out[0] = delpc; s.out[1] = ptc;
+    s.orect[0] = s.orect[1] = R(is - 1, ie + 1, js - 1, je + 1); s.k1 = npz; add_face(P, "c_sw", s, 1); }
   Fld ke_c = W("ke_c", npz), vort_c = W("vort_c", npz);
-  { CswKeVort s; s.in[0] = ua; s.in[1] = va; s.in[2] = uc0; s.in[3] = vc0; s.in[4] = g.face ? u : none; s.in[5] = g.face ? v : none; s.out[0] = ke_c; s.out[1] = vort_c;
-    s.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); s.orect[1] = R(is, ie + 1, js, je + 1); s.dt2 = dt2; s.k1 = npz; add(P, "c_sw", s); }
+  { CswKeVortD s; s.in[0] = ua; s.in[1] = va; s.in[2] = uc0; s.in[3] = vc0; s.in[4] = g.face ? u : none; s.in[5] = g.face ? v : none; s.out[0] = ke_c; s.out[1] = vort_c;
+    s.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); s.orect[1] = R(is, ie + 1, js, je + 1); s.dt2 = dt2; s.k1 = npz; add_face(P, "c_sw", s, 1); }
   Fld uc1 = W("uc1", npz), vc1 = W("vc1", npz);
-  { CswUpdate s; s.in[0] = uc0; s.in[1] = vc0; s.in[2] = u; s.in[3] = v; s.in[4] = vort_c; s.in[5] = ke_c; s.out[0] = uc1; s.out[1] = vc1;
-    s.orect[0] = R(is, ie + 1, js, je); s.orect[1] = R(is, ie, js, je + 1); s.dt2 = dt2; s.k1 = npz; add(P, "c_sw", s); }
+  { CswUpdateD s; s.in[0] = uc0; s.in[1] = vc0; s.in[2] = u; s.in[3] = v; s.in[4] = vort_c; s.in[5] = ke_c; s.out[0] = uc1; s.out[1] = vc1;
+    s.orect[0] = R(is, ie + 1, js, je); s.orect[1] = R(is, ie, js, je + 1); s.dt2 = dt2; s.k1 = npz; add_face(P, "c_sw", s, 1); }
   if (opt.nord > 0) add_halo(P, "halo_divgd", H_CORNER, divgd);
   // ---- geopk (C grid) + p_grad_c
   Fld pe_c = W("pe_c", npz + 1), peln_c = W("peln_c", npz + 1), pkc = W("pkc", npz + 1), gz = W("gz", npz + 1);
@@ -455,8 +479,8 @@ inline void Dycore::build_acoustic() {
     s.orect[3] = R(isd, ied, js - 1, je + 2); s.orect[4] = s.orect[5] = R(isd, ied, js, je + 1); s.dt = dt; s.k1 = npz; add(P, "d_sw", s);
   } else {
     Fld ut_a = W("ut_a", npz), vt_a = W("vt_a", npz);
-    { DswWindsA s; s.in[0] = uc; s.in[1] = vc; s.out[0] = ut_a; s.out[1] = vt_a; s.orect[0] = R(is - 1, ie + 2, jsd, jed); s.orect[1] = R(isd, ied, js - 1, je + 2);
-      s.dt = dt; s.k1 = npz; add(P, "d_sw", s); }
+    { DswWindsAD s; s.in[0] = uc; s.in[1] = vc; s.out[0] = ut_a; s.out[1] = vt_a; s.orect[0] = R(is - 1, ie + 2, jsd, jed); s.orect[1] = R(isd, ied, js - 1, je + 2);
+      s.dt = dt; s.k1 = npz; add_face(P, "d_sw", s, 1); }
     Fld ut_e = W("ut_e", npz), vt_e = W("vt_e", npz);
     const int npx = g.nx + 1, npy = g.ny + 1;
     DswWindsE se; se.in[0] = ut_a; se.in[1] = vt_a; se.in[2] = uc; se.in[3] = vc; se.out[0] = ut_e; se.out[1] = vt_e; se.k1 = npz;
@@ -464,9 +488,9 @@ inline void Dycore::build_acoustic() {
       const Rect r = e == 0 ? R(is - 1, ie + 2, 0, 1) : e == 1 ? R(is - 1, ie + 2, npy - 1, npy) : e == 2 ? R(0, 1, js - 1, je + 2) : R(npx - 1, npx, js - 1, je + 2);
       se.orect[e < 2 ? 0 : 1] = r; se.orect[e < 2 ? 1 : 0] = empty_in(r); add(P, "d_sw", se);
     }
-    DswWindsC s; s.in[0] = ut_a; s.in[1] = vt_a; s.in[2] = ut_e; s.in[3] = vt_e; s.out[0] = ut; s.out[1] = crx; s.out[2] = xfx; s.out[3] = vt; s.out[4] = cry; s.out[5] = yfx;
+    DswWindsCD s; s.in[0] = ut_a; s.in[1] = vt_a; s.in[2] = ut_e; s.in[3] = vt_e; s.out[0] = ut; s.out[1] = crx; s.out[2] = xfx; s.out[3] = vt; s.out[4] = cry; s.out[5] = yfx;
     s.orect[0] = R(is - 1, ie + 2, jsd, jed); s.orect[1] = s.orect[2] = R(is, ie + 1, jsd, jed);
-    s.orect[3] = R(isd, ied, js - 1, je + 2); s.orect[4] = s.orect[5] = R(isd, ied, js, je + 1); s.dt = dt; s.k1 = npz; add(P, "d_sw", s);
+    s.orect[3] = R(isd, ied, js - 1, je + 2); s.orect[4] = s.orect[5] = R(isd, ied, js, je + 1); s.dt = dt; s.k1 = npz; add_face(P, "d_sw", s, 1);
   }
   Fld rax = W("ra_x", npz), ray = W("ra_y", npz);
   { DswRa s; s.in[0] = xfx; s.in[1] = yfx; s.out[0] = rax; s.out[1] = ray; s.orect[0] = R(is, ie, jsd, jed); s.orect[1] = R(isd, ied, js, je);
@@ -479,22 +503,22 @@ inline void Dycore::build_acoustic() {
   { DswUpdateDp s; s.in[0] = delp; s.in[1] = pt; s.in[2] = fx; s.in[3] = fy; s.in[4] = gx; s.in[5] = gy; s.out[0] = delp_o; s.out[1] = pt_o;
     s.orect[0] = s.orect[1] = R(is, ie, js, je); s.k1 = npz; add(P, "d_sw", s); }
   Fld vb = W("vb", npz), ub = W("ub", npz), ke = W("ke", npz);
-  { DswKeWinds s; s.in[0] = uc; s.in[1] = vc; s.in[2] = g.face ? ut : none; s.in[3] = g.face ? vt : none; s.out[0] = vb; s.out[1] = ub; s.orect[0] = s.orect[1] = R(is, ie + 1, js, je + 1); s.dt = dt;
-    s.k1 = npz; add(P, "d_sw", s); }
-  { DswKe s; s.in[0] = vb; s.in[1] = ub; s.in[2] = u; s.in[3] = v; s.in[4] = g.face ? ut : none; s.in[5] = g.face ? vt : none; s.dt = dt; s.out[0] = ke; s.orect[0] = R(is, ie + 1, js, je + 1); s.k1 = npz; add(P, "d_sw", s); }
+  { DswKeWindsD s; s.in[0] = uc; s.in[1] = vc; s.in[2] = g.face ? ut : none; s.in[3] = g.face ? vt : none; s.out[0] = vb; s.out[1] = ub; s.orect[0] = s.orect[1] = R(is, ie + 1, js, je + 1); s.dt = dt;
+    s.k1 = npz; add_face(P, "d_sw", s, 1); }
+  { DswKeD s; s.in[0] = vb; s.in[1] = ub; s.in[2] = u; s.in[3] = v; s.in[4] = g.face ? ut : none; s.in[5] = g.face ? vt : none; s.dt = dt; s.out[0] = ke; s.orect[0] = R(is, ie + 1, js, je + 1); s.k1 = npz; add_face(P, "d_sw", s, 3); }
   Fld wk = W("wk", npz), vorta = W("vort_abs", npz);
   { DswVort s; s.in[0] = u; s.in[1] = v; s.out[0] = wk; s.out[1] = vorta; s.orect[0] = s.orect[1] = R(isd, ied, jsd, jed); s.k1 = npz; add(P, "d_sw", s); }
   Fld da = W("dd_a", npz), db = W("dd_b", npz), dc = W("dd_c", npz), vortb = W("vort_b", npz), ke2 = W("ke2", npz);
-  { DdA s; s.in[0] = divgd; s.in[1] = u; s.in[2] = v; s.in[3] = ua; s.in[4] = va; s.in[5] = g.face ? uc : none; s.in[6] = g.face ? vc : none; s.out[0] = da; s.out[1] = db;
-    s.orect[0] = R(is - 1, ie + 1, js, je + 1); s.orect[1] = R(is, ie + 1, js - 1, je + 1); s.k1 = npz; add(P, "d_sw", s); }
-  { DdB s; s.in[0] = da; s.in[1] = db; s.out[0] = dc; s.orect[0] = R(is, ie + 1, js, je + 1); s.k1 = npz; add(P, "d_sw", s); }
+  { DdAD s; s.in[0] = divgd; s.in[1] = u; s.in[2] = v; s.in[3] = ua; s.in[4] = va; s.in[5] = g.face ? uc : none; s.in[6] = g.face ? vc : none; s.out[0] = da; s.out[1] = db;
+    s.orect[0] = R(is - 1, ie + 1, js, je + 1); s.orect[1] = R(is, ie + 1, js - 1, je + 1); s.k1 = npz; add_face(P, "d_sw", s, 1); }
+  { DdBD s; s.in[0] = da; s.in[1] = db; s.out[0] = dc; s.orect[0] = R(is, ie + 1, js, je + 1); s.k1 = npz; add_face(P, "d_sw", s, 1); }
   build_a2b(P, "d_sw", "a2bw", wk, vortb, npz);
   { DdC s; s.in[0] = ke; s.in[1] = dc; s.in[2] = divgd; s.in[3] = vortb; s.out[0] = ke2; s.orect[0] = R(is, ie + 1, js, je + 1);
     s.dt = dt; s.dddmp = opt.dddmp; s.d4_bg = opt.d4_bg; s.k1 = npz; add(P, "d_sw", s); }
   Fld fxv = W("fxv", npz), fyv = W("fyv", npz);
   build_tp(P, "d_sw", "tpv", vorta, crx, cry, xfx, yfx, rax, ray, xfx, yfx, Fld{}, HORD_VT, DAMP_NONE, false, fxv, fyv);
   Fld d6 = W("del6_d2", npz);
-  { Del6A s; s.in[0] = wk; s.out[0] = d6; s.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); s.k1 = npz; add(P, "d_sw", s); }
+  { Del6AD s; s.in[0] = wk; s.out[0] = d6; s.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); s.k1 = npz; add_face(P, "d_sw", s, 1); }
   Fld u_m = W("u_m", npz), v_m = W("v_m", npz);
   { DswUpdateUV s; s.in[0] = u; s.in[1] = v; s.in[2] = ke2; s.in[3] = fxv; s.in[4] = fyv; s.in[5] = wk; s.in[6] = d6; s.out[0] = u_m; s.out[1] = v_m;
     s.orect[0] = R(is, ie, js, je + 1); s.orect[1] = R(is, ie + 1, js, je); s.k1 = npz; add(P, "d_sw", s); }

@@ -16,7 +16,8 @@ namespace fv3 {
   Fld out[NO];                                                       \
   Rect orect[NO];                                                    \
   int k0 = 1, k1 = 1;                                                \
-  static const char* name() { return NAME; }
+  static const char* name() { return NAME; }                        \
+  static const char* ename() { return NAME "e"; }
 // Adjoint refinements a stage may override: uses(M, di, dj, dk) = does any output read input M at that
 // offset (exact stencil inside the box); wants(M) = bit mask of the outputs that depend on input M
 // (0: the input only steers branches).  Stages that read corner-halo points through an index map
@@ -34,6 +35,20 @@ namespace fv3 {
 #define SSG(n, i, j) c.m.sin_sg[n][c.mi(tile, (i), (j))]
 #define CSG(n, i, j) c.m.cos_sg[n][c.mi(tile, (i), (j))]
 #define IN(M, ...) a.template in<M>(__VA_ARGS__)
+
+// A stage body written with `template <bool EDGE, ...> eval_e` becomes two stage types: Edged<D,false> for the bulk launch
+// (no face edge within reach of its outputs: every edge branch and corner view compiled out) and Edged<D,true> for the
+// strips next to the face edges (dycore.h add_face).
+template <class D, bool EDGE>
+struct Edged : D {
+  Edged() = default;
+  Edged(const D& d) : D(d) {}
+  static constexpr int NALIAS = EDGE ? D::NALIAS : 0;
+  static const char* name() { return EDGE ? D::ename() : D::name(); }
+  HD bool alias(const Ctx& c, int M, int i, int j, int n, int& ai, int& aj) const { return EDGE && D::alias(c, M, i, j, n, ai, aj); }
+  template <class T, class A>
+  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const { this->template eval_e<EDGE, T, A>(a, c, tile, i, j, k, o); }
+};
 
 constexpr double A1 = 0.5625, A2 = -0.0625;            // sw_core_tlm.F90:56-57
 constexpr double P1 = 7. / 12., P2 = -1. / 12.;        // tp_core_tlm.F90 p1,p2
@@ -87,13 +102,13 @@ HD T tp_uv_flux(int iord, bool face, int m, int n1, bool row_edge, const Q& q, c
 // ===================================================================== c_sw
 // d2a2c_vect A: D-grid winds -> A-grid (sw_core_tlm.F90:6505-6611); within 3 cells of a face edge the
 // 4-point Lagrange interpolation gives way to 2-point averages (:6548-6602, npt = 4).
-struct CswInterpA {
+struct CswInterpAD {
   STAGE_COMMON("CswInterpA", 2, 4)   // in: u v   out: utmp vtmp ua va
   HD static constexpr Box box(int M) { return M == 0 ? Box{0, 0, -1, 2, 0, 0} : Box{-1, 2, 0, 0, 0, 0}; }
-  template <class T, class A>
-  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+  template <bool EDGE, class T, class A>
+  HD void eval_e(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     T ut = T(0.), vt = T(0.);
-    const bool band = c.g.face && (i <= 3 || i >= c.g.nx - 2 || j <= 3 || j >= c.g.ny - 2);
+    const bool band = EDGE && (i <= 3 || i >= c.g.nx - 2 || j <= 3 || j >= c.g.ny - 2);
     if (orect[0].has(i, j)) ut = band ? 0.5 * (IN(0, i, j) + IN(0, i, j + 1)) : A2 * (IN(0, i, j - 1) + IN(0, i, j + 2)) + A1 * (IN(0, i, j) + IN(0, i, j + 1));
     if (orect[1].has(i, j)) vt = band ? 0.5 * (IN(1, i, j) + IN(1, i + 1, j)) : A2 * (IN(1, i - 1, j) + IN(1, i + 2, j)) + A1 * (IN(1, i, j) + IN(1, i + 1, j));
     o[0] = ut; o[1] = vt;
@@ -102,6 +117,8 @@ struct CswInterpA {
     o[3] = (vt - ut * cs) * r2;
   }
 };
+typedef Edged<CswInterpAD, false> CswInterpA;
+typedef Edged<CswInterpAD, true> CswInterpAE;
 
 // d2a2c_vect C: A-grid -> C-grid + contravariant flux-form winds (:6617-6803, :713-733).  The corner
 // fixes of utmp/vtmp/ua/va (:6617-6640, :6662-6677, :6726-6760) are read through d2a2c_xview/yview.
@@ -170,36 +187,38 @@ struct CswInterpC_ {
 };
 
 // divergence_corner (sw_core_tlm.F90:4036-4081)
-struct CswDivg {
+struct CswDivgD {
   STAGE_COMMON("CswDivg", 4, 1)   // in: u v ua va   out: divgd
   HD static constexpr Box box(int M) { return M == 0 ? Box{-1, 0, 0, 0, 0, 0} : M == 1 ? Box{0, 0, -1, 0, 0, 0} : Box{-1, 0, -1, 0, 0, 0}; }
-  template <class T, class A>
+  template <bool EDGE, class T, class A>
   HD T uf(const A& a, const Ctx& c, int tile, int i, int j) const {
     const double w = MET(dyc, i, j) * 0.5 * (SSG(4, i, j - 1) + SSG(2, i, j));
-    if (c.g.face && (j == 1 || j == c.g.ny + 1)) return IN(0, i, j) * w;
+    if (EDGE && (j == 1 || j == c.g.ny + 1)) return IN(0, i, j) * w;
     return (IN(0, i, j) - 0.25 * (IN(3, i, j - 1) + IN(3, i, j)) * (CSG(4, i, j - 1) + CSG(2, i, j))) * w;
   }
-  template <class T, class A>
+  template <bool EDGE, class T, class A>
   HD T vf(const A& a, const Ctx& c, int tile, int i, int j) const {
     const double w = MET(dxc, i, j) * 0.5 * (SSG(3, i - 1, j) + SSG(1, i, j));
-    if (c.g.face && (i == 1 || i == c.g.nx + 1)) return IN(1, i, j) * w;
+    if (EDGE && (i == 1 || i == c.g.nx + 1)) return IN(1, i, j) * w;
     return (IN(1, i, j) - 0.25 * (IN(2, i - 1, j) + IN(2, i, j)) * (CSG(3, i - 1, j) + CSG(1, i, j))) * w;
   }
-  template <class T, class A>
-  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+  template <bool EDGE, class T, class A>
+  HD void eval_e(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     const int npx = c.g.nx + 1, npy = c.g.ny + 1;
-    const bool F = c.g.face;
+    constexpr bool F = EDGE;
     const bool drop_lo = F && j == 1 && (i == 1 || i == npx), drop_hi = F && j == npy && (i == 1 || i == npx);   // :4071-4078
-    T d = uf<T>(a, c, tile, i - 1, j) - uf<T>(a, c, tile, i, j);
-    if (!drop_lo) d = d + vf<T>(a, c, tile, i, j - 1);
-    if (!drop_hi) d = d - vf<T>(a, c, tile, i, j);
+    T d = uf<EDGE, T>(a, c, tile, i - 1, j) - uf<EDGE, T>(a, c, tile, i, j);
+    if (!drop_lo) d = d + vf<EDGE, T>(a, c, tile, i, j - 1);
+    if (!drop_hi) d = d - vf<EDGE, T>(a, c, tile, i, j);
     o[0] = MET(rarea_c, i, j) * d;
   }
 };
+typedef Edged<CswDivgD, false> CswDivg;
+typedef Edged<CswDivgD, true> CswDivgE;
 
 // first-order upwind transport of delp, pt on the C grid (sw_core_tlm.F90:739-808); the corner halo of
 // delp/pt is read through fill2_4corners' x-view for the x-fluxes and y-view otherwise.
-struct CswTransport {
+struct CswTransportD {
   STAGE_BASE("CswTransport", 4, 2)   // in: delp pt utf vtf   out: delpc ptc
   HD static constexpr bool uses(int M, int di, int dj, int) { return M >= 2 || di == 0 || dj == 0; }
   HD static constexpr unsigned wants(int M) { return M == 1 ? 0x2u : 0x3u; }
@@ -209,31 +228,33 @@ struct CswTransport {
   HD bool alias(const Ctx& c, int M, int i, int j, int n, int& ai, int& aj) const {
     return M < 2 && fill2_alias(c.g, n + 1, i, j, ai, aj);
   }
-  template <int M, class T, class A>
-  HD T rd(const A& a, const Ctx& c, int dir, int i, int j) const { fill2_map(c.g, dir, i, j); return IN(M, i, j); }
-  template <class T, class A>
-  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+  template <bool EDGE, int M, class T, class A>
+  HD T rd(const A& a, const Ctx& c, int dir, int i, int j) const { if (EDGE) fill2_map(c.g, dir, i, j); return IN(M, i, j); }
+  template <bool EDGE, class T, class A>
+  HD void eval_e(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     T fx1[2], fx[2], fy1[2], fy[2];
     for (int d = 0; d < 2; ++d) {
       T ut = IN(2, i + d, j);
       const int iu = (val(ut) > 0.) ? i + d - 1 : i + d;
-      fx1[d] = ut * rd<0, T>(a, c, 1, iu, j);
-      fx[d] = fx1[d] * rd<1, T>(a, c, 1, iu, j);
+      fx1[d] = ut * rd<EDGE, 0, T>(a, c, 1, iu, j);
+      fx[d] = fx1[d] * rd<EDGE, 1, T>(a, c, 1, iu, j);
       T vt = IN(3, i, j + d);
       const int ju = (val(vt) > 0.) ? j + d - 1 : j + d;
-      fy1[d] = vt * rd<0, T>(a, c, 2, i, ju);
-      fy[d] = fy1[d] * rd<1, T>(a, c, 2, i, ju);
+      fy1[d] = vt * rd<EDGE, 0, T>(a, c, 2, i, ju);
+      fy[d] = fy1[d] * rd<EDGE, 1, T>(a, c, 2, i, ju);
     }
     const double ra = MET(rarea, i, j);
-    T dp = rd<0, T>(a, c, 2, i, j), p = rd<1, T>(a, c, 2, i, j);
+    T dp = rd<EDGE, 0, T>(a, c, 2, i, j), p = rd<EDGE, 1, T>(a, c, 2, i, j);
     T dpc = dp + (fx1[0] - fx1[1] + (fy1[0] - fy1[1])) * ra;
     o[0] = dpc;
     o[1] = (p * dp + (fx[0] - fx[1] + (fy[0] - fy[1])) * ra) / dpc;
   }
 };
+typedef Edged<CswTransportD, false> CswTransport;
+typedef Edged<CswTransportD, true> CswTransportE;
 
 // kinetic energy at cell centres and absolute vorticity at corners (sw_core_tlm.F90:853-957)
-struct CswKeVort {
+struct CswKeVortD {
   STAGE_BASE("CswKeVort", 6, 2)   // in: ua va uc0 vc0 u v   out: ke vort
   STAGE_NO_ALIAS
   double dt2;
@@ -242,10 +263,10 @@ struct CswKeVort {
   HD static constexpr Box box(int M) {
     return M < 2 ? Box{0, 0, 0, 0, 0, 0} : M == 2 ? Box{0, 1, -1, 0, 0, 0} : M == 3 ? Box{-1, 0, 0, 1, 0, 0} : M == 4 ? Box{0, 0, 0, 1, 0, 0} : Box{0, 1, 0, 0, 0, 0};
   }
-  template <class T, class A>
-  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+  template <bool EDGE, class T, class A>
+  HD void eval_e(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = T(0.);
-    const bool F = c.g.face; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
+    constexpr bool F = EDGE; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
     if ((a.want & 0x1u) && orect[0].has(i, j)) {
       T ua = IN(0, i, j), va = IN(1, i, j), ku, kv;
       if (val(ua) > 0.) {
@@ -273,19 +294,21 @@ struct CswKeVort {
     }
   }
 };
+typedef Edged<CswKeVortD, false> CswKeVort;
+typedef Edged<CswKeVortD, true> CswKeVortE;
 
 // time-centred C-grid winds (sw_core_tlm.F90:985-1037)
-struct CswUpdate {
+struct CswUpdateD {
   STAGE_BASE("CswUpdate", 6, 2)   // in: uc0 vc0 u v vort ke   out: uc1 vc1
   STAGE_NO_ALIAS
   double dt2;
   HD static constexpr bool uses(int M, int di, int dj, int) { return M < 4 || (M == 4 ? !(di == 1 && dj == 1) : !(di == -1 && dj == -1)); }
   HD static constexpr unsigned wants(int M) { return (M == 0 || M == 3) ? 0x1u : (M == 1 || M == 2) ? 0x2u : 0x3u; }
   HD static constexpr Box box(int M) { return M < 4 ? Box{0, 0, 0, 0, 0, 0} : M == 4 ? Box{0, 1, 0, 1, 0, 0} : Box{-1, 0, -1, 0, 0, 0}; }
-  template <class T, class A>
-  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+  template <bool EDGE, class T, class A>
+  HD void eval_e(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = T(0.);
-    const bool F = c.g.face; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
+    constexpr bool F = EDGE; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
     if ((a.want & 0x1u) && orect[0].has(i, j)) {
       T uc = IN(0, i, j);
       T fy1 = (F && (i == 1 || i == npx)) ? dt2 * IN(3, i, j) : dt2 * (IN(3, i, j) - uc * MET(cosa_u, i, j)) / MET(sina_u, i, j);
@@ -300,6 +323,8 @@ struct CswUpdate {
     }
   }
 };
+typedef Edged<CswUpdateD, false> CswUpdate;
+typedef Edged<CswUpdateD, true> CswUpdateE;
 
 // p_grad_c, hydrostatic (dyn_core_tlm.F90:3310-3334)
 struct PGradC {
@@ -365,12 +390,12 @@ struct DswWinds {
 // Face tiles, pass A: the winds away from the edges and the edge-normal values on the edges
 // (:2717-2751, :2768-2776, :2795-2803, :2821-2830).  ut on the two rows next to a south/north edge is
 // left 0 here (pass B).
-struct DswWindsA {
+struct DswWindsAD {
   STAGE_COMMON("DswWindsA", 2, 2)   // in: uc vc   out: ut_a vt_a
   double dt;
   HD static constexpr Box box(int M) { return M == 0 ? Box{0, 1, -1, 0, 0, 0} : Box{-1, 0, 0, 1, 0, 0}; }
-  template <class T, class A>
-  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+  template <bool EDGE, class T, class A>
+  HD void eval_e(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = T(0.);
     const int npx = c.g.nx + 1, npy = c.g.ny + 1;
     if (orect[0].has(i, j)) {
@@ -384,6 +409,8 @@ struct DswWindsA {
     }
   }
 };
+typedef Edged<DswWindsAD, false> DswWindsA;
+typedef Edged<DswWindsAD, true> DswWindsAE;
 // Pass B, on the strips next to the face edges only: the two ut rows next to a south/north edge and the two vt
 // columns next to a west/east edge from the pass-A winds (:2752-2766, :2777-2793, :2804-2819, :2831-2846), and the
 // 2x2 systems at the four corners (:2856-2919), which also only read pass-A values.  Everything else is pass A.
@@ -428,12 +455,12 @@ struct DswWindsE {
 };
 // Pass C (pointwise): final winds = strip values where there are any, pass A elsewhere; Courant numbers and area
 // fluxes (:2932-2968).
-struct DswWindsC {
+struct DswWindsCD {
   STAGE_COMMON("DswWindsC", 4, 6)   // in: ut_a vt_a ut_e vt_e   out: ut crx xfx vt cry yfx
   double dt;
   HD static constexpr Box box(int) { return Box{0, 0, 0, 0, 0, 0}; }
-  template <class T, class A>
-  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+  template <bool EDGE, class T, class A>
+  HD void eval_e(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     for (int n = 0; n < 6; ++n) o[n] = T(0.);
     const int npx = c.g.nx + 1, npy = c.g.ny + 1;
     if (orect[0].has(i, j)) {
@@ -448,6 +475,8 @@ struct DswWindsC {
     }
   }
 };
+typedef Edged<DswWindsCD, false> DswWindsC;
+typedef Edged<DswWindsCD, true> DswWindsCE;
 
 struct DswRa {   // sw_core_tlm.F90:2969-2978
   STAGE_COMMON("DswRa", 2, 2)   // in: xfx yfx   out: ra_x ra_y
@@ -530,10 +559,10 @@ struct TpQj {   // tp_core_tlm.F90:173-181
 // del-4 inner Laplacian of deln_flux / del6_vt_flux (nord = 1): d2 after one pass, the corner halo of
 // the damped field read through copy_corners' x-view for the x-differences and y-view for the
 // y-differences (tp_core_tlm.F90:1970-2008, sw_core_tlm.F90:3747-3776).
-template <int M, class T, class A>
+template <bool EDGE, int M, class T, class A>
 HD T lap_corner(const A& a, const Ctx& c, int tile, int i, int j) {
-  auto rx = [&](int ii, int jj) -> T { corner_map(c.g, 1, ii, jj); return a.template in<M>(ii, jj); };
-  auto ry = [&](int ii, int jj) -> T { corner_map(c.g, 2, ii, jj); return a.template in<M>(ii, jj); };
+  auto rx = [&](int ii, int jj) -> T { if (EDGE) corner_map(c.g, 1, ii, jj); return a.template in<M>(ii, jj); };
+  auto ry = [&](int ii, int jj) -> T { if (EDGE) corner_map(c.g, 2, ii, jj); return a.template in<M>(ii, jj); };
   T fxa = MET(del6_v, i, j) * (rx(i - 1, j) - rx(i, j));
   T fxb = MET(del6_v, i + 1, j) * (rx(i, j) - rx(i + 1, j));
   T fya = MET(del6_u, i, j) * (ry(i, j - 1) - ry(i, j));
@@ -546,7 +575,7 @@ HD void damp_of(const LevelParams& l, int sel, int& nord, double& damp_c) {
   else if (sel == DAMP_T) { nord = l.nord_t; damp_c = l.damp_t; }
   else { nord = -1; damp_c = 0.; }
 }
-struct TpD2 {
+struct TpD2D {
   STAGE_BASE("TpD2", 1, 1)   // in: q   out: d2b  (is-1..ie+1, js-1..je+1); zero where the level does not use nord=1
   HD static constexpr bool uses(int, int di, int dj, int) { return di == 0 || dj == 0; }
   HD static constexpr unsigned wants(int) { return 0x1u; }
@@ -555,15 +584,17 @@ struct TpD2 {
   HD bool alias(const Ctx& c, int, int i, int j, int n, int& ai, int& aj) const { return corner_alias(c.g, n + 1, i, j, ai, aj); }
   int dsel; int use_mass;
   HD static constexpr Box box(int) { return Box{-1, 1, -1, 1, 0, 0}; }
-  template <class T, class A>
-  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+  template <bool EDGE, class T, class A>
+  HD void eval_e(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     int nord; double dc; damp_of(c.lev[k - 1], dsel, nord, dc);
     o[0] = T(0.);
     if (nord != 1 || !(dc > 1.e-4)) return;
     const double damp = use_mass ? 1.0 : (dc * c.m.da_min) * (dc * c.m.da_min);
-    o[0] = damp * lap_corner<0, T>(a, c, tile, i, j);
+    o[0] = damp * lap_corner<EDGE, 0, T>(a, c, tile, i, j);
   }
 };
+typedef Edged<TpD2D, false> TpD2;
+typedef Edged<TpD2D, true> TpD2E;
 // flux averaging + damping fluxes (tp_core_tlm.F90:187-234, deln_flux :1918-2043)
 struct TpFlux {
   STAGE_BASE("TpFlux", 9, 2)   // in: fx_o fx2 mx fy_o fy2 my q d2b mass   out: fx fy
@@ -621,14 +652,14 @@ struct DswUpdateDp {
 
 // B-grid advective winds for the KE fluxes (sw_core_tlm.F90:3126-3254): standard formula, mean of the
 // edge-normal winds along a face edge, 2-point extrapolation from both sides across it.
-struct DswKeWinds {
+struct DswKeWindsD {
   STAGE_COMMON("DswKeWinds", 4, 2)   // in: uc vc ut vt   out: vb ub
   double dt;
   HD static constexpr Box box(int M) { return M == 0 ? Box{0, 0, -1, 0, 0, 0} : M == 1 ? Box{-1, 0, 0, 0, 0, 0} : M == 2 ? Box{0, 0, -2, 1, 0, 0} : Box{-2, 1, 0, 0, 0, 0}; }
-  template <class T, class A>
-  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+  template <bool EDGE, class T, class A>
+  HD void eval_e(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     const double dt5 = 0.5 * dt, dt4 = 0.25 * dt;
-    const bool F = c.g.face; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
+    constexpr bool F = EDGE; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
     const bool ie_ = F && (i == 1 || i == npx), je_ = F && (j == 1 || j == npy);
     if (!ie_ && !je_) {
       const double cs = MET(cosa, i, j), rs = MET(rsina, i, j);
@@ -643,14 +674,16 @@ struct DswKeWinds {
     else o[1] = dt4 * (-IN(2, i, j - 2) + 3. * (IN(2, i, j - 1) + IN(2, i, j)) - IN(2, i, j + 1));
   }
 };
+typedef Edged<DswKeWindsD, false> DswKeWinds;
+typedef Edged<DswKeWindsD, true> DswKeWindsE;
 // KE = 0.5*(vb*ytp_v + ub*xtp_u), face corners from the edge-normal winds (sw_core_tlm.F90:3197-3273)
-struct DswKe {
+struct DswKeD {
   STAGE_COMMON("DswKe", 6, 1)   // in: vb ub u v ut vt   out: ke
   double dt;
   HD static constexpr Box box(int M) { return M < 2 ? Box{0, 0, 0, 0, 0, 0} : M == 2 ? Box{-3, 2, 0, 0, 0, 0} : M == 3 ? Box{0, 0, -3, 2, 0, 0} : M == 4 ? Box{0, 0, -1, 0, 0, 0} : Box{-1, 0, 0, 0, 0, 0}; }
-  template <class T, class A>
-  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    const bool F = c.g.face; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
+  template <bool EDGE, class T, class A>
+  HD void eval_e(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+    constexpr bool F = EDGE; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
     if (F && (i == 1 || i == npx) && (j == 1 || j == npy)) {   // :3258-3273
       const double dt6 = dt / 6.;
       if (i == 1 && j == 1)
@@ -673,6 +706,8 @@ struct DswKe {
     o[0] = 0.5 * (vb * fv + ub * fu);
   }
 };
+typedef Edged<DswKeD, false> DswKe;
+typedef Edged<DswKeD, true> DswKeE;
 // relative and absolute vorticity (sw_core_tlm.F90:3275-3293, :3535-3540)
 struct DswVort {
   STAGE_COMMON("DswVort", 2, 2)   // in: u v   out: wk vort_abs
@@ -686,16 +721,16 @@ struct DswVort {
 };
 
 // ---- divergence damping (compute_divergence_damping, sw_core_tlm.F90:7760-8072), nord in {0,1} ----
-struct DdA {
+struct DdAD {
   STAGE_BASE("DdA", 7, 2)   // in: divgd u v ua va uc vc (uc, vc: upwind side on a face edge only)   out: da db
   STAGE_NO_ALIAS
   HD static constexpr bool uses(int M, int di, int dj, int) { return M == 0 ? !(di == 1 && dj == 1) : M == 3 ? dj == 0 : M == 4 ? di == 0 : true; }
   HD static constexpr unsigned wants(int M) { return M == 0 ? 0x3u : (M == 1 || M == 4) ? 0x1u : M >= 5 ? 0x0u : 0x2u; }
   HD static constexpr Box box(int M) { return M == 0 ? Box{0, 1, 0, 1, 0, 0} : (M == 3 || M == 4) ? Box{-1, 0, -1, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
-  template <class T, class A>
-  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+  template <bool EDGE, class T, class A>
+  HD void eval_e(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     const int nord = c.lev[k - 1].nord;
-    const bool F = c.g.face; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
+    constexpr bool F = EDGE; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
     o[0] = o[1] = T(0.);
     if (nord == 0) {   // :7874-7922
       if ((a.want & 0x1u) && orect[0].has(i, j)) {
@@ -712,12 +747,14 @@ struct DdA {
     }
   }
 };
-struct DdB {   // :7924-7937 (nord=0: delpc) / :7990-8006 (nord>0: new divg_d); one term dropped at the face corners
+typedef Edged<DdAD, false> DdA;
+typedef Edged<DdAD, true> DdAE;
+struct DdBD {   // :7924-7937 (nord=0: delpc) / :7990-8006 (nord>0: new divg_d); one term dropped at the face corners
   STAGE_COMMON("DdB", 2, 1)   // in: da db   out: dc
   HD static constexpr Box box(int M) { return M == 0 ? Box{-1, 0, 0, 0, 0, 0} : Box{0, 0, -1, 0, 0, 0}; }
-  template <class T, class A>
-  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    const bool F = c.g.face; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
+  template <bool EDGE, class T, class A>
+  HD void eval_e(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+    constexpr bool F = EDGE; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
     const bool drop_lo = F && j == 1 && (i == 1 || i == npx), drop_hi = F && j == npy && (i == 1 || i == npx);
     T d = IN(0, i - 1, j) - IN(0, i, j);
     if (!drop_lo) d = d + IN(1, i, j - 1);
@@ -725,6 +762,8 @@ struct DdB {   // :7924-7937 (nord=0: delpc) / :7990-8006 (nord>0: new divg_d); 
     o[0] = MET(rarea_c, i, j) * d;
   }
 };
+typedef Edged<DdBD, false> DdB;
+typedef Edged<DdBD, true> DdBE;
 // a2b_ord4 (a2b_edge_tlm.F90:48-542): (A) the x- and y-interpolated edge-centred values qx, qy
 template <bool EDGE>
 struct A2bA_ {
@@ -848,7 +887,7 @@ struct DdC {   // Smagorinsky-type coefficient and damping term added to KE (:79
   }
 };
 // del6_vt_flux inner Laplacian without the damp factor (sw_core_tlm.F90:3747-3776, nord_v = 1)
-struct Del6A {
+struct Del6AD {
   STAGE_BASE("Del6A", 1, 1)   // in: wk   out: d2b
   HD static constexpr bool uses(int, int di, int dj, int) { return di == 0 || dj == 0; }
   HD static constexpr unsigned wants(int) { return 0x1u; }
@@ -856,9 +895,11 @@ struct Del6A {
   HD static constexpr int alias_box(int M) { return M; }
   HD bool alias(const Ctx& c, int, int i, int j, int n, int& ai, int& aj) const { return corner_alias(c.g, n + 1, i, j, ai, aj); }
   HD static constexpr Box box(int) { return Box{-1, 1, -1, 1, 0, 0}; }
-  template <class T, class A>
-  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const { o[0] = lap_corner<0, T>(a, c, tile, i, j); }
+  template <bool EDGE, class T, class A>
+  HD void eval_e(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const { o[0] = lap_corner<EDGE, 0, T>(a, c, tile, i, j); }
 };
+typedef Edged<Del6AD, false> Del6A;
+typedef Edged<Del6AD, true> Del6AE;
 // momentum update (sw_core_tlm.F90:3555-3564) + vorticity-damping fluxes, trajectory and
 // perturbation coefficients kept apart (sw_core_tlm.F90:2436-2452, :2502-2530)
 struct DswUpdateUV {
@@ -970,5 +1011,13 @@ struct OneGradP {
     }
   }
 };
+
+// inputs that only the face-edge formulas of a stage read (bit m = input m): not given to the bulk launch
+template <class D> constexpr unsigned edge_only_inputs(const D*) { return 0u; }
+constexpr unsigned edge_only_inputs(const CswKeVortD*) { return 0x30u; }
+constexpr unsigned edge_only_inputs(const DswKeWindsD*) { return 0xCu; }
+constexpr unsigned edge_only_inputs(const DswKeD*) { return 0x30u; }
+constexpr unsigned edge_only_inputs(const DdAD*) { return 0x60u; }
+constexpr unsigned edge_only_inputs(const DswWindsCD*) { return 0xCu; }
 
 }  // namespace fv3
