@@ -66,6 +66,34 @@ HD double val(const Dual& a) { return a.v; }
 HD double combine(double a, double) { return a; }
 HD Dual combine(const Dual& a, const Dual& b) { return Dual(a.v, b.d); }
 
+// Forward-mode scalar with N tangent directions: the joint adjoint launcher (exec.h) seeds one direction per stage
+// input, so one evaluation of an output point yields its derivatives with respect to every input at once.  All loops
+// have constant trip counts; directions that are never seeded are compile-time zeros and fold away.
+template <int N>
+struct DualV {
+  double v; double d[N];
+  HD DualV() : v(0.0) { for (int n = 0; n < N; ++n) d[n] = 0.0; }
+  HD DualV(double v_) : v(v_) { for (int n = 0; n < N; ++n) d[n] = 0.0; }
+};
+template <int N> HD DualV<N> operator+(const DualV<N>& a, const DualV<N>& b) { DualV<N> r; r.v = a.v + b.v; for (int n = 0; n < N; ++n) r.d[n] = a.d[n] + b.d[n]; return r; }
+template <int N> HD DualV<N> operator-(const DualV<N>& a, const DualV<N>& b) { DualV<N> r; r.v = a.v - b.v; for (int n = 0; n < N; ++n) r.d[n] = a.d[n] - b.d[n]; return r; }
+template <int N> HD DualV<N> operator*(const DualV<N>& a, const DualV<N>& b) { DualV<N> r; r.v = a.v * b.v; for (int n = 0; n < N; ++n) r.d[n] = a.d[n] * b.v + a.v * b.d[n]; return r; }
+template <int N> HD DualV<N> operator/(const DualV<N>& a, const DualV<N>& b) { DualV<N> r; const double ib = 1.0 / b.v, q = a.v * ib; r.v = q; for (int n = 0; n < N; ++n) r.d[n] = (a.d[n] - q * b.d[n]) * ib; return r; }
+template <int N> HD DualV<N> operator-(const DualV<N>& a) { DualV<N> r; r.v = -a.v; for (int n = 0; n < N; ++n) r.d[n] = -a.d[n]; return r; }
+template <int N> HD DualV<N> operator+(const DualV<N>& a, double b) { DualV<N> r = a; r.v = a.v + b; return r; }
+template <int N> HD DualV<N> operator+(double a, const DualV<N>& b) { DualV<N> r = b; r.v = a + b.v; return r; }
+template <int N> HD DualV<N> operator-(const DualV<N>& a, double b) { DualV<N> r = a; r.v = a.v - b; return r; }
+template <int N> HD DualV<N> operator-(double a, const DualV<N>& b) { DualV<N> r; r.v = a - b.v; for (int n = 0; n < N; ++n) r.d[n] = -b.d[n]; return r; }
+template <int N> HD DualV<N> operator*(const DualV<N>& a, double b) { DualV<N> r; r.v = a.v * b; for (int n = 0; n < N; ++n) r.d[n] = a.d[n] * b; return r; }
+template <int N> HD DualV<N> operator*(double a, const DualV<N>& b) { DualV<N> r; r.v = a * b.v; for (int n = 0; n < N; ++n) r.d[n] = a * b.d[n]; return r; }
+template <int N> HD DualV<N> operator/(const DualV<N>& a, double b) { const double ib = 1.0 / b; DualV<N> r; r.v = a.v * ib; for (int n = 0; n < N; ++n) r.d[n] = a.d[n] * ib; return r; }
+template <int N> HD DualV<N> operator/(double a, const DualV<N>& b) { DualV<N> r; const double q = a / b.v; r.v = q; for (int n = 0; n < N; ++n) r.d[n] = -q * b.d[n] / b.v; return r; }
+template <int N> HD DualV<N> dlog(const DualV<N>& a) { DualV<N> r; r.v = log(a.v); for (int n = 0; n < N; ++n) r.d[n] = a.d[n] / a.v; return r; }
+template <int N> HD DualV<N> dexp(const DualV<N>& a) { DualV<N> r; const double e = exp(a.v); r.v = e; for (int n = 0; n < N; ++n) r.d[n] = a.d[n] * e; return r; }
+template <int N> HD DualV<N> dsqrt(const DualV<N>& a) { DualV<N> r; const double sq = sqrt(a.v); r.v = sq; for (int n = 0; n < N; ++n) r.d[n] = a.v == 0.0 ? 0.0 : a.d[n] / (2.0 * sq); return r; }
+template <int N> HD double val(const DualV<N>& a) { return a.v; }
+template <int N> HD DualV<N> combine(const DualV<N>& a, const DualV<N>& b) { DualV<N> r = b; r.v = a.v; return r; }
+
 // ------------------------------------------------------------------ geometry
 // All 2-D planes share one padded index map: (isd:ied+1, jsd:jed+1), isd = 1-ng, ng = 3.
 struct Geom {
@@ -153,6 +181,21 @@ struct AccAD {
     const Fld& f = s.in[M];
     double t = f.t[(size_t)(tile * f.nk + k - 1 + dk) * c.g.plane + c.g.idx(i, j)];
     return Dual(t, (M == MS && i == si && j == sj && k + dk == sk) ? 1.0 : 0.0);
+  }
+};
+// Joint adjoint accessor: direction M is seeded where input M is read at the thread's own point — for the inputs in
+// `mask` (those whose stencil contains the current output offset) only, which keeps the bookkeeping of the per-input
+// launcher (and of the corner-alias launch that complements it) exact.
+template <class S>
+struct AccADV {
+  const S& s; const Ctx& c; int tile, k; int si, sj, sk;
+  unsigned mask;       // inputs seeded at this offset (bit m = input m)
+  unsigned want;       // outputs needed
+  template <int M> HD DualV<S::NIN> in(int i, int j, int dk = 0) const {
+    const Fld& f = s.in[M];
+    DualV<S::NIN> r(f.t[(size_t)(tile * f.nk + k - 1 + dk) * c.g.plane + c.g.idx(i, j)]);
+    r.d[M] = (((mask >> M) & 1u) && i == si && j == sj && k + dk == sk) ? 1.0 : 0.0;
+    return r;
   }
 };
 #ifdef FV3LM_HOST_EMUL

@@ -118,6 +118,88 @@ HD void body_ad_one(const S& s, const Ctx& c, const Rect& R, int i, int j, int z
   }
   f.p[(size_t)(tile * f.nk + kk - 1) * c.g.plane + c.g.idx(i, j)] += acc;
 }
+// Joint form of the same gather: all inputs of a level class at once.  For every output offset in the union of their
+// boxes the stage is evaluated ONCE with one tangent direction per input (DualV), instead of once per input: the loads,
+// the branches and the common subexpressions of an evaluation are shared, which is what the per-input form spent most
+// of its time on for stages with many inputs (flux assembly, pointwise updates).
+// Level classes: inputs of one class have the same number of levels (npz vs npz+1); kclass_of() names the class.
+template <class S> constexpr int kclass_of(const S*, int) { return 0; }
+template <class S> constexpr bool joint_ad(const S*) { return true; }
+template <class S, int KC>
+HD constexpr Box class_box() {
+  Box u{0, 0, 0, 0, 0, 0}; bool first = true;
+  for (int m = 0; m < S::NIN; ++m) {
+    if (kclass_of((const S*)nullptr, m) != KC || !S::wants(m)) continue;
+    const Box b = S::box(m);
+    if (first) { u = b; first = false; continue; }
+    if (b.di0 < u.di0) u.di0 = b.di0; if (b.di1 > u.di1) u.di1 = b.di1;
+    if (b.dj0 < u.dj0) u.dj0 = b.dj0; if (b.dj1 > u.dj1) u.dj1 = b.dj1;
+    if (b.dk0 < u.dk0) u.dk0 = b.dk0; if (b.dk1 > u.dk1) u.dk1 = b.dk1;
+  }
+  return u;
+}
+template <class S, int KC>
+HD constexpr bool class_any() {
+  for (int m = 0; m < S::NIN; ++m) if (kclass_of((const S*)nullptr, m) == KC && S::wants(m)) return true;
+  return false;
+}
+template <class S, int KC>
+HD void body_ad_joint(const S& s, const Ctx& c, const Rect& R, int i, int j, int z) {
+  if constexpr (class_any<S, KC>()) {
+    constexpr int N = S::NIN;
+    int nk = 0;
+#pragma unroll
+    for (int m = 0; m < N; ++m) if (kclass_of((const S*)nullptr, m) == KC && S::wants(m) && s.in[m].p && nk == 0) nk = s.in[m].nk;
+    if (nk == 0 || z >= c.g.ntile * nk) return;
+    const int tile = z / nk, kk = 1 + z % nk;
+    constexpr Box ub = class_box<S, KC>();
+    if (i < R.i0 + ub.di0 || i > R.i1 + ub.di1 || j < R.j0 + ub.dj0 || j > R.j1 + ub.dj1) return;
+    double acc[N];
+#pragma unroll
+    for (int m = 0; m < N; ++m) acc[m] = 0.0;
+#pragma unroll
+    for (int dk = ub.dk0; dk <= ub.dk1; ++dk) {
+      const int k = kk - dk;
+      if (k < s.k0 || k > s.k1) continue;
+#pragma unroll
+      for (int dj = ub.dj0; dj <= ub.dj1; ++dj) {
+        const int oj = j - dj;
+        if (oj < R.j0 || oj > R.j1) continue;
+#pragma unroll
+        for (int di = ub.di0; di <= ub.di1; ++di) {
+          const int oi = i - di;
+          if (oi < R.i0 || oi > R.i1) continue;
+          unsigned mask = 0u, want = 0u;
+#pragma unroll
+          for (int m = 0; m < N; ++m) {
+            const Box b = S::box(m);
+            if (kclass_of((const S*)nullptr, m) == KC && S::wants(m) && di >= b.di0 && di <= b.di1 && dj >= b.dj0 && dj <= b.dj1 && dk >= b.dk0 &&
+                dk <= b.dk1 && S::uses(m, di, dj, dk)) { mask |= 1u << m; want |= S::wants(m); }
+          }
+          if (!mask) continue;
+          AccADV<S> a{s, c, tile, k, i, j, kk, mask, want};
+          DualV<N> o[S::NOUT];
+          s.template eval<DualV<N>>(a, c, tile, oi, oj, k, o);
+#pragma unroll
+          for (int n = 0; n < S::NOUT; ++n)
+            if (((want >> n) & 1u) && s.orect[n].has(oi, oj)) {
+              const double oa = s.out[n].p[(size_t)(tile * s.out[n].nk + k - 1) * c.g.plane + c.g.idx(oi, oj)];
+#pragma unroll
+              for (int m = 0; m < N; ++m) if (((mask >> m) & 1u) && ((S::wants(m) >> n) & 1u)) acc[m] += o[n].d[m] * oa;
+            }
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < N; ++m)
+      if (kclass_of((const S*)nullptr, m) == KC && S::wants(m) && s.in[m].p) {
+        const Box b = S::box(m);
+        if (!(i < R.i0 + b.di0 || i > R.i1 + b.di1 || j < R.j0 + b.dj0 || j > R.j1 + b.dj1))
+          s.in[m].p[(size_t)(tile * nk + kk - 1) * c.g.plane + c.g.idx(i, j)] += acc[m];
+      }
+  }
+}
+
 // Corner-halo reads through an index map (edges.h): input point (i,j) is also read at its alias
 // locations.  Outputs reached only that way are added here, by a second, small launch over the points
 // around the four face corners (the main kernel keeps its fully unrolled fast path).  mask = outputs of
@@ -192,6 +274,11 @@ template <class S, int M>
 struct AdLoop<S, M, true> {
   HD static void run(const S&, const Ctx&, const Rect&, int, int, int, int) {}
 };
+template <class S>
+HD void ad_point(const S& s, const Ctx& c, const Rect& R, int i, int j, int z, int nkmax) {
+  if constexpr (joint_ad((const S*)nullptr)) { body_ad_joint<S, 0>(s, c, R, i, j, z); body_ad_joint<S, 1>(s, c, R, i, j, z); }
+  else AdLoop<S, 0>::run(s, c, R, i, j, z, nkmax);
+}
 
 template <class S>
 inline Rect ad_input_rect(const S& s, const Ctx& c, const Rect& R) {
@@ -253,7 +340,7 @@ __global__ void __launch_bounds__(BX* BY) k_stage_tl(S s, Ctx c, Rect R, int tr)
 template <class S>
 __global__ void __launch_bounds__(BX* BY) k_stage_ad(S s, Ctx c, Rect R, Rect Q, int nkmax, int tr) {
   int i, j, bx = blockIdx.x, by = blockIdx.y; xcd_block(gridDim.x, gridDim.y, bx, by); thread_point(Q, tr, bx, by, threadIdx.x, threadIdx.y, i, j);
-  if (i <= Q.i1 && j <= Q.j1) AdLoop<S, 0>::run(s, c, R, i, j, blockIdx.z, nkmax);
+  if (i <= Q.i1 && j <= Q.j1) ad_point(s, c, R, i, j, blockIdx.z, nkmax);
 }
 template <class S>
 __global__ void __launch_bounds__(64) k_stage_ad_alias(S s, Ctx c, Rect R) {
@@ -348,7 +435,7 @@ void run_ad(Exec& ex, const S& s, const Ctx& c) {
   for (int m = 0; m < S::NIN; ++m) if (s.in[m].nk > nkmax) nkmax = s.in[m].nk;
   for (int z = 0; z < c.g.ntile * nkmax; ++z)
     for (int j = Q.j0; j <= Q.j1; ++j)
-      for (int i = Q.i0; i <= Q.i1; ++i) AdLoop<S, 0>::run(s, c, R, i, j, z, nkmax);
+      for (int i = Q.i0; i <= Q.i1; ++i) ad_point(s, c, R, i, j, z, nkmax);
   if constexpr (S::NALIAS > 0) if (c.g.face)
     for (int z = 0; z < c.g.ntile * nkmax; ++z)
       for (int cn = 0; cn < 4; ++cn)

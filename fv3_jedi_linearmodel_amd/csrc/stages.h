@@ -1012,6 +1012,10 @@ struct OneGradP {
   }
 };
 
+// level classes for the joint adjoint (exec.h): pkc/gz and pk_b/gz_b carry npz+1 levels, the winds npz
+constexpr int kclass_of(const PGradC*, int M) { return M < 2 ? 1 : 0; }
+constexpr int kclass_of(const OneGradP*, int M) { return M < 2 ? 0 : 1; }
+
 // inputs that only the face-edge formulas of a stage read (bit m = input m): not given to the bulk launch
 template <class D> constexpr unsigned edge_only_inputs(const D*) { return 0u; }
 constexpr unsigned edge_only_inputs(const CswKeVortD*) { return 0x30u; }
