@@ -120,8 +120,20 @@ def main():
                     t.copy_(torch.tensor(list(data), dtype=torch.uint8))
                 dist.broadcast(t, src=0)
                 return bytes(t.cpu().tolist())
-            comm_init_rccl(lib, rank, world, bcast)
-        active = len(cube.faces_of(rank, world)) > 0     # ranks beyond the sixth have no face
+            nact = min(world, 6)                          # ranks beyond the sixth have no face and stay out of the communicator
+            if rank < nact:
+                comm_init_rccl(lib, rank, nact, bcast)
+            else:
+                bcast(None)
+            grp = dist.new_group(ranks=list(range(nact)))
+            if rank < nact:
+                from fv3_jedi_linearmodel_amd._lib import set_allreduce_callback
+                def allmax(buf):                          # tracer_2d's max Courant number per level over all faces
+                    t = torch.from_numpy(buf.copy()).cuda()
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=grp)
+                    buf[:] = t.cpu().numpy()
+                set_allreduce_callback(lib, allmax)
+        active = len(cube.faces_of(rank, world)) > 0
         if active:
             c = CubeCase(n=args.nx, npz=args.npz, n_split=args.n_split, k_split=args.k_split, dt=args.dt, backend="hip", nq=args.nq,
                          rank=rank, world=world)

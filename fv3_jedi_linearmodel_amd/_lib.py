@@ -84,6 +84,20 @@ def comm_init_rccl(lib, rank, world, broadcast_bytes):
         raise Fv3LmError(lib.err())
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, _dp, C.c_int)
+
+
+def set_allreduce_callback(lib, fn):
+    """fn(buf: numpy view) must replace buf by its element-wise max over the ranks that hold faces (tracer_2d's
+    mp_reduce_max of the per-level Courant numbers, fv_tracer2d_tlm.F90:1306).  Not needed with one rank."""
+    def tramp(user, buf, n):
+        fn(np.ctypeslib.as_array(buf, shape=(n,)))
+    cb = ALLREDUCE_FN(tramp)
+    lib._allreduce_cb = cb
+    lib.L.fv3lm_set_allreduce_callback.argtypes = [ALLREDUCE_FN, C.c_void_p]
+    lib.L.fv3lm_set_allreduce_callback(cb, None)
+
+
 def set_transport_callback(lib, fn):
     """fn(peers, sendbufs, recvbufs): lists of numpy views (host memory in the emulation build).  Test transports (gloo)."""
     def tramp(user, npeers, peers, sb, sc, rb, rc):

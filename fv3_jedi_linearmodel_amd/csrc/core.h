@@ -140,6 +140,8 @@ struct LevelParams {
   int hord_mt, hord_vt, hord_tm, hord_dp, hord_tr;
   int nord, nord_v, nord_w, nord_t, nord_v_pert;
   double d2_divg, damp_vt, damp_w, damp_t, d_con, damp_vt_pert;
+  // tracer_2d sub-cycling of the current call (fv_tracer2d_tlm.F90:1306-1345): sub-steps this level takes and 1/that
+  int tr_ksplt = 1; double tr_frac = 1.0;
 };
 
 // Point context handed to every stage evaluation.
@@ -148,6 +150,7 @@ struct Ctx {
   Metrics m;
   const LevelParams* lev;   // [npz]
   int nlev;                 // levels per tile in this launch
+  int tr_it = 1;            // tracer_2d: current sub-step (levels with tr_ksplt < tr_it are done)
   HD int mi(int tile, int i, int j) const { return tile * g.plane + g.idx(i, j); }
 };
 

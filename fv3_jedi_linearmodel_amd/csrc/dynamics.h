@@ -72,9 +72,30 @@ struct CmaxFn {
   }
 };
 
+// dp1 <- dp2 between sub-steps for the levels still sub-cycling (fv_tracer2d_tlm.F90:1431-1437)
+struct TrDp1Fn {
+  Geom g; Fld dp1, dp2; const LevelParams* lev; int it, mode;
+  HD void operator()(int i, int j, int z) const {
+    const int k = 1 + z % g.npz;
+    if (it > lev[k - 1].tr_ksplt) return;
+    const size_t n = (size_t)z * g.plane + g.idx(i, j);
+    if (mode == MODE_AD) { dp2.p[n] += dp1.p[n]; dp1.p[n] = 0.; return; }
+    dp1.t[n] = dp2.t[n];
+    if (mode == MODE_TL) dp1.p[n] = dp2.p[n];
+  }
+};
+typedef void (*fv3lm_allreduce_fn)(void* user, double* buf, int n);   // in-place max over ranks (host buffer)
+struct AllReduce { fv3lm_allreduce_fn cb = nullptr; void* user = nullptr; };
+inline AllReduce& allreduce_max_hook() { static AllReduce a; return a; }
+
 struct Dynamics : Dycore {
   Arena tshared, twork;
-  Program tracer_pre, tracer_q, pt_in;
+  Program tracer_scale, tracer_pre, tracer_q, pt_in;
+  Fld tr_dp2;
+  int cur_km = 0;                                   // k_split iteration being run (tracer checkpoints are per iteration)
+  std::vector<std::vector<int>> tr_ksplt_km;        // per k_split iteration: sub-steps per level, from the forward sweep
+  std::vector<int> tr_nsplt_km;
+  std::map<long, double*> sub_ck;                   // sub-step checkpoints (nsplt > 1 only): key (km, it, field)
   std::vector<Fld> q;
   Fld dp1, qc, qc_o, pe2, pu_ad, pv_ad;
   double *ak_dev = nullptr, *bk_dev = nullptr, *remap_ws = nullptr, *cmax_dev = nullptr;
@@ -91,6 +112,13 @@ struct Dynamics : Dycore {
   RemapArgs remap_args(bool last_step);
   void pressures(int mode);
   void tracer_fwd(int mode);
+  void set_tracer_levels(const std::vector<int>& ksplt);
+  double* subck(int km, int it, int n) {
+    const long key = ((long)km * 64 + it) * 64 + n;
+    auto f_ = sub_ck.find(key);
+    if (f_ != sub_ck.end()) return f_->second;
+    double* p = (double*)dev_alloc(n3 * 8); sub_ck[key] = p; return p;
+  }
   void tracer_ad();
   void fv_dynamics(int mode);
   void step_tl() { pressures(MODE_TL); fv_dynamics(MODE_TL); }
@@ -116,7 +144,8 @@ inline bool Dynamics::init2(const double* ak, const double* bk) {
   pe2 = S("pe2", npz + 1); pu_ad = S("pu_ad", npz + 1); pv_ad = S("pv_ad", npz + 1);
   remap_ws = (double*)dev_alloc((size_t)REMAP_WS_SLOTS * (npz + 2) * g.ntile * g.plane * 8);
   cmax_dev = (double*)dev_alloc((size_t)g.ntile * npz * 8);
-  tshared.init(n3 * 6); twork.init(n3 * 10);
+  tshared.init(n3 * 10); twork.init(n3 * 10);
+  tr_ksplt_km.assign(k_split, std::vector<int>(npz, 1)); tr_nsplt_km.assign(k_split, 1);
   build_tracer();
   { DynPtIn s; s.in[0] = f("pt"); s.in[1] = nq > 0 ? q[0] : Fld{}; if (!s.in[1].t) s.in[1].nk = npz; s.in[2] = f("pkz"); s.out[0] = f("pt_o");
     s.orect[0] = R(1, g.nx, 1, g.ny); s.k1 = npz; s.zvir = opt.zvir; s.has_q = nq > 0; add(pt_in, "pt_in", s); }
@@ -129,24 +158,37 @@ inline void Dynamics::destroy2() {
   dev_free(ak_dev); dev_free(bk_dev); dev_free(remap_ws); dev_free(cmax_dev); dev_free(ck_k); dev_free(ck_0);
   tshared.destroy(); twork.destroy();
   for (double* p : snap) dev_free(p);
+  for (auto& kv : sub_ck) dev_free(kv.second);
 }
 
 inline void Dynamics::build_tracer() {
   const int is = 1, ie = g.nx, js = 1, je = g.ny, isd = g.isd(), ied = g.ied(), jsd = g.jsd(), jed = g.jed(), npz = g.npz;
   auto TS = [&](const char* n) { Fld x = tshared.take((size_t)g.ntile * npz * g.plane, npz); F[n] = x; return x; };
   Fld xfx = TS("tr_xfx"), yfx = TS("tr_yfx"), dp2 = TS("tr_dp2"), rax = TS("tr_rax"), ray = TS("tr_ray");
+  Fld cxs = TS("tr_cxs"), cys = TS("tr_cys"), mfxs = TS("tr_mfxs"), mfys = TS("tr_mfys");
+  tr_dp2 = dp2;
   Fld cx = f("cx"), cy = f("cy"), mfx = f("mfx"), mfy = f("mfy");
-  { TrFlux s; s.in[0] = cx; s.in[1] = cy; s.out[0] = xfx; s.out[1] = yfx; s.orect[0] = R(is, ie + 1, jsd, jed); s.orect[1] = R(isd, ied, js, je + 1);
-    s.k1 = npz; add(tracer_pre, "tracer", s); }
-  { TrDp2Ra s; s.in[0] = dp1; s.in[1] = mfx; s.in[2] = mfy; s.in[3] = xfx; s.in[4] = yfx; s.out[0] = dp2; s.out[1] = rax; s.out[2] = ray;
+  // once per call: scaled Courant numbers / mass fluxes and the area fluxes
+  { TrScale s; s.in[0] = cx; s.in[1] = cy; s.in[2] = mfx; s.in[3] = mfy; s.out[0] = cxs; s.out[1] = cys; s.out[2] = mfxs; s.out[3] = mfys;
+    s.orect[0] = R(is, ie + 1, jsd, jed); s.orect[1] = R(isd, ied, js, je + 1); s.orect[2] = R(is, ie + 1, js, je); s.orect[3] = R(is, ie, js, je + 1);
+    s.k1 = npz; add(tracer_scale, "tracer", s); }
+  { TrFlux s; s.in[0] = cxs; s.in[1] = cys; s.out[0] = xfx; s.out[1] = yfx; s.orect[0] = R(is, ie + 1, jsd, jed); s.orect[1] = R(isd, ied, js, je + 1);
+    s.k1 = npz; add(tracer_scale, "tracer", s); }
+  // once per sub-step
+  { TrDp2Ra s; s.in[0] = dp1; s.in[1] = mfxs; s.in[2] = mfys; s.in[3] = xfx; s.in[4] = yfx; s.out[0] = dp2; s.out[1] = rax; s.out[2] = ray;
     s.orect[0] = R(is, ie, js, je); s.orect[1] = R(is, ie, jsd, jed); s.orect[2] = R(isd, ied, js, je); s.k1 = npz; add(tracer_pre, "tracer", s); }
-  // per-tracer program on the staging field qc -> qc_o, work arrays in twork
+  // per tracer and sub-step, on the staging field qc -> qc_o, work arrays in twork
   Arena save = work; work = twork;
   Fld fx = W("tr_fx", npz), fy = W("tr_fy", npz);
-  build_tp(tracer_q, "tracer", "tpq", qc, cx, cy, xfx, yfx, rax, ray, mfx, mfy, Fld{}, HORD_TR, DAMP_NONE, false, fx, fy);
+  build_tp(tracer_q, "tracer", "tpq", qc, cxs, cys, xfx, yfx, rax, ray, mfxs, mfys, Fld{}, HORD_TR, DAMP_NONE, false, fx, fy);
   { TrUpdate s; s.in[0] = qc; s.in[1] = dp1; s.in[2] = dp2; s.in[3] = fx; s.in[4] = fy; s.out[0] = qc_o; s.orect[0] = R(is, ie, js, je); s.k1 = npz;
     add(tracer_q, "tracer", s); }
   twork = work; work = save;
+}
+
+inline void Dynamics::set_tracer_levels(const std::vector<int>& ksplt) {
+  for (int k = 0; k < g.npz; ++k) { lev_host[k].tr_ksplt = ksplt[k]; lev_host[k].tr_frac = 1. / double(ksplt[k]); }
+  h2d(ex, lev_dev, lev_host.data(), sizeof(LevelParams) * g.npz);
 }
 
 inline RemapArgs Dynamics::remap_args(bool last_step) {
@@ -163,43 +205,79 @@ inline void Dynamics::pressures(int mode) {
   for_points(ex, Rect{1, g.nx, 1, g.ny}, g.ntile, PressFn{a, mode}, "pressures");
 }
 
-// tracer_2d forward (nonlinear or tangent); q halos must be valid
+// tracer_2d forward (nonlinear or tangent); q halos must be valid.  The sub-step count comes from the trajectory's maximum
+// Courant number per level over all faces and ranks (fv_tracer2d_tlm.F90:1248-1317).
 inline void Dynamics::tracer_fwd(int mode) {
   const size_t b3 = n3 * 8;
-  run_group(tracer_pre, nullptr, mode);
-  if (mode == MODE_NL || mode == MODE_TL) {   // nsplt from the trajectory's max Courant number
-    dev_zero(ex, cmax_dev, (size_t)g.ntile * g.npz * 8);
-    for_points(ex, Rect{1, g.nx, 1, 1}, g.ntile * g.npz, CmaxFn{g, f("cx"), f("cy"), ctx.m.sin_sg[5], cmax_dev}, "tracer_cmax");
-    std::vector<double> cm((size_t)g.ntile * g.npz);
+  const int npz = g.npz, km = cur_km;
+  {
+    dev_zero(ex, cmax_dev, (size_t)g.ntile * npz * 8);
+    for_points(ex, Rect{1, g.nx, 1, 1}, g.ntile * npz, CmaxFn{g, f("cx"), f("cy"), ctx.m.sin_sg[5], cmax_dev}, "tracer_cmax");
+    std::vector<double> cm((size_t)g.ntile * npz), cl(npz, 0.);
     d2h(ex, cm.data(), cmax_dev, cm.size() * 8);
-    double cg = 0.; for (double c : cm) if (!(c < cg)) cg = c;
+    for (int t = 0; t < g.ntile; ++t) for (int k = 0; k < npz; ++k) if (cl[k] < cm[(size_t)t * npz + k]) cl[k] = cm[(size_t)t * npz + k];
+    if (allreduce_max_hook().cb) allreduce_max_hook().cb(allreduce_max_hook().user, cl.data(), npz);
+    double cg = 0.; for (double c : cl) if (!(c < cg)) cg = c;
     const int nsplt = int(1. + cg);
+    std::vector<int> ks(npz, 1);
+    if (nsplt != 1) for (int k = 0; k < npz; ++k) ks[k] = int(1. + cl[k]);
+    if (nsplt > 60) { tracer_subcycle_error = true; return; }
+    tr_ksplt_km[km] = ks; tr_nsplt_km[km] = nsplt;
     if (nsplt > nsplt_max) nsplt_max = nsplt;
-    if (nsplt != 1) tracer_subcycle_error = true;   // sub-cycled tracer transport (nsplt > 1) not built yet
   }
-  for (int n = 0; n < nq; ++n) {
-    dev_copy(ex, qc.t, q[n].t, b3);
-    if (mode == MODE_TL) dev_copy(ex, qc.p, q[n].p, b3);
-    run_group(tracer_q, nullptr, mode);
-    dev_copy(ex, q[n].t, qc_o.t, b3);
-    if (mode == MODE_TL) dev_copy(ex, q[n].p, qc_o.p, b3);
+  const int nsplt = tr_nsplt_km[km];
+  set_tracer_levels(tr_ksplt_km[km]);
+  run_group(tracer_scale, nullptr, mode);
+  for (int it = 1; it <= nsplt; ++it) {
+    ctx.tr_it = it;
+    if (mode == MODE_NL && nsplt > 1) {     // trajectory of the later sub-steps for the backward sweep
+      dev_copy(ex, subck(km, it, nq), dp1.t, b3);
+      for (int n = 0; n < nq; ++n) dev_copy(ex, subck(km, it, n), q[n].t, b3);
+    }
+    run_group(tracer_pre, nullptr, mode);
+    for (int n = 0; n < nq; ++n) {
+      dev_copy(ex, qc.t, q[n].t, b3);
+      if (mode == MODE_TL) dev_copy(ex, qc.p, q[n].p, b3);
+      run_group(tracer_q, nullptr, mode);
+      dev_copy(ex, q[n].t, qc_o.t, b3);
+      if (mode == MODE_TL) dev_copy(ex, q[n].p, qc_o.p, b3);
+    }
+    if (it != nsplt) {
+      for_points(ex, Rect{1, g.nx, 1, g.ny}, g.ntile * npz, TrDp1Fn{g, dp1, tr_dp2, lev_dev, it, mode}, "tracer_dp1");
+      for (int n = 0; n < nq; ++n) halo(mode, H_CELL, q[n]);
+    }
   }
+  ctx.tr_it = 1;
 }
 // adjoint: trajectory of dp1, mfx..cy and the pre-transport q[n] must be in place; q[n].p holds the
 // adjoint of the transported tracers on entry, of the inputs on exit; mfx..cy.p, dp1.p accumulate.
 inline void Dynamics::tracer_ad() {
   const size_t b3 = n3 * 8;
-  run_group(tracer_pre, nullptr, MODE_NL);
+  const int npz = g.npz, km = cur_km, nsplt = tr_nsplt_km[km];
+  set_tracer_levels(tr_ksplt_km[km]);
+  run_group(tracer_scale, nullptr, MODE_NL);
   dev_zero(ex, tshared.p, tshared.used * 8);
-  for (int n = nq - 1; n >= 0; --n) {
-    dev_copy(ex, qc.t, q[n].t, b3);
-    run_group(tracer_q, nullptr, MODE_NL);
-    dev_zero(ex, twork.p, twork.used * 8);
-    dev_copy(ex, qc_o.p, q[n].p, b3); dev_zero(ex, qc.p, b3);
-    run_group(tracer_q, nullptr, MODE_AD);
-    dev_copy(ex, q[n].p, qc.p, b3);
+  for (int it = nsplt; it >= 1; --it) {
+    ctx.tr_it = it;
+    if (it != nsplt) {
+      for (int n = nq - 1; n >= 0; --n) halo(MODE_AD, H_CELL, q[n]);
+      for_points(ex, Rect{1, g.nx, 1, g.ny}, g.ntile * npz, TrDp1Fn{g, dp1, tr_dp2, lev_dev, it, MODE_AD}, "tracer_dp1");
+    }
+    if (nsplt > 1) dev_copy(ex, dp1.t, subck(km, it, nq), b3);
+    run_group(tracer_pre, nullptr, MODE_NL);
+    for (int n = nq - 1; n >= 0; --n) {
+      dev_copy(ex, qc.t, nsplt > 1 ? subck(km, it, n) : q[n].t, b3);
+      run_group(tracer_q, nullptr, MODE_NL);
+      dev_zero(ex, twork.p, twork.used * 8);
+      dev_copy(ex, qc_o.p, q[n].p, b3); dev_zero(ex, qc.p, b3);
+      run_group(tracer_q, nullptr, MODE_AD);
+      dev_copy(ex, q[n].p, qc.p, b3);
+    }
+    run_group(tracer_pre, nullptr, MODE_AD);
+    if (it != 1) for (const char* nm : {"tr_dp2", "tr_rax", "tr_ray"}) dev_zero(ex, f(nm).p, b3);   // per-sub-step adjoints
   }
-  run_group(tracer_pre, nullptr, MODE_AD);
+  run_group(tracer_scale, nullptr, MODE_AD);
+  ctx.tr_it = 1;
 }
 
 inline void Dynamics::fv_dynamics(int mode) {
@@ -213,7 +291,7 @@ inline void Dynamics::fv_dynamics(int mode) {
       halo(mode, H_DVEC, f("u"), f("v")); halo(mode, H_CELL, f("delp")); halo(mode, H_CELL, f("pt"));
       dev_copy(ex, dp1.t, f("delp").t, b3);
       if (mode == MODE_TL) dev_copy(ex, dp1.p, f("delp").p, b3);
-      ck_base = km * n_split;
+      ck_base = km * n_split; cur_km = km;
       dyn_core(mode);
       if (nq > 0) {
         for (int n = 0; n < nq; ++n) halo(mode, H_CELL, q[n]);
@@ -256,6 +334,7 @@ inline void Dynamics::fv_dynamics(int mode) {
       for (int n = 0; n < nq; ++n) dev_copy(ex, q[n].t, ckq(km, n), b3);
       for (int n = 0; n < 4; ++n) dev_copy(ex, f(mf[n]).t, ckm(km, n), b3);
       dev_copy(ex, dp1.t, ckpt + ((size_t)(km * n_split) * 4 + 2) * n3, b3);   // delp at the start of this k_split step
+      cur_km = km;
       tracer_ad();
       for (int n = 0; n < nq; ++n) halo(MODE_AD, H_CELL, q[n]);
     }

@@ -65,7 +65,7 @@ int fv3lm_field_get(fv3lm_handle* h, const char* name, int which, double* host) 
 // sticky conditions a sweep may have run into
 static int status(fv3lm_handle* h) {
   if (h->d.halo_missing) return fail("halo exchange needed before fv3lm_set_exchange provided its table (face mode)");
-  if (h->d.tracer_subcycle_error) return fail("tracer_2d: max Courant number >= 1 needs sub-cycling (nsplt > 1), not built yet");
+  if (h->d.tracer_subcycle_error) return fail("tracer_2d: accumulated Courant number > 60: trajectory is not usable");
   return 0;
 }
 int fv3lm_set_face_data(fv3lm_handle* h, const double* edge, const double* ecorner) {
@@ -114,6 +114,7 @@ int fv3lm_comm_destroy(void) {
 #endif
   return 0;
 }
+int fv3lm_set_allreduce_callback(fv3lm_allreduce_fn fn, void* user) { allreduce_max_hook().cb = fn; allreduce_max_hook().user = user; return 0; }
 int fv3lm_set_transport_callback(fv3lm_transport_fn fn, void* user) { transport().cb = fn; transport().user = user; return 0; }
 int fv3lm_halo(fv3lm_handle* h, int kind, const char* name0, const char* name1, int mode) {
   if (mode < 0 || mode > 2 || kind < 0 || kind >= H_NKIND) return fail("bad mode or kind");
@@ -140,6 +141,7 @@ int fv3lm_tracer_2d(fv3lm_handle* h, int mode) {
   if (mode == MODE_AD) h->d.tracer_ad(); else h->d.tracer_fwd(mode);
   return status(h);
 }
+int fv3lm_tracer_nsplt(fv3lm_handle* h) { return h->d.nsplt_max; }   /* largest sub-step count tracer_2d has used so far */
 int fv3lm_remap(fv3lm_handle* h, int mode, int last_step) { run_remap(h->d.ex, mode, h->d.remap_args(last_step != 0)); return 0; }
 int fv3lm_fv_dynamics(fv3lm_handle* h, int mode) { h->d.fv_dynamics(mode); return status(h); }
 int fv3lm_step_tl(fv3lm_handle* h) { h->d.step_tl(); return status(h); }

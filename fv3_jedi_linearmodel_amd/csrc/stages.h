@@ -934,6 +934,21 @@ struct DswUpdateUV {
 };
 
 // ===================================================================== tracer_2d (fv_tracer2d_tlm.F90:1148-1446)
+// Sub-cycling: Courant numbers and mass fluxes of a level are divided by the number of sub-steps it takes
+// (fv_tracer2d_tlm.F90:1318-1345; the count comes from the trajectory only).  Scaled copies: the accumulators stay intact.
+struct TrScale {
+  STAGE_COMMON("TrScale", 4, 4)   // in: cx cy mfx mfy   out: cxs cys mfxs mfys
+  HD static constexpr Box box(int) { return Box{0, 0, 0, 0, 0, 0}; }
+  template <class T, class A>
+  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+    const double f = c.lev[k - 1].tr_frac;
+    o[0] = o[1] = o[2] = o[3] = T(0.);
+    if (orect[0].has(i, j)) o[0] = IN(0, i, j) * f;
+    if (orect[1].has(i, j)) o[1] = IN(1, i, j) * f;
+    if (orect[2].has(i, j)) o[2] = IN(2, i, j) * f;
+    if (orect[3].has(i, j)) o[3] = IN(3, i, j) * f;
+  }
+};
 struct TrFlux {   // accumulated Courant numbers -> area fluxes (:1226-1247)
   STAGE_COMMON("TrFlux", 2, 2)   // in: cx cy   out: xfx yfx
   HD static constexpr Box box(int) { return Box{0, 0, 0, 0, 0, 0}; }
@@ -967,6 +982,7 @@ struct TrUpdate {   // q update (:1423-1430)
   HD static constexpr Box box(int M) { return M == 3 ? Box{0, 1, 0, 0, 0, 0} : M == 4 ? Box{0, 0, 0, 1, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+    if (c.tr_it > c.lev[k - 1].tr_ksplt) { o[0] = IN(0, i, j); return; }   // this level has finished its sub-steps (:1361)
     o[0] = (IN(0, i, j) * IN(1, i, j) + (IN(3, i, j) - IN(3, i + 1, j) + (IN(4, i, j) - IN(4, i, j + 1))) * MET(rarea, i, j)) / IN(2, i, j);
   }
 };

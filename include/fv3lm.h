@@ -114,6 +114,7 @@ int fv3lm_step_ad(fv3lm_handle* h);
 /* Sub-operators, same mode argument (tests and kernel-level benchmarks): */
 int fv3lm_pressures(fv3lm_handle* h, int mode);                 /* compute_fv3_pressures{,_tlm,_bwd} TLM/fv_pressure.F90 */
 int fv3lm_tracer_2d(fv3lm_handle* h, int mode);                 /* TRACER_2D_TLM fv_tracer2d_tlm.F90:757 / _FWD+_BWD */
+int fv3lm_tracer_nsplt(fv3lm_handle* h);                        /* largest tracer sub-step count (nsplt, fv_tracer2d_tlm.F90:1317) used so far */
 int fv3lm_remap(fv3lm_handle* h, int mode, int last_step);      /* LAGRANGIAN_TO_EULERIAN_TLM fv_mapz_tlm.F90:69 / _FWD+_BWD */
 int fv3lm_fv_dynamics(fv3lm_handle* h, int mode);               /* FV_DYNAMICS_TLM fv_dynamics_tlm.F90:87 / _FWD+_BWD */
 /* Per-kernel HIP-event profile of everything launched between begin and end, on the library's stream:

@@ -369,6 +369,25 @@ void orc_cube_dyn_core(void* cv, int mode, double bdt, int n_split, double** in_
     }
   });
 }
+// tracer_2d on the cube (global sub-cycling count, halo exchange between sub-steps).  in: dp1, mfx, mfy, cx, cy, q[nq]   out: q[nq]
+void orc_cube_tracer_2d(void* cv, int mode, int nq, double** in_t, double** in_p, double** out_t, double** out_p) {
+  OrcCube* c = (OrcCube*)cv; OrcHandle* h = c->f[0]; const int npz = h->npz;
+  const size_t np = (size_t)h->bd.pi() * h->bd.pj();
+  std::vector<int> nk(5 + nq, npz), nko(nq, npz);
+  auto in = mkio6(5 + nq, in_t, in_p, nk.data(), np); auto out = mkio6(nq, out_t, out_p, nko.data(), np);
+  drive(mode, h->bd, in, out, [&](auto& x, auto& y) {
+    using T = typename std::decay<decltype(x[0].p[0].d[0])>::type;
+    std::vector<DynState<T>> S(6); std::vector<Arr3<T>> dp1(6);
+    for (int t = 0; t < 6; ++t) {
+      S[t].init(h->bd, npz, nq);
+      dp1[t] = x[0 * 6 + t]; S[t].mfx = x[1 * 6 + t]; S[t].mfy = x[2 * 6 + t]; S[t].cx = x[3 * 6 + t]; S[t].cy = x[4 * 6 + t];
+      for (int n = 0; n < nq; ++n) S[t].q[n] = x[(5 + n) * 6 + t];
+    }
+    tracer_2d_cube(S, dp1, npz, h->o.hord_tr, c->G, h->bd, c->X);
+    for (int t = 0; t < 6; ++t) for (int n = 0; n < nq; ++n) y[n * 6 + t] = S[t].q[n];
+  });
+}
+
 // fv_dynamics on the cube.  in: u, v, pt(=T), delp, pe, peln, pk (npz+1), pkz, q[nq]   out: u, v, pt(=T), delp, q[nq]
 void orc_cube_fv_dynamics(void* cv, int mode, int nq, double bdt, int n_split, int k_split, double** in_t, double** in_p,
                           double** out_t, double** out_p) {

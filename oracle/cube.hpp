@@ -86,6 +86,56 @@ void dyn_core_cube(std::vector<DynState<T>>& S, const std::vector<Arr2<double>>&
   }
 }
 
+// tracer_2d on all faces: the sub-cycling count comes from the maximum Courant number over the whole cube
+// (mp_reduce_max, fv_tracer2d_tlm.F90:1306) and the tracer halos are exchanged between sub-steps (:1440-1444), so the
+// faces advance sub-step by sub-step together.
+template <class T>
+void tracer_2d_cube(std::vector<DynState<T>>& S, std::vector<Arr3<T>>& dp1, int npz, int hord, const std::vector<Grid>& G, const Bounds& bd,
+                    const CubeTables& X) {
+  const int nt = (int)S.size();
+  std::vector<double> cmax(npz + 1, 0.), loc;
+  for (int t = 0; t < nt; ++t) {
+    tracer_2d(S[t].q, dp1[t], S[t].mfx, S[t].mfy, S[t].cx, S[t].cy, npz, hord, G[t], bd, nullptr, nullptr, &loc);
+    for (int k = 1; k <= npz; ++k) cmax[k] = std::max(cmax[k], loc[k]);
+  }
+  double cg = cmax[1];
+  for (int k = 2; k <= npz; ++k) if (!(cmax[k] < cg)) cg = cmax[k];
+  const int nsplt = int(1. + cg);
+  if (nsplt == 1) {
+    for (int t = 0; t < nt; ++t) tracer_2d(S[t].q, dp1[t], S[t].mfx, S[t].mfy, S[t].cx, S[t].cy, npz, hord, G[t], bd, nullptr, &cmax);
+    return;
+  }
+  // nsplt > 1: run the per-face routine one sub-step at a time so that the halo exchange can sit between sub-steps.
+  // Its scaling of cx, cy, mfx, mfy by 1/ksplt is applied once here; each call below then sees Courant numbers < 1 per
+  // level and does exactly one sub-step (ksplt levels that are already done are masked by restoring them afterwards).
+  std::vector<int> ksplt(npz + 1, 1);
+  for (int k = 1; k <= npz; ++k) ksplt[k] = int(1. + cmax[k]);
+  for (int t = 0; t < nt; ++t)
+    for (int k = 1; k <= npz; ++k) {
+      const double frac = 1. / double(ksplt[k]);
+      for (auto* a : {&S[t].cx, &S[t].cy, &S[t].mfx, &S[t].mfy}) for (auto& x : a->plane(k).d) x = x * frac;
+    }
+  std::vector<double> one(npz + 1, 0.);     // scaled Courant numbers: a single sub-step per call
+  for (int it = 1; it <= nsplt; ++it) {
+    for (int t = 0; t < nt; ++t) {
+      std::vector<Arr3<T>> q0 = S[t].q; Arr3<T> dp0 = dp1[t];
+      tracer_2d(S[t].q, dp1[t], S[t].mfx, S[t].mfy, S[t].cx, S[t].cy, npz, hord, G[t], bd, nullptr, &one);
+      for (int k = 1; k <= npz; ++k) {
+        if (it > ksplt[k]) { for (size_t n = 0; n < q0.size(); ++n) S[t].q[n].plane(k) = q0[n].plane(k); dp1[t].plane(k) = dp0.plane(k); continue; }
+        if (it != nsplt)      // dp1 = dp2 (fv_tracer2d_tlm.F90:1431-1437)
+          for (int j = bd.js; j <= bd.je; ++j)
+            for (int i = bd.is; i <= bd.ie; ++i)
+              dp1[t](i, j, k) = dp0(i, j, k) + (S[t].mfx(i, j, k) - S[t].mfx(i + 1, j, k) + (S[t].mfy(i, j, k) - S[t].mfy(i, j + 1, k))) * G[t].rarea(i, j);
+      }
+    }
+    if (it != nsplt)
+      for (size_t n = 0; n < S[0].q.size(); ++n) {
+        std::vector<Arr3<T>*> qs; for (auto& s : S) qs.push_back(&s.q[n]);
+        exchange(X.rows[X_CELL], qs, std::vector<Arr3<T>*>());
+      }
+  }
+}
+
 template <class T>
 void fv_dynamics_cube(std::vector<DynState<T>>& S, const std::vector<Arr2<double>>& phis, int npz, double bdt, int n_split, int k_split,
                       const DampOpts& o, const Consts& c, double ptop, const std::vector<double>& ak, const std::vector<double>& bk,
@@ -112,11 +162,7 @@ void fv_dynamics_cube(std::vector<DynState<T>>& S, const std::vector<Arr2<double
         std::vector<Arr3<T>*> qs; for (auto& s : S) qs.push_back(&s.q[n]);
         exchange(X.rows[X_CELL], qs, none);
       }
-      for (int t = 0; t < nt; ++t) {
-        int nsplt = 1;
-        tracer_2d(S[t].q, dp1[t], S[t].mfx, S[t].mfy, S[t].cx, S[t].cy, npz, o.hord_tr, G[t], bd, &nsplt);
-        if (nsplt != 1) { std::fprintf(stderr, "oracle: cube tracer_2d needs the global nsplt (= %d here); sub-cycling across faces not restated\n", nsplt); std::abort(); }
-      }
+      tracer_2d_cube(S, dp1, npz, o.hord_tr, G, bd, X);
     }
     if (npz > 4) for (int t = 0; t < nt; ++t) lagrangian_to_eulerian(n_map == k_split, S[t], npz, c.akap, c.zvir, ptop, ak, bk, bd);
   }

@@ -9,6 +9,7 @@
 //   fv_dynamics_tlm.F90  FV_DYNAMICS (:999-1745 / _TLM :87-995), hydrostatic, adiabatic=.false.,
 //                        consv_te=0, tau=0, nwat<=1 (no fill2d), omega diagnostics not restated.
 #pragma once
+#include <functional>
 #include "dyn_core.hpp"
 
 namespace orc {
@@ -83,7 +84,8 @@ void map_col(int km, const std::vector<T>& pe1, const std::vector<T>& q1, int kn
 // tracer_2d, fv_tracer2d_tlm.F90:1148-1446 (q_split = 0, nord_tr/trdm = 0).  dp1 = delp before dyn_core.
 template <class T>
 void tracer_2d(std::vector<Arr3<T>>& q, Arr3<T>& dp1, Arr3<T>& mfx, Arr3<T>& mfy, Arr3<T>& cx, Arr3<T>& cy, int npz,
-               int hord, const Grid& g, const Bounds& bd, int* nsplt_out = nullptr) {
+               int hord, const Grid& g, const Bounds& bd, int* nsplt_out = nullptr, const std::vector<double>* cmax_all = nullptr,
+               std::vector<double>* cmax_out = nullptr, const std::function<void(std::vector<Arr3<T>>&)>* halo = nullptr) {
   const int is = bd.is, ie = bd.ie, js = bd.js, je = bd.je, isd = bd.isd, ied = bd.ied, jsd = bd.jsd, jed = bd.jed;
   const int nq = (int)q.size();
   Arr3<T> xfx(bd, npz), yfx(bd, npz);
@@ -108,6 +110,8 @@ void tracer_2d(std::vector<Arr3<T>>& q, Arr3<T>& dp1, Arr3<T>& mfx, Arr3<T>& mfy
         if (cmax[k] < c) cmax[k] = c;
       }
   }
+  if (cmax_out) { *cmax_out = cmax; return; }          // first pass of a multi-tile run: only the local maxima
+  if (cmax_all) cmax = *cmax_all;                      // mp_reduce_max over all tiles / ranks (fv_tracer2d_tlm.F90:1306)
   double c_global = cmax[1];
   for (int k = 2; k <= npz; ++k) if (!(cmax[k] < c_global)) c_global = cmax[k];
   const int nsplt = int(1. + c_global);
@@ -147,7 +151,7 @@ void tracer_2d(std::vector<Arr3<T>>& q, Arr3<T>& dp1, Arr3<T>& mfx, Arr3<T>& mfy
         for (int j = js; j <= je; ++j)
           for (int i = is; i <= ie; ++i) dp1(i, j, k) = dp2(i, j);
     }
-    if (it != nsplt) for (auto& qq : q) halo_periodic(qq, bd);
+    if (it != nsplt) { if (halo) (*halo)(q); else for (auto& qq : q) halo_periodic(qq, bd); }
   }
 }
 

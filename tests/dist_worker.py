@@ -16,7 +16,7 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from common import CubeCase
     from groups import cube_step_state, masked
-    from fv3_jedi_linearmodel_amd._lib import set_transport_callback
+    from fv3_jedi_linearmodel_amd._lib import set_transport_callback, set_allreduce_callback
     kw = dict(n=8, npz=6, n_split=2, k_split=2, backend="emul", nq=2)
     ref = CubeCase(**kw)                       # whole cube in this process
     c = CubeCase(rank=rank, world=world, **kw)   # this rank's faces
@@ -32,6 +32,12 @@ def main():
         for q in reqs:
             q.wait()
     set_transport_callback(c.lib, transport)
+
+    def allmax(buf):
+        t = torch.from_numpy(buf.copy())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        buf[:] = t.numpy()
+    set_allreduce_callback(c.lib, allmax)
 
     F = c.faces
     names = ["u", "v", "pt", "delp"] + ["q%d" % (n + 1) for n in range(c.nq)]

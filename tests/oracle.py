@@ -165,6 +165,9 @@ class CubeOracle:
         n = self.npz
         return self._call("orc_cube_dyn_core", mode, [C.c_double(bdt), C.c_int(n_split)], ins, ins_p, [n] * 8 + [n + 1, n + 1, n + 1, n], outs_p)
 
+    def tracer_2d(self, mode, nq, ins, ins_p=None, outs_p=None):
+        return self._call("orc_cube_tracer_2d", mode, [C.c_int(nq)], ins, ins_p, [self.npz] * nq, outs_p)
+
     def fv_dynamics(self, mode, nq, bdt, n_split, k_split, ins, ins_p=None, outs_p=None):
         return self._call("orc_cube_fv_dynamics", mode, [C.c_int(nq), C.c_double(bdt), C.c_int(n_split), C.c_int(k_split)], ins, ins_p,
                           [self.npz] * (4 + nq), outs_p)

@@ -42,3 +42,18 @@ def test_cube_fv_dynamics_ad(ccase_q):
 def test_cube_step_dot_product(ccase_q):
     lhs, rhs = cube_dot_product_step(ccase_q)
     assert abs(lhs - rhs) <= 1e-11 * abs(lhs), (lhs, rhs)
+
+
+from groups import cube_check_tracer
+
+
+def test_cube_tracer(ccase_q):
+    cube_check_tracer(ccase_q, TL, 1e-11)
+    cube_check_tracer(ccase_q, AD, 1e-10)
+
+
+def test_cube_tracer_subcycling(ccase_q):
+    """max Courant number over the whole cube >= 1: sub-steps with the q halo exchange in between"""
+    cube_check_tracer(ccase_q, TL, 1e-11, scale=80.0)
+    cube_check_tracer(ccase_q, AD, 1e-10, scale=80.0)
+    assert ccase_q.dy.lib.L.fv3lm_tracer_nsplt(ccase_q.dy.h) >= 2

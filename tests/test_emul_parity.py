@@ -97,3 +97,10 @@ def test_fv_dynamics(case_q, mode):
 def test_dot_product_step(case_q):
     lhs, rhs = dot_product_step(case_q)
     assert abs(lhs - rhs) <= 1e-12 * abs(lhs), (lhs, rhs)
+
+
+def test_tracer_subcycling(case_q):
+    """accumulated Courant number >= 1: nsplt = 2 with per-level sub-step counts (fv_tracer2d_tlm.F90:1306-1345)"""
+    check_tracer(case_q, TL, 1e-11, scale=10.0)
+    check_tracer(case_q, AD, 1e-10, scale=10.0)
+    assert case_q.dy.lib.L.fv3lm_tracer_nsplt(case_q.dy.h) >= 2

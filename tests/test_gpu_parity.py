@@ -198,3 +198,17 @@ def test_rccl_single_rank_comm():
     lib = fv3.load_hip_library()
     comm_init_rccl(lib, 0, 1, lambda data: data)
     assert lib.L.fv3lm_comm_destroy() == 0
+
+
+def test_tracer_subcycling_gpu():
+    """max Courant number >= 1: tracer_2d sub-cycles (periodic tile; six faces with the q exchange between sub-steps)"""
+    from common import Case, CubeCase
+    from groups import check_tracer, cube_check_tracer
+    c = Case(nx=12, ny=10, npz=10, n_split=2, k_split=2, dt=1800.0, backend="hip", nq=3)
+    check_tracer(c, TL, 1e-11, scale=10.0)
+    check_tracer(c, AD, 1e-10, scale=10.0)
+    assert c.dy.lib.L.fv3lm_tracer_nsplt(c.dy.h) >= 2
+    cc = CubeCase(n=8, npz=6, n_split=2, k_split=2, backend="hip", oracle=True, nq=2)
+    cube_check_tracer(cc, TL, 1e-11, scale=80.0)
+    cube_check_tracer(cc, AD, 1e-10, scale=80.0)
+    assert cc.dy.lib.L.fv3lm_tracer_nsplt(cc.dy.h) >= 2
