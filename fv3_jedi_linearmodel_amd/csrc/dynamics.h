@@ -142,7 +142,7 @@ inline bool Dynamics::init2(const double* ak, const double* bk) {
   for (int n = 0; n < nq; ++n) { char nm[16]; std::snprintf(nm, sizeof nm, "q%d", n + 1); q.push_back(S(nm, npz)); }
   dp1 = S("dp1", npz); qc = S("qc", npz); qc_o = S("qc_o", npz);
   pe2 = S("pe2", npz + 1); pu_ad = S("pu_ad", npz + 1); pv_ad = S("pv_ad", npz + 1);
-  remap_ws = (double*)dev_alloc((size_t)REMAP_WS_SLOTS * (npz + 2) * g.ntile * g.plane * 8);
+  remap_ws = (double*)dev_alloc((size_t)remap_ws_slots(nq) * (npz + 2) * g.ntile * g.plane * 8);
   cmax_dev = (double*)dev_alloc((size_t)g.ntile * npz * 8);
   tshared.init(n3 * 10); twork.init(n3 * 10);
   tr_ksplt_km.assign(k_split, std::vector<int>(npz, 1)); tr_nsplt_km.assign(k_split, 1);

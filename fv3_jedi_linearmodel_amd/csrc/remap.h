@@ -258,36 +258,50 @@ struct RemapArgs {
 };
 HD size_t fidx(const Geom& g, const Fld& f, int tile, int i, int j, int k) { return ((size_t)(tile * f.nk + k - 1)) * g.plane + g.idx(i, j); }
 
-// scalars: T (log p), tracers, delp, pk, peln, pkz, final pt (fv_mapz_tlm.F90:1586-1835, :2203-2250)
+// scalars: T (log p), tracers, delp, pk, peln, pkz, final pt (fv_mapz_tlm.F90:1586-1835, :2203-2250).
+// Two launches: (1) one thread per (column, field) — field 0 maps T_v in log p, field n tracer n in p — each with its own
+// workspace slots; (2) one thread per column for the new pressures and the final temperature conversion.
 template <class T>
-HD void remap_scalars_col(const RemapArgs& a, int i, int j, int tile, size_t col) {
+HD void remap_field_col(const RemapArgs& a, int field, int i, int j, int tile, size_t col) {
   const Geom& g = a.g; const int km = g.npz;
   const ColWs ws{a.ws + col, a.ws_stride, km + 2};
   typedef FIO<T> IO; typedef WsIO<T> W;
-  const int SG = 0, SE = 1, SO = 2;
+  const int SG = 3 * field, SE = 3 * field + 1, SO = 3 * field + 2;      // in units of T (x2 slots for Dual)
   auto pe1 = [&](int k) { return IO::ld(a.pe, fidx(g, a.pe, tile, i, j, k)); };
   auto pn1 = [&](int k) { return IO::ld(a.peln, fidx(g, a.peln, tile, i, j, k)); };
   auto pk1 = [&](int k) { return IO::ld(a.pk, fidx(g, a.pk, tile, i, j, k)); };
   const T ps = pe1(km + 1);
   auto pe2 = [&](int k) -> T { return k == 1 ? T(a.ptop) : (k == km + 1 ? ps : a.ak[k - 1] + a.bk[k - 1] * ps); };
-  auto pn2 = [&](int k) -> T { return (k == 1 || k == km + 1) ? pn1(k) : dlog(pe2(k)); };
-  auto tv = [&](int k) -> T { return IO::ld(a.pt, fidx(g, a.pt, tile, i, j, k)) * (pk1(k + 1) - pk1(k)) / (a.akap * (pn1(k + 1) - pn1(k))); };
   auto outw = [&](int k, const T& x) { W::set(ws, SO, k, x); };
-  map_col<T>(km, pn1, tv, pn2, outw, ws, SG, SE);
-  for (int k = 1; k <= km; ++k) IO::st(a.pt, fidx(g, a.pt, tile, i, j, k), W::get(ws, SO, k));   // T_v on the new levels
-  for (int n = 0; n < a.nq; ++n) {
-    const Fld& qf = a.q[n];
+  if (field == 0) {
+    auto pn2 = [&](int k) -> T { return (k == 1 || k == km + 1) ? pn1(k) : dlog(pe2(k)); };
+    auto tv = [&](int k) -> T { return IO::ld(a.pt, fidx(g, a.pt, tile, i, j, k)) * (pk1(k + 1) - pk1(k)) / (a.akap * (pn1(k + 1) - pn1(k))); };
+    map_col<T>(km, pn1, tv, pn2, outw, ws, SG, SE);
+    for (int k = 1; k <= km; ++k) IO::st(a.pt, fidx(g, a.pt, tile, i, j, k), W::get(ws, SO, k));   // T_v on the new levels
+  } else {
+    const Fld& qf = a.q[field - 1];
     auto q1 = [&](int k) { return IO::ld(qf, fidx(g, qf, tile, i, j, k)); };
     map_col<T>(km, pe1, q1, pe2, outw, ws, SG, SE);
     for (int k = 1; k <= km; ++k) IO::st(qf, fidx(g, qf, tile, i, j, k), W::get(ws, SO, k));
   }
+}
+template <class T>
+HD void remap_press_col(const RemapArgs& a, int i, int j, int tile) {
+  const Geom& g = a.g; const int km = g.npz;
+  typedef FIO<T> IO;
+  auto pe1 = [&](int k) { return IO::ld(a.pe, fidx(g, a.pe, tile, i, j, k)); };
+  auto pn1 = [&](int k) { return IO::ld(a.peln, fidx(g, a.peln, tile, i, j, k)); };
+  auto pk1 = [&](int k) { return IO::ld(a.pk, fidx(g, a.pk, tile, i, j, k)); };
+  const T ps = pe1(km + 1);
+  auto pe2 = [&](int k) -> T { return k == 1 ? T(a.ptop) : (k == km + 1 ? ps : a.ak[k - 1] + a.bk[k - 1] * ps); };
   // new pressures; pk/peln end levels keep their values (:1650-1661)
   T pk_hi = pk1(1), pn_hi = pn1(1), pe_hi = pe2(1);
+  const T pn_bot = pn1(km + 1), pk_bot = pk1(km + 1);
   IO::st(a.pe2, fidx(g, a.pe2, tile, i, j, 1), pe_hi);
   for (int k = 1; k <= km; ++k) {
     const T pe_lo = pe2(k + 1);
     T pn_lo, pk_lo;
-    if (k == km) { pn_lo = pn1(km + 1); pk_lo = pk1(km + 1); } else { pn_lo = dlog(pe_lo); pk_lo = dexp(a.akap * pn_lo); }
+    if (k == km) { pn_lo = pn_bot; pk_lo = pk_bot; } else { pn_lo = dlog(pe_lo); pk_lo = dexp(a.akap * pn_lo); }
     const T pkz = (pk_lo - pk_hi) / (a.akap * (pn_lo - pn_hi));
     const size_t n0 = fidx(g, a.pt, tile, i, j, k);
     IO::st(a.delp, n0, pe_lo - pe_hi);
@@ -381,11 +395,18 @@ HD void remap_pe_gather_ad(const RemapArgs& a, int i, int j, int tile) {
 // adjoint of remap_scalars_col.  Trajectory inputs (pre-remap pe, peln, pk, pt, q) must be in place.
 // Incoming adjoints: pt.p, q[n].p, delp.p, pk.p, peln.p, pkz.p (of the remapped fields); outgoing:
 // pt.p, q[n].p (of the inputs), pk.p, peln.p replaced, pe.p accumulated, delp.p = pkz.p = 0.
-HD void remap_scalars_col_ad(const RemapArgs& a, int i, int j, int tile, size_t col) {
+// Adjoint of the scalar remap in three launches (the column maps of the different fields are independent):
+//   k1, per column:          trajectory of the remapped T_v and q_v, final conversion, pkz / pk / peln / delp adjoints
+//   k2, per (column, field): adjoint of one column map (field 0: T_v in log p; field n: tracer n in p), own workspace slots
+//   k3, per column:          sums the pressure adjoints of all maps, T_v -> pt, pk2 / pn2 chain, write-back
+// Workspace slots: 0..21 shared accumulators (as named below), 22 + 13 f .. for the map of field f.
+struct RemapAdSlots { static constexpr int SPE1 = 13, SPN1 = 14, SPK1 = 15, SPE2 = 16, SPN2 = 17, SPK2 = 18, ST2 = 19, SQ2 = 20, SV = 21, FBASE = 22, FN = 13; };
+HD MapAdSlots remap_field_slots(int f) { const int b = RemapAdSlots::FBASE + RemapAdSlots::FN * f; return MapAdSlots{b, b + 1, b + 2, b + 3, b + 4, b + 5, b + 6, b + 7, b + 8, b + 9, b + 10, b + 11, b + 12}; }
+
+HD void remap_ad_k1(const RemapArgs& a, int i, int j, int tile, size_t col) {
   const Geom& g = a.g; const int km = g.npz;
   const ColWs ws{a.ws + col, a.ws_stride, km + 2};
-  const MapAdSlots S{0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12};
-  const int SPE1 = 13, SPN1 = 14, SPK1 = 15, SPE2 = 16, SPN2 = 17, SPK2 = 18, ST2 = 19, SQ2 = 20, SV = 21;
+  typedef RemapAdSlots R_;
   auto pe1 = [&](int k) { return a.pe.t[fidx(g, a.pe, tile, i, j, k)]; };
   auto pn1 = [&](int k) { return a.peln.t[fidx(g, a.peln, tile, i, j, k)]; };
   auto pk1 = [&](int k) { return a.pk.t[fidx(g, a.pk, tile, i, j, k)]; };
@@ -396,14 +417,14 @@ HD void remap_scalars_col_ad(const RemapArgs& a, int i, int j, int tile, size_t 
   auto ptin = [&](int k) { return a.pt.t[fidx(g, a.pt, tile, i, j, k)]; };
   auto tv = [&](int k) -> double { return ptin(k) * (pk1(k + 1) - pk1(k)) / (a.akap * (pn1(k + 1) - pn1(k))); };
   for (int k = 0; k <= km + 1; ++k)
-    for (int s : {SPE1, SPN1, SPK1, SPE2, SPN2, SPK2}) ws.at(s, k) = 0.;
+    for (int s_ : {R_::SPE1, R_::SPN1, R_::SPK1, R_::SPE2, R_::SPN2, R_::SPK2}) ws.at(s_, k) = 0.;
   // trajectory of the remapped T_v and q_v (needed by the final conversion)
   {
-    auto outT = [&](int k, double x) { ws.at(ST2, k) = x; };
+    auto outT = [&](int k, double x) { ws.at(R_::ST2, k) = x; };
     map_col<double>(km, pn1, tv, pn2, outT, ws, 0, 1);
     if (a.nq > 0 && a.last_step) {
       auto q1 = [&](int k) { return a.q[0].t[fidx(g, a.q[0], tile, i, j, k)]; };
-      auto outQ = [&](int k, double x) { ws.at(SQ2, k) = x; };
+      auto outQ = [&](int k, double x) { ws.at(R_::SQ2, k) = x; };
       map_col<double>(km, pe1, q1, pe2, outQ, ws, 0, 1);
     }
   }
@@ -412,81 +433,118 @@ HD void remap_scalars_col_ad(const RemapArgs& a, int i, int j, int tile, size_t 
     const size_t n0 = fidx(g, a.pt, tile, i, j, k);
     const double pk_hi = pk2(k), pk_lo = pk2(k + 1), pn_hi = pn2(k), pn_lo = pn2(k + 1);
     const double den = a.akap * (pn_lo - pn_hi), pkz = (pk_lo - pk_hi) / den;
-    const double pt_ad = a.pt.p[n0], t2 = ws.at(ST2, k);
+    const double pt_ad = a.pt.p[n0], t2 = ws.at(R_::ST2, k);
     double pkz_ad = a.pkz.p[n0], t2_ad;
     if (a.last_step) {
-      const double qv = a.nq > 0 ? ws.at(SQ2, k) : 0., f = 1. + a.zvir * qv;
+      const double qv = a.nq > 0 ? ws.at(R_::SQ2, k) : 0., f = 1. + a.zvir * qv;
       t2_ad = pt_ad / f;
       if (a.nq > 0) a.q[0].p[fidx(g, a.q[0], tile, i, j, k)] += -(t2 / f) * a.zvir * pt_ad / f;
     } else {
       t2_ad = pt_ad / pkz;
       pkz_ad += -(t2 / pkz) * pt_ad / pkz;
     }
-    ws.at(SV, k) = t2_ad;
+    ws.at(R_::SV, k) = t2_ad;
     const double za = pkz_ad / den;
-    ws.at(SPK2, k + 1) += za; ws.at(SPK2, k) -= za;
+    ws.at(R_::SPK2, k + 1) += za; ws.at(R_::SPK2, k) -= za;
     const double zb = -pkz * a.akap * za;
-    ws.at(SPN2, k + 1) += zb; ws.at(SPN2, k) -= zb;
+    ws.at(R_::SPN2, k + 1) += zb; ws.at(R_::SPN2, k) -= zb;
     const double dpa = a.delp.p[n0];
-    ws.at(SPE2, k + 1) += dpa; ws.at(SPE2, k) -= dpa;
+    ws.at(R_::SPE2, k + 1) += dpa; ws.at(R_::SPE2, k) -= dpa;
     a.delp.p[n0] = 0.; a.pkz.p[n0] = 0.;
   }
   for (int k = 2; k <= km; ++k) {   // pk_out(k) = pk2(k), peln_out(k) = pn2(k) for interior interfaces
-    ws.at(SPK2, k) += a.pk.p[fidx(g, a.pk, tile, i, j, k)];
-    ws.at(SPN2, k) += a.peln.p[fidx(g, a.peln, tile, i, j, k)];
+    ws.at(R_::SPK2, k) += a.pk.p[fidx(g, a.pk, tile, i, j, k)];
+    ws.at(R_::SPN2, k) += a.peln.p[fidx(g, a.peln, tile, i, j, k)];
   }
-  // T map (coordinates pn1 -> pn2)
-  {
-    for (int k = 0; k <= km + 1; ++k) { ws.at(S.SP1, k) = 0.; ws.at(S.SQ1, k) = 0.; ws.at(S.SP2, k) = 0.; }
-    auto q2ad = [&](int k) { return ws.at(SV, k); };
+}
+HD void remap_ad_k2(const RemapArgs& a, int field, int i, int j, int tile, size_t col) {
+  const Geom& g = a.g; const int km = g.npz;
+  const ColWs ws{a.ws + col, a.ws_stride, km + 2};
+  const MapAdSlots S = remap_field_slots(field);
+  auto pe1 = [&](int k) { return a.pe.t[fidx(g, a.pe, tile, i, j, k)]; };
+  const double ps = pe1(km + 1);
+  auto pe2 = [&](int k) -> double { return k == 1 ? a.ptop : (k == km + 1 ? ps : a.ak[k - 1] + a.bk[k - 1] * ps); };
+  for (int k = 0; k <= km + 1; ++k) { ws.at(S.SP1, k) = 0.; ws.at(S.SQ1, k) = 0.; ws.at(S.SP2, k) = 0.; }
+  if (field == 0) {   // T map (coordinates pn1 -> pn2)
+    auto pn1 = [&](int k) { return a.peln.t[fidx(g, a.peln, tile, i, j, k)]; };
+    auto pk1 = [&](int k) { return a.pk.t[fidx(g, a.pk, tile, i, j, k)]; };
+    auto pn2 = [&](int k) -> double { return (k == 1 || k == km + 1) ? pn1(k) : log(pe2(k)); };
+    auto tv = [&](int k) -> double { return a.pt.t[fidx(g, a.pt, tile, i, j, k)] * (pk1(k + 1) - pk1(k)) / (a.akap * (pn1(k + 1) - pn1(k))); };
+    auto q2ad = [&](int k) { return ws.at(RemapAdSlots::SV, k); };
     map_col_ad(km, pn1, tv, pn2, q2ad, ws, S);
-    for (int k = 1; k <= km + 1; ++k) { ws.at(SPN1, k) += ws.at(S.SP1, k); ws.at(SPN2, k) += ws.at(S.SP2, k); }
-    for (int k = 1; k <= km; ++k) {   // T_v(k) = pt * dpk / (akap * dln)
-      const double tv_ad = ws.at(S.SQ1, k), dpk = pk1(k + 1) - pk1(k), den = a.akap * (pn1(k + 1) - pn1(k)), pt0 = ptin(k);
-      a.pt.p[fidx(g, a.pt, tile, i, j, k)] = tv_ad * dpk / den;
-      const double za = pt0 * tv_ad / den;
-      ws.at(SPK1, k + 1) += za; ws.at(SPK1, k) -= za;
-      const double zb = -(pt0 * dpk / den) * a.akap * tv_ad / den;
-      ws.at(SPN1, k + 1) += zb; ws.at(SPN1, k) -= zb;
-    }
-  }
-  // tracer maps (coordinates pe1 -> pe2)
-  for (int n = 0; n < a.nq; ++n) {
-    const Fld& qf = a.q[n];
-    for (int k = 0; k <= km + 1; ++k) { ws.at(S.SP1, k) = 0.; ws.at(S.SQ1, k) = 0.; ws.at(S.SP2, k) = 0.; }
+  } else {            // tracer map (coordinates pe1 -> pe2)
+    const Fld& qf = a.q[field - 1];
     auto q1 = [&](int k) { return qf.t[fidx(g, qf, tile, i, j, k)]; };
     auto q2ad = [&](int k) { return qf.p[fidx(g, qf, tile, i, j, k)]; };
     map_col_ad(km, pe1, q1, pe2, q2ad, ws, S);
     for (int k = 1; k <= km; ++k) qf.p[fidx(g, qf, tile, i, j, k)] = ws.at(S.SQ1, k);
-    for (int k = 1; k <= km + 1; ++k) { ws.at(SPE1, k) += ws.at(S.SP1, k); ws.at(SPE2, k) += ws.at(S.SP2, k); }
+  }
+}
+HD void remap_ad_k3(const RemapArgs& a, int i, int j, int tile, size_t col) {
+  const Geom& g = a.g; const int km = g.npz;
+  const ColWs ws{a.ws + col, a.ws_stride, km + 2};
+  typedef RemapAdSlots R_;
+  auto pe1 = [&](int k) { return a.pe.t[fidx(g, a.pe, tile, i, j, k)]; };
+  auto pn1 = [&](int k) { return a.peln.t[fidx(g, a.peln, tile, i, j, k)]; };
+  auto pk1 = [&](int k) { return a.pk.t[fidx(g, a.pk, tile, i, j, k)]; };
+  const double ps = pe1(km + 1);
+  auto pe2 = [&](int k) -> double { return k == 1 ? a.ptop : (k == km + 1 ? ps : a.ak[k - 1] + a.bk[k - 1] * ps); };
+  auto pn2 = [&](int k) -> double { return (k == 1 || k == km + 1) ? pn1(k) : log(pe2(k)); };
+  auto pk2 = [&](int k) -> double { return (k == 1 || k == km + 1) ? pk1(k) : exp(a.akap * pn2(k)); };
+  {   // T map: pressure adjoints into the log-p accumulators, T_v(k) = pt * dpk / (akap * dln)
+    const MapAdSlots S = remap_field_slots(0);
+    for (int k = 1; k <= km + 1; ++k) { ws.at(R_::SPN1, k) += ws.at(S.SP1, k); ws.at(R_::SPN2, k) += ws.at(S.SP2, k); }
+    for (int k = 1; k <= km; ++k) {
+      const double tv_ad = ws.at(S.SQ1, k), dpk = pk1(k + 1) - pk1(k), den = a.akap * (pn1(k + 1) - pn1(k)), pt0 = a.pt.t[fidx(g, a.pt, tile, i, j, k)];
+      a.pt.p[fidx(g, a.pt, tile, i, j, k)] = tv_ad * dpk / den;
+      const double za = pt0 * tv_ad / den;
+      ws.at(R_::SPK1, k + 1) += za; ws.at(R_::SPK1, k) -= za;
+      const double zb = -(pt0 * dpk / den) * a.akap * tv_ad / den;
+      ws.at(R_::SPN1, k + 1) += zb; ws.at(R_::SPN1, k) -= zb;
+    }
+  }
+  for (int n = 0; n < a.nq; ++n) {   // tracer maps: pressure adjoints, in tracer order
+    const MapAdSlots S = remap_field_slots(1 + n);
+    for (int k = 1; k <= km + 1; ++k) { ws.at(R_::SPE1, k) += ws.at(S.SP1, k); ws.at(R_::SPE2, k) += ws.at(S.SP2, k); }
   }
   // pk2 = exp(akap pn2), pn2 = log pe2 on interior interfaces; end levels pass through to pk1/pn1
   for (int k = 2; k <= km; ++k) {
-    const double pn_ad = ws.at(SPN2, k) + a.akap * pk2(k) * ws.at(SPK2, k);
-    ws.at(SPE2, k) += pn_ad / pe2(k);
+    const double pn_ad = ws.at(R_::SPN2, k) + a.akap * pk2(k) * ws.at(R_::SPK2, k);
+    ws.at(R_::SPE2, k) += pn_ad / pe2(k);
   }
   for (int k : {1, km + 1}) {   // end interfaces pass through: pk_out = pk1, peln_out = pn1
-    ws.at(SPN1, k) += ws.at(SPN2, k) + a.peln.p[fidx(g, a.peln, tile, i, j, k)];
-    ws.at(SPK1, k) += ws.at(SPK2, k) + a.pk.p[fidx(g, a.pk, tile, i, j, k)];
+    ws.at(R_::SPN1, k) += ws.at(R_::SPN2, k) + a.peln.p[fidx(g, a.peln, tile, i, j, k)];
+    ws.at(R_::SPK1, k) += ws.at(R_::SPK2, k) + a.pk.p[fidx(g, a.pk, tile, i, j, k)];
   }
-  double ps_ad = ws.at(SPE2, km + 1);
-  for (int k = 2; k <= km; ++k) ps_ad += a.bk[k - 1] * ws.at(SPE2, k);
-  ws.at(SPE1, km + 1) += ps_ad;
+  double ps_ad = ws.at(R_::SPE2, km + 1);
+  for (int k = 2; k <= km; ++k) ps_ad += a.bk[k - 1] * ws.at(R_::SPE2, k);
+  ws.at(R_::SPE1, km + 1) += ps_ad;
   // write back: pk.p / peln.p replaced by the input adjoints, pe.p accumulated
   for (int k = 1; k <= km + 1; ++k) {
-    a.pk.p[fidx(g, a.pk, tile, i, j, k)] = ws.at(SPK1, k);
-    a.peln.p[fidx(g, a.peln, tile, i, j, k)] = ws.at(SPN1, k);
-    a.pe.p[fidx(g, a.pe, tile, i, j, k)] += ws.at(SPE1, k);
+    a.pk.p[fidx(g, a.pk, tile, i, j, k)] = ws.at(R_::SPK1, k);
+    a.peln.p[fidx(g, a.peln, tile, i, j, k)] = ws.at(R_::SPN1, k);
+    a.pe.p[fidx(g, a.pe, tile, i, j, k)] += ws.at(R_::SPE1, k);
   }
 }
 
-struct RemapScalFn {
-  RemapArgs a; int mode;
+struct RemapFieldFn {      // z = tile * nf + field
+  RemapArgs a; int mode, nf;
+  HD void operator()(int i, int j, int z) const {
+    const int tile = z / nf, field = z % nf;
+    const size_t col = (size_t)tile * a.g.plane + a.g.idx(i, j);
+    if (mode == MODE_NL) remap_field_col<double>(a, field, i, j, tile, col);
+    else if (mode == MODE_TL) remap_field_col<Dual>(a, field, i, j, tile, col);
+    else remap_ad_k2(a, field, i, j, tile, col);
+  }
+};
+struct RemapPressFn {
+  RemapArgs a; int mode;     // MODE_AD: stage 1 of the adjoint; mode 3: stage 3
   HD void operator()(int i, int j, int z) const {
     const size_t col = (size_t)z * a.g.plane + a.g.idx(i, j);
-    if (mode == MODE_NL) remap_scalars_col<double>(a, i, j, z, col);
-    else if (mode == MODE_TL) remap_scalars_col<Dual>(a, i, j, z, col);
-    else remap_scalars_col_ad(a, i, j, z, col);
+    if (mode == MODE_NL) remap_press_col<double>(a, i, j, z);
+    else if (mode == MODE_TL) remap_press_col<Dual>(a, i, j, z);
+    else if (mode == MODE_AD) remap_ad_k1(a, i, j, z, col);
+    else remap_ad_k3(a, i, j, z, col);
   }
 };
 struct RemapWindFn {
@@ -514,15 +572,17 @@ struct RemapPeFn {
   }
 };
 
-// Workspace: 22 slots of (npz+2) doubles per column, columns = ntile*plane.
-constexpr int REMAP_WS_SLOTS = 22;
+// Workspace: 22 shared slots + 13 per scalar field (T and the tracers) of (npz+2) doubles per column, columns = ntile*plane.
+inline int remap_ws_slots(int nq) { return RemapAdSlots::FBASE + RemapAdSlots::FN * (1 + nq); }
 inline void run_remap(Exec& ex, int mode, const RemapArgs& a) {
   const Geom& g = a.g;
   const Rect A{1, g.nx, 1, g.ny}, U{1, g.nx, 1, g.ny + 1}, V{1, g.nx + 1, 1, g.ny}, H{0, g.nx + 1, 0, g.ny + 1};
   if (mode != MODE_AD) {
     const double cells = double(g.nx) * g.ny * g.ntile * g.npz, w = mode == MODE_TL ? 2. : 1.;
     // algorithmic bytes: scalars read pe,peln,pk,pt,q[nq]; write pt,q[nq],delp,pk,peln,pkz,pe2; winds read pe x2, u|v; write u|v
-    for_points(ex, A, g.ntile, RemapScalFn{a, mode}, mode == MODE_TL ? "remap_scalars.tl" : "remap_scalars.nl", 8. * w * (10. + 2. * a.nq) * cells);
+    const int nf = 1 + a.nq;
+    for_points(ex, A, g.ntile * nf, RemapFieldFn{a, mode, nf}, mode == MODE_TL ? "remap_fields.tl" : "remap_fields.nl", 8. * w * (5. + 2. * a.nq) * cells);
+    for_points(ex, A, g.ntile, RemapPressFn{a, mode}, mode == MODE_TL ? "remap_press.tl" : "remap_press.nl", 8. * w * (5. + 7.) * cells);
     for_points(ex, U, g.ntile, RemapWindFn{a, mode, 0}, mode == MODE_TL ? "remap_wind.tl" : "remap_wind.nl", 8. * w * 4. * cells);
     for_points(ex, V, g.ntile, RemapWindFn{a, mode, 1}, mode == MODE_TL ? "remap_wind.tl" : "remap_wind.nl", 8. * w * 4. * cells);
     for_points(ex, A, g.ntile, RemapPeFn{a, mode}, "remap_pe");
@@ -531,7 +591,10 @@ inline void run_remap(Exec& ex, int mode, const RemapArgs& a) {
     for_points(ex, V, g.ntile, RemapWindFn{a, mode, 1}, "remap_wind.ad", 8. * 7. * cells);
     for_points(ex, U, g.ntile, RemapWindFn{a, mode, 0}, "remap_wind.ad", 8. * 7. * cells);
     for_points(ex, H, g.ntile, RemapGatherFn{a}, "remap_gather.ad", 8. * 4. * cells);
-    for_points(ex, A, g.ntile, RemapScalFn{a, mode}, "remap_scalars.ad", 8. * (16. + 3. * a.nq) * cells);
+    const int nf = 1 + a.nq;
+    for_points(ex, A, g.ntile, RemapPressFn{a, MODE_AD}, "remap_scalars1.ad", 8. * 12. * cells);
+    for_points(ex, A, g.ntile * nf, RemapFieldFn{a, MODE_AD, nf}, "remap_fields.ad", 8. * (4. + 3. * a.nq) * cells);
+    for_points(ex, A, g.ntile, RemapPressFn{a, 3}, "remap_scalars3.ad", 8. * 8. * cells);
   }
 }
 
