@@ -92,7 +92,9 @@ struct GeopkFn {
     else geopk_col_ad(a, i, j, z);
   }
 };
-inline void run_geopk(Exec& ex, int mode, const GeopkArgs& a) {
+inline void run_geopk(Exec& ex, int mode, const GeopkArgs& a0) {
+  GeopkArgs a = a0;
+  a.delp = ex.sh(a.delp); a.pt = ex.sh(a.pt); a.pe = ex.sh(a.pe); a.peln = ex.sh(a.peln); a.pk = ex.sh(a.pk); a.gz = ex.sh(a.gz); a.pkz = ex.sh(a.pkz);
   // algorithmic bytes: delp, pt in; pe, peln, pk, gz (+pkz) out; x2 for TL; adjoint reads/updates the same set
   const double cells = double(a.R.i1 - a.R.i0 + 1) * (a.R.j1 - a.R.j0 + 1) * a.g.ntile * a.g.npz;
   const double per = (a.cg ? 6. : 7.) * (mode == MODE_NL ? 1. : mode == MODE_TL ? 2. : 3.);
@@ -138,7 +140,8 @@ struct HaloAdZeroFn {
     f.p[(size_t)z * g.plane + g.idx(i, j)] = 0.0;
   }
 };
-inline void run_halo(Exec& ex, int mode, const Geom& g, const Fld& f) {
+inline void run_halo(Exec& ex, int mode, const Geom& g, const Fld& f0) {
+  const Fld f = ex.sh(f0);
   const Rect full{g.isd(), g.ied() + 1, g.jsd(), g.jed() + 1}, inner{1, g.nx, 1, g.ny};
   const int nz = g.ntile * f.nk;
   if (mode == MODE_AD) {
@@ -160,7 +163,7 @@ struct AccumFn {
   }
 };
 inline void run_accum(Exec& ex, int mode, const Geom& g, const Fld& acc, const Fld& x, const Rect& R) {
-  for_points(ex, R, g.ntile * acc.nk, AccumFn{g, acc, x, mode}, "accum");
+  for_points(ex, R, g.ntile * acc.nk, AccumFn{g, ex.sh(acc), ex.sh(x), mode}, "accum");
 }
 
 // ---------------------------------------------------------------- plane copy of the interior+everything (state hand-over)

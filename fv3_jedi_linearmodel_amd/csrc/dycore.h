@@ -127,6 +127,12 @@ struct Dycore {
   std::map<std::string, Fld> F;       // field registry (debug/test access + driver)
   Program acoustic;                   // one acoustic step
   double* ckpt = nullptr;             // [n_split*k_split][4][field3]
+  // Trajectory slots: as many acoustic steps as free HBM allows keep the trajectory of ALL their intermediates (one copy of
+  // the work arena's trajectory side + pe, peln, pk, pkz each), written by the forward sweep of step_nl; the backward sweep
+  // then skips the nonlinear recompute of those steps.  Steps without a slot are recomputed from their 4-field checkpoint.
+  std::vector<double*> traj_slot, traj_slot_p;   // work.t copy, (pe, peln, pk, pkz).t copy
+  void init_traj_slots();
+  bool has_slot(int a) const { return a < (int)traj_slot.size(); }
   int ck_base = 0;                    // first acoustic-step slot of the current k_split iteration
   size_t n3 = 0, n3p = 0;             // doubles per npz / npz+1 field
   std::string err;
@@ -182,8 +188,8 @@ struct Dycore {
     if (!g.face) { run_halo(ex, mode, g, f0); if (f1.t) run_halo(ex, mode, g, f1); return; }
     if (xt[kind].n == 0 && !xr[kind].active) { halo_missing = true; return; }
     // forward: local rows and remote rows write disjoint halo elements; adjoint: both add into the sources, one after the other
-    run_exchange(ex, mode, g, xt[kind], f0, f1);
-    if (!run_exchange_remote(ex, mode, g, xr[kind], f0, f1, err)) halo_missing = true;
+    run_exchange(ex, mode, g, xt[kind], ex.sh(f0), ex.sh(f1));
+    if (!run_exchange_remote(ex, mode, g, xr[kind], ex.sh(f0), ex.sh(f1), err)) halo_missing = true;
   }
   // when: 0 every acoustic step, 1 all but the last, 2 the last only (face mode; the periodic wrap does
   // both jobs at once and ignores it)
@@ -339,10 +345,11 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
   if (phis_host) h2d(ex, hs_dev, phis_host, np * 8);
   ctx.g = g; ctx.lev = lev_dev; ctx.nlev = npz;
   n3 = np * npz; n3p = np * (npz + 1);
-  state.init(n3 * (20 + 3 * (size_t)nq) + n3p * 8);
-  work.init(n3 * (g.face ? 116 : 110) + n3p * 14);
+  state.init(n3 * (16 + 3 * (size_t)nq) + n3p * 8);
+  work.init(n3 * (g.face ? 120 : 114) + n3p * 14);
   build_acoustic();
   ckpt = (double*)dev_alloc((size_t)n_split * k_split * 4 * n3 * 8);
+  ex.wlo = work.t; ex.whi = work.t + work.cap;
   return true;
 }
 
@@ -402,12 +409,29 @@ inline bool Dycore::set_exchange_remote(int kind, int npeers, const int* peers, 
   return true;
 }
 
+// called after every other allocation (Dynamics::init2): take what is left of the HBM, minus a reserve
+inline void Dycore::init_traj_slots() {
+  const size_t slot_bytes = work.cap * 8, extra_bytes = (3 * n3p + n3) * 8;
+  int want = n_split * k_split;
+  if (const char* e = std::getenv("FV3LM_TRAJ_SLOTS")) want = std::min(want, std::max(0, std::atoi(e)));
+#ifndef FV3LM_HOST_EMUL
+  size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = 0;
+  const size_t reserve = (size_t)6 << 30;
+  const int fit = fr > reserve ? (int)((fr - reserve) / (slot_bytes + extra_bytes)) : 0;
+  if (want > fit) want = fit;
+#endif
+  for (int n = 0; n < want; ++n) { traj_slot.push_back((double*)dev_alloc(slot_bytes)); traj_slot_p.push_back((double*)dev_alloc(extra_bytes)); }
+}
+
 inline void Dycore::destroy() {
   for (double* p : metric_dev) dev_free(p);
   dev_free(lev_dev); dev_free(hs_dev); dev_free(ckpt); dev_free(edge_dev); dev_free(ecorner_dev);
   for (ExTable& t : xt) { dev_free(t.rows); dev_free(t.src); dev_free(t.ptr); dev_free(t.dst); }
   for (ExRemote& x : xr) { dev_free(x.send_rows); dev_free(x.recv_rows); dev_free(x.asrc); dev_free(x.aptr); dev_free(x.apos); dev_free(x.sendbuf); dev_free(x.recvbuf); }
   state.destroy(); work.destroy();
+  for (double* q_ : traj_slot) dev_free(q_);
+  for (double* q_ : traj_slot_p) dev_free(q_);
 #ifndef FV3LM_HOST_EMUL
   if (ex.stream) (void)hipStreamDestroy(ex.stream);
 #endif
@@ -421,7 +445,7 @@ inline void Dycore::build_acoustic() {
   Program& P = acoustic;
   // prognostic state (step input / output) and accumulators
   Fld u = S("u", npz), v = S("v", npz), delp = S("delp", npz), pt = S("pt", npz);
-  Fld u_o = S("u_o", npz), v_o = S("v_o", npz), delp_o = S("delp_o", npz), pt_o = S("pt_o", npz);
+  Fld u_o = W("u_o", npz), v_o = W("v_o", npz), delp_o = W("delp_o", npz), pt_o = W("pt_o", npz);   // step outputs: per-step trajectory like every work array
   Fld mfx = S("mfx", npz), mfy = S("mfy", npz), cx = S("cx", npz), cy = S("cy", npz);
   Fld pe = S("pe", npz + 1), peln = S("peln", npz + 1), pk = S("pk", npz + 1), pkz = S("pkz", npz);
   // ---- c_sw
@@ -545,32 +569,53 @@ inline void Dycore::build_acoustic() {
 inline void Dycore::dyn_core(int mode) {
   const char* names[4] = {"u", "v", "delp", "pt"};
   const char* onames[4] = {"u_o", "v_o", "delp_o", "pt_o"};
+  const char* pnames[4] = {"pe", "peln", "pk", "pkz"};
   const size_t b3 = n3 * 8;
+  auto slot_io = [&](int a, bool save) {      // pe, peln, pk, pkz trajectory of step a <-> its slot
+    double* q_ = traj_slot_p[a];
+    for (int n = 0; n < 4; ++n) {
+      const size_t nb = (n < 3 ? n3p : n3) * 8;
+      if (save) dev_copy(ex, q_, f(pnames[n]).t, nb); else dev_copy(ex, f(pnames[n]).t, q_, nb);
+      q_ += (n < 3 ? n3p : n3);
+    }
+  };
   if (mode != MODE_AD) {
     for (const char* a : {"mfx", "mfy", "cx", "cy"}) { dev_zero(ex, f(a).t, b3); if (mode == MODE_TL) dev_zero(ex, f(a).p, b3); }
     for (int it = 0; it < n_split; ++it) {
-      if (mode == MODE_NL)
-        for (int n = 0; n < 4; ++n) dev_copy(ex, ckpt + ((size_t)(ck_base + it) * 4 + n) * n3, f(names[n]).t, b3);
+      const int a = ck_base + it;
+      if (mode == MODE_NL) {
+        for (int n = 0; n < 4; ++n) dev_copy(ex, ckpt + ((size_t)a * 4 + n) * n3, f(names[n]).t, b3);
+        ex.tshift = has_slot(a) ? traj_slot[a] - work.t : 0;
+      }
       last_acoustic = (it == n_split - 1);
       run_group(acoustic, nullptr, mode);
       for (int n = 0; n < 4; ++n) {
-        dev_copy(ex, f(names[n]).t, f(onames[n]).t, b3);
+        dev_copy(ex, f(names[n]).t, ex.sh(f(onames[n])).t, b3);
         if (mode == MODE_TL) dev_copy(ex, f(names[n]).p, f(onames[n]).p, b3);
       }
+      if (mode == MODE_NL && has_slot(a)) slot_io(a, true);
+      ex.tshift = 0;
     }
   } else {
     // incoming adjoint lives in the input-named buffers; move it to the *_o side of the last step
     for (int it = n_split - 1; it >= 0; --it) {
-      for (int n = 0; n < 4; ++n) dev_copy(ex, f(names[n]).t, ckpt + ((size_t)(ck_base + it) * 4 + n) * n3, b3);
-      // recompute this step's nonlinear intermediates (flux capacitors left alone)
+      const int a = ck_base + it;
+      for (int n = 0; n < 4; ++n) dev_copy(ex, f(names[n]).t, ckpt + ((size_t)a * 4 + n) * n3, b3);
       last_acoustic = (it == n_split - 1);
-      run_group(acoustic, nullptr, MODE_NL, true);
+      if (has_slot(a)) {       // this step's intermediates were kept by the forward sweep
+        ex.tshift = traj_slot[a] - work.t;
+        slot_io(a, false);
+      } else {                 // recompute this step's nonlinear intermediates (flux capacitors left alone)
+        ex.tshift = 0;
+        run_group(acoustic, nullptr, MODE_NL, true);
+      }
       zero_work_adjoint();
       for (int n = 0; n < 4; ++n) { dev_copy(ex, f(onames[n]).p, f(names[n]).p, b3); dev_zero(ex, f(names[n]).p, b3); }
       run_group(acoustic, nullptr, MODE_AD);
       // pe, peln, pk, pkz of earlier steps are overwritten by later ones: their adjoint is zero there
-      for (const char* a : {"pe", "peln", "pk"}) dev_zero(ex, f(a).p, n3p * 8);
+      for (const char* a_ : {"pe", "peln", "pk"}) dev_zero(ex, f(a_).p, n3p * 8);
       dev_zero(ex, f("pkz").p, b3);
+      ex.tshift = 0;
     }
   }
 }

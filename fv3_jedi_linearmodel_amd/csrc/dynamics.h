@@ -152,6 +152,7 @@ inline bool Dynamics::init2(const double* ak, const double* bk) {
   ck_k_stride = (size_t)(2 * nq + 7) * n3 + 3 * n3p;
   ck_k = (double*)dev_alloc(ck_k_stride * k_split * 8);
   ck_0 = (double*)dev_alloc(2 * n3 * 8);
+  init_traj_slots();
   return true;
 }
 inline void Dynamics::destroy2() {

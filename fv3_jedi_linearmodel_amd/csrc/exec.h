@@ -7,6 +7,7 @@
 // one level stay together in an XCD's L2 while the stencil rows are re-read.
 #pragma once
 #include "core.h"
+#include <cstddef>
 #include <string>
 #include <vector>
 
@@ -25,6 +26,11 @@ struct Exec {
   hipStream_t stream = nullptr;
 #endif
   bool check_boxes = false;   // host emulation only: verify declared stencil boxes
+  // Trajectory slots (dycore.h): while tshift != 0 every trajectory pointer into the work arena [wlo, whi) is redirected
+  // to the slot of the acoustic step being run, so that the backward sweep finds that step's intermediates without
+  // recomputing them.
+  double* wlo = nullptr; double* whi = nullptr; std::ptrdiff_t tshift = 0;
+  Fld sh(const Fld& f) const { Fld r = f; if (tshift && f.t >= wlo && f.t < whi) r.t = f.t + tshift; return r; }
   long launches = 0;
   bool profiling = false;
   std::vector<ProfRec> recs;
@@ -456,7 +462,12 @@ void for_points(Exec& ex, const Rect& R, int nz, const F& f, const char* tag = "
 #endif
 
 template <class S>
-void run(Exec& ex, int mode, const S& s, const Ctx& c) {
+void run(Exec& ex, int mode, const S& s0, const Ctx& c) {
+  S s = s0;
+  if (ex.tshift) {
+    for (int m = 0; m < S::NIN; ++m) s.in[m] = ex.sh(s.in[m]);
+    for (int n = 0; n < S::NOUT; ++n) s.out[n] = ex.sh(s.out[n]);
+  }
   if (mode == MODE_NL) run_nl(ex, s, c);
   else if (mode == MODE_TL) run_tl(ex, s, c);
   else run_ad(ex, s, c);

@@ -104,3 +104,14 @@ def test_tracer_subcycling(case_q):
     check_tracer(case_q, TL, 1e-11, scale=10.0)
     check_tracer(case_q, AD, 1e-10, scale=10.0)
     assert case_q.dy.lib.L.fv3lm_tracer_nsplt(case_q.dy.h) >= 2
+
+
+@pytest.mark.parametrize("slots", ["0", "1"])
+def test_trajectory_slots(slots, monkeypatch):
+    """The backward sweep either finds a step's intermediates in a trajectory slot or recomputes them from the 4-field
+    checkpoint (FV3LM_TRAJ_SLOTS caps the number of slots; default: as many as fit): same adjoint either way."""
+    monkeypatch.setenv("FV3LM_TRAJ_SLOTS", slots)
+    c = Case(nx=12, ny=10, npz=6, n_split=3, dt=1800.0, backend="emul")
+    check_dyn_core(c, AD, 1e-10)
+    lhs, rhs = dot_product_test(c)
+    assert abs(lhs - rhs) <= 1e-12 * abs(lhs), (lhs, rhs)
