@@ -329,8 +329,11 @@ HD void xcd_block(int gx, int gy, int& bx, int& by) {
   const int logical = (res < r ? res * (q + 1) : r * (q + 1) + (res - r) * q) + l / 8;
   bx = logical % gx; by = logical / gx;
 }
+// tr = lanes per row.  0: the normal mapping, a wave = 64 consecutive points of one row.  8 or 16 (narrow column strips of
+// the face-edge stages): a wave covers 64/tr rows of tr points, so its loads touch 64/tr short row pieces instead of one
+// point of 64 different rows.
 HD void thread_point(const Rect& R, int tr, int bx, int by, int tx, int ty, int& i, int& j) {
-  if (tr) { j = R.j0 + bx * BX + tx; i = R.i0 + by * BY + ty; }
+  if (tr) { const int rows = BX / tr; i = R.i0 + bx * tr + tx % tr; j = R.j0 + (by * BY + ty) * rows + tx / tr; }
   else { i = R.i0 + bx * BX + tx; j = R.j0 + by * BY + ty; }
 }
 template <class S>
@@ -355,9 +358,13 @@ __global__ void __launch_bounds__(64) k_stage_ad_alias(S s, Ctx c, Rect R) {
   corner_block_point(c.g, blockIdx.x, threadIdx.x, i, j);
   AdAliasLoop<S, 0>::run(s, c, R, i, j, blockIdx.y);
 }
-inline int strip_tr(const Rect& R) { return (R.i1 - R.i0 + 1 <= 2 * BY && R.j1 - R.j0 + 1 >= BX / 2) ? 1 : 0; }
+inline int strip_tr(const Rect& R) {
+  const int w = R.i1 - R.i0 + 1, h = R.j1 - R.j0 + 1;
+  if (h < BX / 2) return 0;
+  return w <= 8 ? 8 : w <= 16 ? 16 : 0;
+}
 inline dim3 grid_for(const Rect& R, int nz, int tr = 0) {
-  if (tr) return dim3((R.j1 - R.j0 + BX) / BX, (R.i1 - R.i0 + BY) / BY, nz);
+  if (tr) { const int rows = BY * (BX / tr); return dim3((R.i1 - R.i0 + tr) / tr, (R.j1 - R.j0 + rows) / rows, nz); }
   return dim3((R.i1 - R.i0 + BX) / BX, (R.j1 - R.j0 + BY) / BY, nz);
 }
 template <class S>
