@@ -207,7 +207,9 @@ def main():
                                                            % (world, "/".join(str(len(cube.faces_of(r, world))) for r in range(world)),
                                                               ", RCCL point-to-point between ranks" if world > 1 else "")) if cube_mode
                                       else "1 doubly-periodic tile per GPU", cols_rank, args.k_split, args.n_split, args.dt, args.nq),
-                       "columns_per_gpu": cols_rank, "launches_per_step": sum(v[0] for v in prof.values())},
+                       "columns_per_gpu": cols_rank, "launches_per_step": sum(v[0] for v in prof.values()),
+                       "trajectory_slots": "%d of %d acoustic steps keep their intermediates in HBM (no recompute in the backward sweep)"
+                                           % (lib.L.fv3lm_traj_slots(c.dy.h), args.n_split * args.k_split)},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "launches_per_step": cnt, "avg_launch_ms": ms / cnt, "algorithmic_bytes_per_launch": by / cnt,

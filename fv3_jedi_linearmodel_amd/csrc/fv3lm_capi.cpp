@@ -141,6 +141,7 @@ int fv3lm_tracer_2d(fv3lm_handle* h, int mode) {
   if (mode == MODE_AD) h->d.tracer_ad(); else h->d.tracer_fwd(mode);
   return status(h);
 }
+int fv3lm_traj_slots(fv3lm_handle* h) { return (int)h->d.traj_slot.size(); }   /* acoustic steps whose intermediates stay resident */
 int fv3lm_tracer_nsplt(fv3lm_handle* h) { return h->d.nsplt_max; }   /* largest sub-step count tracer_2d has used so far */
 int fv3lm_remap(fv3lm_handle* h, int mode, int last_step) { run_remap(h->d.ex, mode, h->d.remap_args(last_step != 0)); return 0; }
 int fv3lm_fv_dynamics(fv3lm_handle* h, int mode) { h->d.fv_dynamics(mode); return status(h); }

@@ -114,6 +114,9 @@ int fv3lm_step_ad(fv3lm_handle* h);
 /* Sub-operators, same mode argument (tests and kernel-level benchmarks): */
 int fv3lm_pressures(fv3lm_handle* h, int mode);                 /* compute_fv3_pressures{,_tlm,_bwd} TLM/fv_pressure.F90 */
 int fv3lm_tracer_2d(fv3lm_handle* h, int mode);                 /* TRACER_2D_TLM fv_tracer2d_tlm.F90:757 / _FWD+_BWD */
+int fv3lm_traj_slots(fv3lm_handle* h);                          /* acoustic steps (of n_split*k_split) whose intermediates the forward sweep keeps
+                                                                   in HBM so that the backward sweep need not recompute them; chosen at create from free memory,
+                                                                   FV3LM_TRAJ_SLOTS caps it */
 int fv3lm_tracer_nsplt(fv3lm_handle* h);                        /* largest tracer sub-step count (nsplt, fv_tracer2d_tlm.F90:1317) used so far */
 int fv3lm_remap(fv3lm_handle* h, int mode, int last_step);      /* LAGRANGIAN_TO_EULERIAN_TLM fv_mapz_tlm.F90:69 / _FWD+_BWD */
 int fv3lm_fv_dynamics(fv3lm_handle* h, int mode);               /* FV_DYNAMICS_TLM fv_dynamics_tlm.F90:87 / _FWD+_BWD */
