@@ -85,6 +85,27 @@ int fv3lm_set_face_data(fv3lm_handle* h, const double* edge, const double* ecorn
  * plane, tiles 0-based among the resident ones; field 0/1 = first/second component of a pair). */
 int fv3lm_set_exchange(fv3lm_handle* h, int kind, const int* rows, int nrows);
 int fv3lm_halo(fv3lm_handle* h, int kind, const char* field0, const char* field1, int mode);   /* one exchange (tests) */
+/* Faces held by other ranks (one process per GPU).  The rows of a table whose source face lives on another rank become, per
+ * peer, a send list (send_rows[.][3] = field, local tile, index of the source element) and a receive list (recv_rows[.][4] =
+ * field, local tile, index of the halo element, sign), concatenated over the peers in peers[] order; both ends must list the
+ * rows in the order of the global table (cube.split_table).  nsend[p] / nrecv[p] = rows for peer p. */
+int fv3lm_set_exchange_remote(fv3lm_handle* h, int kind, int npeers, const int* peers, const int* nsend, const int* send_rows,
+                              const int* nrecv, const int* recv_rows);
+/* Transport between ranks: RCCL point-to-point (ncclSend / ncclRecv, grouped per exchange) on the library's own stream.
+ * rccl_path: the RCCL shared library the process already uses (e.g. the one bundled with torch), opened with dlopen so that a
+ * process never runs two RCCL runtimes; id128: 128-byte ncclUniqueId made by fv3lm_comm_unique_id on rank 0 and distributed by
+ * the host (mpp_broadcast / MPI_Bcast / torch.distributed); every rank that holds faces then calls fv3lm_comm_init. */
+int fv3lm_comm_unique_id(const char* rccl_path, void* id128);
+int fv3lm_comm_init(const char* rccl_path, const void* id128, int nranks, int rank);
+int fv3lm_comm_destroy(void);
+/* Host hooks.  Transport callback: replaces RCCL (the test-only host-emulation build has no other transport): called once per
+ * exchange with one send and one receive buffer per peer, counts in doubles.  All-reduce callback: in-place element-wise max
+ * over the ranks that hold faces, for tracer_2d's per-level Courant maxima (mp_reduce_max, fv_tracer2d_tlm.F90:1306). */
+typedef void (*fv3lm_transport_fn)(void* user, int npeers, const int* peer_ranks, double* const* sendbufs, const long* send_counts,
+                                   double* const* recvbufs, const long* recv_counts);
+typedef void (*fv3lm_allreduce_fn)(void* user, double* buf, int n);
+int fv3lm_set_transport_callback(fv3lm_transport_fn fn, void* user);
+int fv3lm_set_allreduce_callback(fv3lm_allreduce_fn fn, void* user);
 int fv3lm_destroy(fv3lm_handle* h);     /* %delete, DYN/fv3jedi_lm_dynamics_mod.F90:693-713 */
 const char* fv3lm_last_error(void);
 
