@@ -55,12 +55,12 @@ def pmc_traffic(kernel, args, cube_mode, world):
 
 def cpu_baseline(args, opt):
     """Oracle port (oracle/liboracle.so, one host core) on a bounded sample of the same workload:
-    a 10x10-column tile with the same npz / k_split / n_split / nq."""
+    a 14x14-column tile with the same npz / k_split / n_split / nq (10-20 s of CPU work)."""
     import numpy as np
     from common import Case
     from groups import step_state
     from oracle import NL, TL, AD
-    nx = 10
+    nx = 14
     c = Case(nx=nx, ny=nx, npz=args.npz, n_split=args.n_split, k_split=args.k_split, dt=args.dt, backend="none", nq=args.nq)
     T, P = step_state(c)
     ins_n = ["u", "v", "pt", "delp", "pe", "peln", "pk", "pkz"] + ["q%d" % (n + 1) for n in range(c.nq)]
