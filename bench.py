@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--nq", type=int, default=4)
     ap.add_argument("--tiles", choices=["cube", "periodic"], default="cube")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-host-transport", action="store_true",
+                    help="multi-rank rehearsal on ONE GPU (RCCL refuses two ranks per device): gloo process group, halo messages staged "
+                         "through host memory by a transport callback; exercises everything but the RCCL send/recv calls themselves")
     ap.add_argument("--profile-out", default="")
     args = ap.parse_args()
 
@@ -100,8 +103,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.rehearse_host_transport:
+            local = 0
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     import ctypes as C
     import fv3_jedi_linearmodel_amd as fv3
     from common import Case, CubeCase
@@ -113,7 +120,35 @@ def main():
     if cube_mode:
         from fv3_jedi_linearmodel_amd import cube
         from fv3_jedi_linearmodel_amd._lib import comm_init_rccl
-        if world > 1:      # one RCCL communicator for the face exchange; rank 0's unique id travels through torch.distributed
+        if world > 1 and args.rehearse_host_transport:
+            import numpy as np
+            from fv3_jedi_linearmodel_amd._lib import set_transport_callback, set_allreduce_callback
+            hip = C.CDLL("libamdhip64.so")
+            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+            def transport(peers, sbufs, rbufs):      # sbufs / rbufs are views of DEVICE memory: stage through host
+                reqs, stage = [], []
+                for p, r in zip(peers, rbufs):
+                    if r.size:
+                        h = torch.empty(r.size, dtype=torch.float64); stage.append((r, h)); reqs.append(dist.irecv(h, src=p))
+                for p, s_ in zip(peers, sbufs):
+                    if s_.size:
+                        h = torch.empty(s_.size, dtype=torch.float64)
+                        assert hip.hipMemcpy(h.data_ptr(), s_.ctypes.data, s_.size * 8, 2) == 0
+                        reqs.append(dist.isend(h, dst=p))
+                for q in reqs:
+                    q.wait()
+                for r, h in stage:
+                    assert hip.hipMemcpy(r.ctypes.data, h.data_ptr(), r.size * 8, 1) == 0
+            set_transport_callback(lib, transport)
+            grp = dist.new_group(ranks=list(range(min(world, 6))))
+            if rank < min(world, 6):
+                def allmax(buf):
+                    t = torch.from_numpy(buf.copy())
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=grp)
+                    buf[:] = t.numpy()
+                set_allreduce_callback(lib, allmax)
+        elif world > 1:    # one RCCL communicator for the face exchange; rank 0's unique id travels through torch.distributed
             def bcast(data):
                 t = torch.zeros(128, dtype=torch.uint8, device="cuda")
                 if rank == 0:
@@ -160,7 +195,8 @@ def main():
             c.dy.sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         if active:
             c.dy.sync()
 
@@ -173,7 +209,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_host_transport else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
