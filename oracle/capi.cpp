@@ -9,6 +9,7 @@
 #include "fv_dynamics.hpp"
 #include "fv_pressure.hpp"
 #include "cube.hpp"
+#include "nh.hpp"
 #include <memory>
 #include <string>
 
@@ -279,6 +280,23 @@ void orc_dyn_core(void* hv, int mode, double bdt, int n_split, double** in_t, do
     dyn_core(s, h->phis, npz, bdt, n_split, h->o, h->c, h->ptop, h->g, h->bd);
     y[0] = s.u; y[1] = s.v; y[2] = s.pt; y[3] = s.delp; y[4] = s.mfx; y[5] = s.mfy; y[6] = s.cx; y[7] = s.cy;
     y[8] = s.pe; y[9] = s.peln; y[10] = s.pk; y[11] = s.pkz;
+  });
+}
+
+// non-hydrostatic dyn_core (n_split acoustic steps).  in: u, v, pt, delp, w, delz   out: u, v, pt, delp, w, delz (npz), pe, peln, pk, zh (npz+1)
+void orc_dyn_core_nh(void* hv, int mode, double bdt, int n_split, double a_imp, double p_fac, double scale_z, double** in_t, double** in_p,
+                     double** out_t, double** out_p) {
+  OrcHandle* h = (OrcHandle*)hv; int npz = h->npz;
+  std::vector<int> nk(6, npz); int nko[10] = {npz, npz, npz, npz, npz, npz, npz + 1, npz + 1, npz + 1, npz + 1};
+  auto in = mkio(6, in_t, in_p, nk.data()); auto out = mkio(10, out_t, out_p, nko);
+  NhOpts nh; nh.a_imp = a_imp; nh.p_fac = p_fac; nh.scale_z = scale_z;
+  drive(mode, h->bd, in, out, [&](auto& x, auto& y) {
+    using T = typename std::decay<decltype(x[0].p[0].d[0])>::type;
+    DynState<T> s; s.init(h->bd, npz, 0);
+    NhState<T> n; n.zh.init(h->bd, npz + 1);
+    s.u = x[0]; s.v = x[1]; s.pt = x[2]; s.delp = x[3]; n.w = x[4]; n.delz = x[5];
+    dyn_core_nh(s, n, h->phis, npz, bdt, n_split, h->o, h->c, h->ptop, h->ak, h->bk, nh, h->g, h->bd);
+    y[0] = s.u; y[1] = s.v; y[2] = s.pt; y[3] = s.delp; y[4] = n.w; y[5] = n.delz; y[6] = s.pe; y[7] = s.peln; y[8] = s.pk; y[9] = n.zh;
   });
 }
 

@@ -284,12 +284,16 @@ void fill2_4corners(Arr2<T>& q1, Arr2<T>& q2, int dir, const Bounds& bd) {
   }
 }
 
-// c_sw, hydrostatic, sw_core_tlm.F90:646-1038.  delp/pt corner halos are filled in place by the
+// fill_4corners (one field; the same two-point pattern as fill2_4corners), sw_core_tlm.F90:6953-7060
+template <class T>
+void fill_4corners(Arr2<T>& q, int dir, const Bounds& bd) { Arr2<T> other = q; fill2_4corners(q, other, dir, bd); }
+
+// c_sw, sw_core_tlm.F90:646-1038.  Non-hydrostatic (w_in, wc given): w is carried by the same upwind fluxes (:758-778, :812-838).  delp/pt corner halos are filled in place by the
 // reference (intent(inout)); the oracle works on copies.
 template <class T>
 void c_sw(Arr2<T>& delpc, const Arr2<T>& delp_in, Arr2<T>& ptc, const Arr2<T>& pt_in, const Arr2<T>& u, const Arr2<T>& v,
           Arr2<T>& uc, Arr2<T>& vc, Arr2<T>& ua, Arr2<T>& va, Arr2<T>& ut, Arr2<T>& vt, Arr2<T>& divg_d, int nord,
-          double dt2, const Grid& g, const Bounds& bd) {
+          double dt2, const Grid& g, const Bounds& bd, const Arr2<T>* w_in = nullptr, Arr2<T>* wc = nullptr) {
   const int is = bd.is, ie = bd.ie, js = bd.js, je = bd.je, iep1 = ie + 1, jep1 = je + 1, npx = bd.npx, npy = bd.npy;
   const bool face = bd.any_edge();
   Arr2<T> delp = delp_in, pt = pt_in;
@@ -305,27 +309,33 @@ void c_sw(Arr2<T>& delpc, const Arr2<T>& delp_in, Arr2<T>& ptc, const Arr2<T>& p
       if (val(vt(i, j)) > 0.) vt(i, j) = dt2 * vt(i, j) * g.dx(i, j) * g.sin_sg[4](i, j - 1);
       else                    vt(i, j) = dt2 * vt(i, j) * g.dx(i, j) * g.sin_sg[2](i, j);
     }
-  Arr2<T> fx(bd), fx1(bd), fy(bd), fy1(bd), ke(bd), vort(bd);
+  Arr2<T> fx(bd), fx1(bd), fy(bd), fy1(bd), ke(bd), vort(bd), fx2(bd), fy2(bd), w(bd);
+  if (w_in) w = *w_in;
   if (face) fill2_4corners(delp, pt, 1, bd);  // :739-741
+  if (w_in && face) fill_4corners(w, 1, bd);
   for (int j = js - 1; j <= jep1; ++j)        // :744-757
     for (int i = is - 1; i <= ie + 2; ++i) {
       if (val(ut(i, j)) > 0.) { fx1(i, j) = delp(i - 1, j); fx(i, j) = pt(i - 1, j); }
       else                    { fx1(i, j) = delp(i, j);     fx(i, j) = pt(i, j); }
       fx1(i, j) = ut(i, j) * fx1(i, j);
       fx(i, j) = fx1(i, j) * fx(i, j);
+      if (w_in) fx2(i, j) = fx1(i, j) * ((val(ut(i, j)) > 0.) ? w(i - 1, j) : w(i, j));
     }
   if (face) fill2_4corners(delp, pt, 2, bd);  // :784-786
+  if (w_in && face) fill_4corners(w, 2, bd);
   for (int j = js - 1; j <= jep1 + 1; ++j)    // :788-800
     for (int i = is - 1; i <= iep1; ++i) {
       if (val(vt(i, j)) > 0.) { fy1(i, j) = delp(i, j - 1); fy(i, j) = pt(i, j - 1); }
       else                    { fy1(i, j) = delp(i, j);     fy(i, j) = pt(i, j); }
       fy1(i, j) = vt(i, j) * fy1(i, j);
       fy(i, j) = fy1(i, j) * fy(i, j);
+      if (w_in) fy2(i, j) = fy1(i, j) * ((val(vt(i, j)) > 0.) ? w(i, j - 1) : w(i, j));
     }
   for (int j = js - 1; j <= jep1; ++j)        // :801-808
     for (int i = is - 1; i <= iep1; ++i) {
       delpc(i, j) = delp(i, j) + (fx1(i, j) - fx1(i + 1, j) + (fy1(i, j) - fy1(i, j + 1))) * g.rarea(i, j);
       ptc(i, j) = (pt(i, j) * delp(i, j) + (fx(i, j) - fx(i + 1, j) + (fy(i, j) - fy(i, j + 1))) * g.rarea(i, j)) / delpc(i, j);
+      if (w_in) (*wc)(i, j) = (w(i, j) * delp(i, j) + (fx2(i, j) - fx2(i + 1, j) + (fy2(i, j) - fy2(i, j + 1))) * g.rarea(i, j)) / delpc(i, j);
     }
   // KE: upstream C-grid wind, true covariant wind at face edges (:853-917)
   for (int j = js - 1; j <= jep1; ++j)
@@ -633,7 +643,7 @@ template <class T>
 void d_sw(Arr2<T>& delp, Arr2<T>& pt, Arr2<T>& u, Arr2<T>& v, Arr2<T>& uc, Arr2<T>& vc, const Arr2<T>& ua,
           const Arr2<T>& va, Arr2<T>& divg_d, Arr2<T>& xflux, Arr2<T>& yflux, Arr2<T>& cx, Arr2<T>& cy,
           Arr2<T>& crx_adv, Arr2<T>& cry_adv, Arr2<T>& xfx_adv, Arr2<T>& yfx_adv, double dt, const LevelParams& lp,
-          double dddmp, double d4_bg, const Grid& g, const Bounds& bd) {
+          double dddmp, double d4_bg, const Grid& g, const Bounds& bd, Arr2<T>* w = nullptr) {
   const int is = bd.is, ie = bd.ie, js = bd.js, je = bd.je, isd = bd.isd, ied = bd.ied, jsd = bd.jsd, jed = bd.jed;
   const int npx = bd.npx, npy = bd.npy;
   const bool face = bd.any_edge();
@@ -768,6 +778,19 @@ void d_sw(Arr2<T>& delp, Arr2<T>& pt, Arr2<T>& u, Arr2<T>& v, Arr2<T>& uc, Arr2<
     for (int i = isd; i <= ied; ++i) cy(i, j) = cy(i, j) + cry_adv(i, j);
     for (int i = is; i <= ie; ++i) yflux(i, j) = yflux(i, j) + fy(i, j);
   }
+  // non-hydrostatic: del-2/4 damping increment of w and transport of w with the mass fluxes (:3020-3062)
+  Arr2<T> dw(bd);
+  if (w) {
+    if (lp.damp_w > 1.e-5) {
+      const double damp4 = std::pow(lp.damp_w * g.da_min_c, lp.nord_w + 1);
+      del6_vt_flux(lp.nord_w, damp4, *w, wk, fx2, fy2, g, bd);
+      for (int j = js; j <= je; ++j)
+        for (int i = is; i <= ie; ++i) dw(i, j) = (fx2(i, j) - fx2(i + 1, j) + (fy2(i, j) - fy2(i, j + 1))) * g.rarea(i, j);
+    }
+    fv_tp_2d<T>(*w, crx_adv, cry_adv, lp.hord_vt, gx, gy, xfx_adv, yfx_adv, g, bd, ra_x, ra_y, &fx, &fy, nullptr, -1, 0.0);
+    for (int j = js; j <= je; ++j)
+      for (int i = is; i <= ie; ++i) (*w)(i, j) = delp(i, j) * (*w)(i, j) + (gx(i, j) - gx(i + 1, j) + (gy(i, j) - gy(i, j + 1))) * g.rarea(i, j);
+  }
   // pt transport (:3064-3072): mass=delp, nord_t, damp_t
   fv_tp_2d<T>(pt, crx_adv, cry_adv, lp.hord_tm, gx, gy, xfx_adv, yfx_adv, g, bd, ra_x, ra_y, &fx, &fy, &delp,
               lp.nord_t, lp.damp_t);
@@ -820,6 +843,13 @@ void d_sw(Arr2<T>& delp, Arr2<T>& pt, Arr2<T>& u, Arr2<T>& v, Arr2<T>& uc, Arr2<
     for (int i = isd; i <= ied + 1; ++i) ut(i, j) = v(i, j) * g.dy(i, j);
   for (int j = jsd; j <= jed; ++j)
     for (int i = isd; i <= ied; ++i) wk(i, j) = g.rarea(i, j) * (vt(i, j) - vt(i, j + 1) + (ut(i + 1, j) - ut(i, j)));
+  if (w) {   // :3305-3330 (new delp)
+    for (int j = js; j <= je; ++j)
+      for (int i = is; i <= ie; ++i) {
+        (*w)(i, j) = (*w)(i, j) / delp(i, j);
+        if (lp.damp_w > 1.e-5) (*w)(i, j) = (*w)(i, j) + dw(i, j);
+      }
+  }
   compute_divergence_damping(lp.nord, lp.d2_divg, d4_bg, dddmp, dt, vort, ptc, delpc, ke, u, v, uc, vc, ua, va,
                              divg_d, wk, g, bd);
   for (int j = jsd; j <= jed; ++j)            // :3535-3540 hydrostatic

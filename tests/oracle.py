@@ -106,6 +106,11 @@ class Oracle:
         return self._call("orc_dyn_core", mode, [C.c_double(bdt), C.c_int(n_split)], ins, ins_p,
                           [n] * 8 + [n + 1, n + 1, n + 1, n], outs_p)
 
+    def dyn_core_nh(self, mode, bdt, n_split, ins, ins_p=None, outs_p=None, a_imp=0.75, p_fac=0.05, scale_z=0.0):
+        n = self.npz
+        return self._call("orc_dyn_core_nh", mode, [C.c_double(bdt), C.c_int(n_split), C.c_double(a_imp), C.c_double(p_fac), C.c_double(scale_z)],
+                          ins, ins_p, [n] * 6 + [n + 1] * 4, outs_p)
+
     def fv_tp_2d(self, mode, hord, nord, damp_c, use_mf, use_mass, ins, ins_p=None, outs_p=None):
         return self._call("orc_fv_tp_2d", mode, [C.c_int(hord), C.c_int(nord), C.c_double(damp_c), C.c_int(use_mf),
                                                  C.c_int(use_mass)], ins, ins_p, [1, 1], outs_p)

@@ -1,0 +1,81 @@
+"""CPU (-m "not gpu") self-consistency checks of the non-hydrostatic oracle (oracle/nh.hpp: update_dz_c/d, riem_solver_c/3,
+SIM1/SIM solvers, nh_p_grad, w transport): groundwork for SURVEY.md §8 row a7, whose product side is not built yet.  The
+restatement is checked against itself: the dual-number tangent equals centred finite differences of the nonlinear code, and
+the taped adjoint is the transpose of the tangent (dot-product identity)."""
+import numpy as np
+import pytest
+from common import Case
+from oracle import NL, TL, AD
+
+
+def nh_state(c, seed=5):
+    """hydrostatically balanced w = small, delz from delp, pt (theta_v) so that the non-hydrostatic pressure equals the layer mean"""
+    o = c.opt
+    delp, pt = c.traj["delp"][0], c.traj["pt"][0]
+    pe = np.concatenate([np.full_like(delp[:1], o.ptop), o.ptop + np.cumsum(delp, axis=0)], axis=0)
+    pm = delp / np.diff(np.log(pe), axis=0)
+    delz = -(delp / o.grav) * o.rdgas * pt / pm ** (1.0 - o.akap)
+    rng = np.random.default_rng(seed)
+    from fv3_jedi_linearmodel_amd.grid import _smooth_field, halo_fill_periodic
+    w = halo_fill_periodic(_smooth_field(rng, (1,) + delp.shape, c.nx, c.ny, 0.05), c.nx, c.ny)[0]
+    T = [c.traj["u"][0], c.traj["v"][0], pt, delp, w, delz]
+    P = [c.pert["u"][0], c.pert["v"][0], c.pert["pt"][0], c.pert["delp"][0],
+         halo_fill_periodic(_smooth_field(rng, (1,) + delp.shape, c.nx, c.ny, 0.01), c.nx, c.ny)[0],
+         halo_fill_periodic(_smooth_field(rng, (1,) + delp.shape, c.nx, c.ny, 0.5), c.nx, c.ny)[0]]
+    return T, P
+
+
+@pytest.fixture(scope="module")
+def nhcase():
+    return Case(nx=10, ny=8, npz=8, n_split=2, dt=600.0, backend="none", hord_ks_traj=0, hord_ks_pert=0)
+
+
+@pytest.fixture(scope="module")
+def nhcase_fd():
+    """The reference damps the vorticity of the perturbation with its own coefficients (sw_core_tlm.F90:2436-2452), so its
+    tangent is the derivative of the nonlinear code only where both sets coincide: vorticity damping off on both sides here."""
+    return Case(nx=10, ny=8, npz=8, n_split=2, dt=600.0, backend="none", hord_ks_traj=0, hord_ks_pert=0, do_vort_damp=0,
+                do_vort_damp_pert=0)
+
+
+def test_nh_nonlinear_is_quiet(nhcase):
+    c = nhcase
+    T, P = nh_state(c)
+    out, _ = c.oracle.dyn_core_nh(NL, c.dims.dt, c.dims.n_split, T)
+    A = c.rect(1, c.nx, 1, c.ny)
+    for a in out:
+        assert np.all(np.isfinite(a[A]))
+    assert np.max(np.abs(out[4][A])) < 5.0            # w stays small from a balanced start
+    assert np.max(np.abs(out[5][A] / T[5][A] - 1.0)) < 0.05   # layer thickness changes by a few per cent at most
+
+
+def test_nh_tangent_matches_finite_differences(nhcase_fd):
+    c = nhcase_fd
+    T, P = nh_state(c)
+    _, tl = c.oracle.dyn_core_nh(TL, c.dims.dt, c.dims.n_split, T, P)
+    eps = 1e-6
+    up, _ = c.oracle.dyn_core_nh(NL, c.dims.dt, c.dims.n_split, [t + eps * p for t, p in zip(T, P)])
+    dn, _ = c.oracle.dyn_core_nh(NL, c.dims.dt, c.dims.n_split, [t - eps * p for t, p in zip(T, P)])
+    A = c.rect(1, c.nx, 1, c.ny)
+    for n in range(6):
+        fd = (up[n][A] - dn[n][A]) / (2 * eps)
+        scale = max(1e-30, np.max(np.abs(tl[n][A])))
+        assert np.max(np.abs(fd - tl[n][A])) / scale < 2e-5, n
+
+
+def test_nh_adjoint_dot_product(nhcase):
+    c = nhcase
+    T, P = nh_state(c)
+    _, tl = c.oracle.dyn_core_nh(TL, c.dims.dt, c.dims.n_split, T, P)
+    rng = np.random.default_rng(9)
+    A = c.rect(1, c.nx, 1, c.ny)
+    seeds = []
+    for n, a in enumerate(tl):
+        s = np.zeros_like(a)
+        if n < 6:
+            s[A] = rng.standard_normal(a[A].shape) / max(1e-30, np.max(np.abs(a[A])))
+        seeds.append(s)
+    _, ad = c.oracle.dyn_core_nh(AD, c.dims.dt, c.dims.n_split, T, None, seeds)
+    lhs = sum(float(np.sum(a * s)) for a, s in zip(tl, seeds))
+    rhs = sum(float(np.sum(a * p)) for a, p in zip(ad, P))
+    assert abs(lhs - rhs) <= 1e-10 * abs(lhs), (lhs, rhs)
