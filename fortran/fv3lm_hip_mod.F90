@@ -35,6 +35,7 @@ module fv3lm_hip_mod
     real(c_double) :: akap, cp, zvir, grav_jedi
     real(c_double) :: cp_air, rdgas, rvgas, grav, radius, omega, hlv
     real(c_double) :: ptop
+    real(c_double) :: a_imp, p_fac, scale_z
   end type fv3lm_options
 
   type, bind(C) :: fv3lm_dims

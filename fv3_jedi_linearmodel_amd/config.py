@@ -19,14 +19,14 @@ class Options(C.Structure):
         + [(n, C.c_double) for n in (
             "dddmp d2_bg d4_bg vtdm4 d2_bg_k1 d2_bg_k2 d_con ke_bg "
             "dddmp_pert d2_bg_pert d4_bg_pert vtdm4_pert d2_bg_k1_pert d2_bg_k2_pert d2_bg_ks_pert "
-            "akap cp zvir grav_jedi cp_air rdgas rvgas grav radius omega hlv ptop").split()]
+            "akap cp zvir grav_jedi cp_air rdgas rvgas grav radius omega hlv ptop a_imp p_fac scale_z").split()]
     )
 
     def int_list(self):
         return [getattr(self, n) for n, t in self._fields_ if t is C.c_int]
 
     def real_list(self):
-        return [getattr(self, n) for n, t in self._fields_ if t is C.c_double]
+        return [getattr(self, n) for n, t in self._fields_ if t is C.c_double and n not in ("a_imp", "p_fac", "scale_z")]
 
 
 class Dims(C.Structure):
@@ -70,6 +70,7 @@ def default_options(**kw):
     o.rdgas, o.rvgas, o.grav, o.radius, o.omega, o.hlv = 287.04, 461.50, 9.80, 6371.0e3, 7.292e-5, 2.500e6
     o.cp_air = o.rdgas / kappa
     o.ptop = 1.0
+    o.a_imp, o.p_fac, o.scale_z = 0.75, 0.05, 0.0    # non-hydrostatic solver (fv_flags_type defaults; the reference default a_imp = 0.75)
     for k, v in kw.items():
         if not hasattr(o, k):
             raise AttributeError(k)

@@ -1,0 +1,132 @@
+// fv3lm-hip: reverse mode for column (k-sequential) operators without hand-written adjoints.
+//
+// The stencil stages get their adjoint from the gather launcher (exec.h).  Column operators — the non-hydrostatic
+// solvers with their Thomas sweeps — are sequential in k and have hundreds of dependent statements per column, so they
+// are written once on a generic scalar and run three ways by the same kernel:
+//   nonlinear  T = double
+//   tangent    T = Dual
+//   adjoint    T = TV, a taped scalar: every arithmetic operation appends (operand ids, partial derivatives) to the
+//              thread's tape, laid out [entry][column] in global memory so that the lanes of a wave write and read
+//              contiguous rows; after the forward replay the same thread walks its tape backwards.  Inputs are leaves
+//              whose adjoint is added to the field's adjoint buffer; an output store moves the field's incoming adjoint onto
+//              the stored variable.  This is the role utils/tapenade/adStack.c plays for the reference, confined to the
+//              column operators and resident in HBM.
+#pragma once
+#include "remap.h"
+
+namespace fv3 {
+
+struct TapeMem {
+  double* part = nullptr;   // [2*cap][stride] partial derivatives
+  int* idx = nullptr;       // [2*cap][stride] operand ids (>= 0 variable, -1 none, <= -2 leaf: field slot, level)
+  double* adj = nullptr;    // [cap][stride]
+  int* overflow = nullptr;  // device flag
+  size_t stride = 0; int cap = 0;
+};
+struct Tape {
+  TapeMem m; size_t col; int n;
+  HD int push(int ia, int ib, double pa, double pb) {
+    if (n >= m.cap) { *m.overflow = 1; return -1; }
+    const int id = n++;
+    const size_t e = (size_t)(2 * id) * m.stride + col;
+    m.part[e] = pa; m.part[e + m.stride] = pb; m.idx[e] = ia; m.idx[e + m.stride] = ib;
+    m.adj[(size_t)id * m.stride + col] = 0.;
+    return id;
+  }
+  HD double& ad(int id) const { return m.adj[(size_t)id * m.stride + col]; }
+};
+struct TV {
+  double v; int id; Tape* t;
+  HD TV() : v(0.), id(-1), t(nullptr) {}
+  HD TV(double v_) : v(v_), id(-1), t(nullptr) {}
+  HD TV(double v_, int id_, Tape* t_) : v(v_), id(id_), t(t_) {}
+};
+HD Tape* tape_of(const TV& a, const TV& b) { return a.t ? a.t : b.t; }
+HD TV tv2(const TV& a, const TV& b, double v, double pa, double pb) {
+  Tape* t = tape_of(a, b);
+  if (!t || (a.id < 0 && b.id < 0)) return TV(v);
+  return TV(v, t->push(a.id, b.id, pa, pb), t);
+}
+HD TV tv1(const TV& a, double v, double pa) {
+  if (!a.t || a.id < 0) return TV(v);
+  return TV(v, a.t->push(a.id, -1, pa, 0.), a.t);
+}
+HD TV operator+(const TV& a, const TV& b) { return tv2(a, b, a.v + b.v, 1., 1.); }
+HD TV operator-(const TV& a, const TV& b) { return tv2(a, b, a.v - b.v, 1., -1.); }
+HD TV operator*(const TV& a, const TV& b) { return tv2(a, b, a.v * b.v, b.v, a.v); }
+HD TV operator/(const TV& a, const TV& b) { const double r = 1. / b.v, q = a.v * r; return tv2(a, b, q, r, -q * r); }
+HD TV operator-(const TV& a) { return tv1(a, -a.v, -1.); }
+HD TV operator+(const TV& a, double b) { return tv1(a, a.v + b, 1.); }
+HD TV operator+(double a, const TV& b) { return tv1(b, a + b.v, 1.); }
+HD TV operator-(const TV& a, double b) { return tv1(a, a.v - b, 1.); }
+HD TV operator-(double a, const TV& b) { return tv1(b, a - b.v, -1.); }
+HD TV operator*(const TV& a, double b) { return tv1(a, a.v * b, b); }
+HD TV operator*(double a, const TV& b) { return tv1(b, a * b.v, a); }
+HD TV operator/(const TV& a, double b) { return tv1(a, a.v / b, 1. / b); }
+HD TV operator/(double a, const TV& b) { const double q = a / b.v; return tv1(b, q, -q / b.v); }
+HD TV dlog(const TV& a) { return tv1(a, log(a.v), 1. / a.v); }
+HD TV dexp(const TV& a) { const double e = exp(a.v); return tv1(a, e, e); }
+HD double val(const TV& a) { return a.v; }
+
+// workspace storage of a taped scalar: value + id (as a double)
+template <> struct WsIO<TV> {
+  static constexpr int W = 2;
+  HD static TV get(const ColWs& w, int s, int k, Tape* t) { return TV(w.at(2 * s, k), (int)w.at(2 * s + 1, k), t); }
+  HD static void set(const ColWs& w, int s, int k, const TV& x) { w.at(2 * s, k) = x.v; w.at(2 * s + 1, k) = (double)x.id; }
+};
+
+// ---- the three ways a column operator touches its fields: f[slot] element (i, j, k) of the thread's column
+struct ColNL {
+  typedef double T;
+  const Geom& g; const Fld* f; int tile, i, j; Tape* tape;
+  HD double ld(int slot, int k) const { return f[slot].t[fidx(g, f[slot], tile, i, j, k)]; }
+  HD void st(int slot, int k, double x) const { f[slot].t[fidx(g, f[slot], tile, i, j, k)] = x; }
+  HD double wget(const ColWs& w, int s, int k) const { return w.at(s, k); }
+  HD void wset(const ColWs& w, int s, int k, double x) const { w.at(s, k) = x; }
+  HD double cst(double x) const { return x; }
+};
+struct ColTL {
+  typedef Dual T;
+  const Geom& g; const Fld* f; int tile, i, j; Tape* tape;
+  HD Dual ld(int slot, int k) const { const size_t n = fidx(g, f[slot], tile, i, j, k); return Dual(f[slot].t[n], f[slot].p[n]); }
+  HD void st(int slot, int k, const Dual& x) const { const size_t n = fidx(g, f[slot], tile, i, j, k); f[slot].t[n] = x.v; f[slot].p[n] = x.d; }
+  HD Dual wget(const ColWs& w, int s, int k) const { return WsIO<Dual>::get(w, s, k); }
+  HD void wset(const ColWs& w, int s, int k, const Dual& x) const { WsIO<Dual>::set(w, s, k, x); }
+  HD Dual cst(double x) const { return Dual(x); }
+};
+struct ColAD {
+  typedef TV T;
+  const Geom& g; const Fld* f; int tile, i, j; Tape* tape;
+  HD TV ld(int slot, int k) const { return TV(f[slot].t[fidx(g, f[slot], tile, i, j, k)], tape->push(-2 - slot, k, 0., 0.), tape); }
+  // trajectory is NOT rewritten (the backward sweep must not disturb it); the field's incoming adjoint moves onto the variable
+  HD void st(int slot, int k, const TV& x) const {
+    const size_t n = fidx(g, f[slot], tile, i, j, k);
+    if (x.id >= 0) tape->ad(x.id) += f[slot].p[n];
+    f[slot].p[n] = 0.;
+  }
+  HD TV wget(const ColWs& w, int s, int k) const { return WsIO<TV>::get(w, s, k, tape); }
+  HD void wset(const ColWs& w, int s, int k, const TV& x) const { WsIO<TV>::set(w, s, k, x); }
+  HD TV cst(double x) const { return TV(x); }
+  // walk the tape backwards; leaves hand their adjoint to the fields
+  HD void reverse() const {
+    for (int id = tape->n - 1; id >= 0; --id) {
+      const size_t e = (size_t)(2 * id) * tape->m.stride + tape->col;
+      const double a = tape->ad(id);
+      const int ia = tape->m.idx[e], ib = tape->m.idx[e + tape->m.stride];
+      if (ia <= -2) { const int slot = -2 - ia; f[slot].p[fidx(g, f[slot], tile, i, j, ib)] += a; continue; }
+      if (a == 0.) continue;
+      if (ia >= 0) tape->ad(ia) += tape->m.part[e] * a;
+      if (ib >= 0) tape->ad(ib) += tape->m.part[e + tape->m.stride] * a;
+    }
+  }
+};
+
+// array of T living in the column workspace, 1-based level index
+template <class IO>
+struct WArr {
+  const IO& io; const ColWs& ws; int slot;
+  HD typename IO::T operator()(int k) const { return io.wget(ws, slot, k); }
+  HD void set(int k, const typename IO::T& x) const { io.wset(ws, slot, k, x); }
+};
+
+}  // namespace fv3

@@ -142,6 +142,7 @@ struct LevelParams {
   double d2_divg, damp_vt, damp_w, damp_t, d_con, damp_vt_pert;
   // tracer_2d sub-cycling of the current call (fv_tracer2d_tlm.F90:1306-1345): sub-steps this level takes and 1/that
   int tr_ksplt = 1; double tr_frac = 1.0;
+  double dp_ref = 0.;       // ak(k+1)-ak(k) + (bk(k+1)-bk(k))*1e5 (dyn_core_tlm.F90:1704-1706), non-hydrostatic interface weights
 };
 
 // Point context handed to every stage evaluation.

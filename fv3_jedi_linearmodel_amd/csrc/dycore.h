@@ -12,6 +12,7 @@
 #include "stages.h"
 #include "column.h"
 #include "exchange.h"
+#include "nh.h"
 #include <functional>
 #include <map>
 #include <string>
@@ -126,7 +127,14 @@ struct Dycore {
   Arena state, work;
   std::map<std::string, Fld> F;       // field registry (debug/test access + driver)
   Program acoustic;                   // one acoustic step
-  double* ckpt = nullptr;             // [n_split*k_split][4][field3]
+  double* ckpt = nullptr;             // [n_split*k_split][step state: u v delp pt (+ w delz zh)]
+  std::vector<const char*> st_in, st_out;   // per-step prognostic fields and the work buffers the step writes them to
+  size_t ck_stride = 0;
+  bool nh = false;                    // non-hydrostatic
+  double* nh_ws = nullptr; TapeMem nh_tape;   // column workspace and reverse-mode tape of the column solvers (nh.h)
+  NhColArgs nh_args(double dt_) const;
+  void add_col(Program& P, const char* group, int kind, const NhColArgs& a, Rect r, Rect skip = Rect{1, 0, 1, 0}, int when = 0);
+  bool nh_overflow();
   // Trajectory slots: as many acoustic steps as free HBM allows keep the trajectory of ALL their intermediates (one copy of
   // the work arena's trajectory side + pe, peln, pk, pkz each), written by the forward sweep of step_nl; the backward sweep
   // then skips the nonlinear recompute of those steps.  Steps without a slot are recomputed from their 4-field checkpoint.
@@ -211,8 +219,8 @@ struct Dycore {
 
   // fv_tp_2d as a stage sequence (tp_core_tlm.F90:83-236): q -> fx, fy.  mx/my = xfx/yfx or mass fluxes.
   void build_tp(Program& P, const char* grp, const std::string& pre, Fld q, Fld crx, Fld cry, Fld xfx, Fld yfx, Fld rax,
-                Fld ray, Fld mx, Fld my, Fld mass, int hsel, int dsel, bool use_mass, Fld fx, Fld fy) {
-    const int is = 1, ie = g.nx, js = 1, je = g.ny, isd = g.isd(), ied = g.ied(), jsd = g.jsd(), jed = g.jed(), npz = g.npz;
+                Fld ray, Fld mx, Fld my, Fld mass, int hsel, int dsel, bool use_mass, Fld fx, Fld fy, int nk = 0) {
+    const int is = 1, ie = g.nx, js = 1, je = g.ny, isd = g.isd(), ied = g.ied(), jsd = g.jsd(), jed = g.jed(), npz = nk ? nk : g.npz;
     Fld fy2 = W((pre + "_fy2").c_str(), npz), q_i = W((pre + "_qi").c_str(), npz), fxo = W((pre + "_fxo").c_str(), npz);
     Fld fx2 = W((pre + "_fx2").c_str(), npz), q_j = W((pre + "_qj").c_str(), npz), fyo = W((pre + "_fyo").c_str(), npz);
     // the four 1-D PPM sweeps; on a face each is a bulk launch (4-point edge values everywhere) plus two strips three flux
@@ -314,8 +322,10 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
   if (face && nx != ny) { err = "cube faces are square: nx must equal ny"; return false; }
   if (ntile < 1) { err = "ntile < 1"; return false; }
   if (o.nord > 1 || o.nord_pert > 1 || o.nord < 0) { err = "nord/nord_pert in {0,1} only"; return false; }
-  if (!o.hydrostatic) { err = "non-hydrostatic path (nh_core) not built yet"; return false; }
-  lev_host.resize(npz);
+  nh = !o.hydrostatic;
+  if (nh && npz < 3) { err = "non-hydrostatic solver needs npz >= 3"; return false; }
+  if (nh && !(o.a_imp > 0.5)) { err = "non-hydrostatic: a_imp must be > 0.5 (semi-implicit solver; the reference's a_imp <= 0.5 Riemann-invariant solver is not built)"; return false; }
+  lev_host.resize(npz + 1);
   for (int k = 1; k <= npz; ++k) {
     if (!resolve_level(o, k, npz, lev_host[k - 1])) { err = "trajectory/perturbation hord split (split_hord) not supported"; return false; }
     const LevelParams& l = lev_host[k - 1];
@@ -325,8 +335,9 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
 #ifndef FV3LM_HOST_EMUL
   HIPCHK(hipStreamCreate(&ex.stream));
 #endif
-  lev_dev = (LevelParams*)dev_alloc(sizeof(LevelParams) * npz);
-  h2d(ex, lev_dev, lev_host.data(), sizeof(LevelParams) * npz);
+  lev_host[npz] = lev_host[npz - 1];          // interface npz+1 of the height transport uses the last layer's schemes
+  lev_dev = (LevelParams*)dev_alloc(sizeof(LevelParams) * (npz + 1));
+  h2d(ex, lev_dev, lev_host.data(), sizeof(LevelParams) * (npz + 1));
   const size_t np = (size_t)ntile * g.plane;
   metric_dev.resize(NMETRIC);
   for (int m = 0; m < NMETRIC; ++m) { metric_dev[m] = (double*)dev_alloc(np * 8); h2d(ex, metric_dev[m], metrics_host[m], np * 8); }
@@ -345,10 +356,20 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
   if (phis_host) h2d(ex, hs_dev, phis_host, np * 8);
   ctx.g = g; ctx.lev = lev_dev; ctx.nlev = npz;
   n3 = np * npz; n3p = np * (npz + 1);
-  state.init(n3 * (16 + 3 * (size_t)nq) + n3p * 8);
-  work.init(n3 * (g.face ? 120 : 114) + n3p * 14);
+  state.init(n3 * (16 + 3 * (size_t)nq + (nh ? 2 : 0)) + n3p * (8 + (nh ? 1 : 0)));
+  work.init(n3 * ((g.face ? 120 : 114) + (nh ? 28 : 0)) + n3p * (14 + (nh ? 44 : 0)));
+  if (nh) {
+    nh_ws = (double*)dev_alloc((size_t)2 * NS_COUNT * (npz + 2) * np * 8);
+    nh_tape.stride = g.plane; nh_tape.cap = 104 * (npz + 2);
+    nh_tape.part = (double*)dev_alloc((size_t)2 * nh_tape.cap * nh_tape.stride * 8);
+    nh_tape.idx = (int*)dev_alloc((size_t)2 * nh_tape.cap * nh_tape.stride * 4);
+    nh_tape.adj = (double*)dev_alloc((size_t)nh_tape.cap * nh_tape.stride * 8);
+    nh_tape.overflow = (int*)dev_alloc(8);
+  }
   build_acoustic();
-  ckpt = (double*)dev_alloc((size_t)n_split * k_split * 4 * n3 * 8);
+  ck_stride = 0;
+  for (const char* n_ : st_in) ck_stride += (size_t)f(n_).nk * np;
+  ckpt = (double*)dev_alloc((size_t)n_split * k_split * ck_stride * 8);
   ex.wlo = work.t; ex.whi = work.t + work.cap;
   return true;
 }
@@ -427,6 +448,7 @@ inline void Dycore::init_traj_slots() {
 inline void Dycore::destroy() {
   for (double* p : metric_dev) dev_free(p);
   dev_free(lev_dev); dev_free(hs_dev); dev_free(ckpt); dev_free(edge_dev); dev_free(ecorner_dev);
+  dev_free(nh_ws); dev_free(nh_tape.part); dev_free(nh_tape.idx); dev_free(nh_tape.adj); dev_free(nh_tape.overflow);
   for (ExTable& t : xt) { dev_free(t.rows); dev_free(t.src); dev_free(t.ptr); dev_free(t.dst); }
   for (ExRemote& x : xr) { dev_free(x.send_rows); dev_free(x.recv_rows); dev_free(x.asrc); dev_free(x.aptr); dev_free(x.apos); dev_free(x.sendbuf); dev_free(x.recvbuf); }
   state.destroy(); work.destroy();
@@ -437,7 +459,29 @@ inline void Dycore::destroy() {
 #endif
 }
 
-// One acoustic step, hydrostatic (dyn_core_tlm.F90:1736-2466).  Inputs u,v,delp,pt (halos valid);
+inline NhColArgs Dycore::nh_args(double dt_) const {
+  NhColArgs a{};
+  a.g = g; a.ws = nh_ws; a.ws_stride = (size_t)g.ntile * g.plane; a.tape = nh_tape; a.hs = hs_dev; a.lev = lev_dev;
+  a.dt = dt_; a.akap = opt.akap; a.ptop = opt.ptop; a.rdgas = opt.rdgas; a.grav = opt.grav; a.a_imp = opt.a_imp; a.p_fac = opt.p_fac; a.scale_z = opt.scale_z;
+  return a;
+}
+// column operator of nh.h as a program step.  when: 0 every acoustic step, 2 the last only
+inline void Dycore::add_col(Program& P, const char* group, int kind, const NhColArgs& a, Rect r, Rect skip, int when) {
+  Dycore* self = this;
+  static const char* tags[] = {"riem_c", "riem3", "edge_profile", "zh_init", "p_ring"};
+  P.push_back(Op{group, [self, kind, a, r, skip, when](Exec& e, int mode) {
+    if (when == 2 && !self->last_acoustic) return;
+    NhColArgs b = a; b.last_call = self->last_acoustic ? 1 : 0;
+    run_nh_col(e, mode, b, kind, r, skip, tags[kind]);
+  }});
+}
+inline bool Dycore::nh_overflow() {
+  if (!nh) return false;
+  int flag = 0; d2h(ex, &flag, nh_tape.overflow, 4);
+  return flag != 0;
+}
+
+// One acoustic step (dyn_core_tlm.F90:1736-2466).  Inputs u,v,delp,pt (halos valid);
 // outputs u_o,v_o,delp_o,pt_o (halos valid) + accumulated mfx,mfy,cx,cy + pe,peln,pk,pkz.
 inline void Dycore::build_acoustic() {
   const int is = 1, ie = g.nx, js = 1, je = g.ny, isd = g.isd(), ied = g.ied(), jsd = g.jsd(), jed = g.jed(), npz = g.npz;
@@ -448,6 +492,14 @@ inline void Dycore::build_acoustic() {
   Fld u_o = W("u_o", npz), v_o = W("v_o", npz), delp_o = W("delp_o", npz), pt_o = W("pt_o", npz);   // step outputs: per-step trajectory like every work array
   Fld mfx = S("mfx", npz), mfy = S("mfy", npz), cx = S("cx", npz), cy = S("cy", npz);
   Fld pe = S("pe", npz + 1), peln = S("peln", npz + 1), pk = S("pk", npz + 1), pkz = S("pkz", npz);
+  st_in = {"u", "v", "delp", "pt"}; st_out = {"u_o", "v_o", "delp_o", "pt_o"};
+  Fld w{}, delz{}, zh{}, w_o{}, delz_o{}, zh_o{};
+  if (nh) {
+    w = S("w", npz); delz = S("delz", npz); zh = S("zh", npz + 1);
+    w_o = W("w_o", npz); delz_o = W("delz_o", npz); zh_o = W("zh_o", npz + 1);
+    for (const char* n_ : {"w", "delz", "zh"}) st_in.push_back(n_);
+    for (const char* n_ : {"w_o", "delz_o", "zh_o"}) st_out.push_back(n_);
+  }
   // ---- c_sw
   Fld utmp = W("utmp", npz), vtmp = W("vtmp", npz), ua = W("ua", npz), va = W("va", npz);
   { CswInterpAD s; s.in[0] = u; s.in[1] = v; s.out[0] = utmp; s.out[1] = vtmp; s.out[2] = ua; s.out[3] = va;
@@ -479,6 +531,12 @@ inline void Dycore::build_acoustic() {
   Fld delpc = W("delpc", npz), ptc = W("ptc", npz);
   { CswTransportD s; s.in[0] = delp; s.in[1] = pt; s.in[2] = utf; s.in[3] = vtf; s.out[0] = delpc; s.out[1] = ptc;
     s.orect[0] = s.orect[1] = R(is - 1, ie + 1, js - 1, je + 1); s.k1 = npz; add_face(P, "c_sw", s, 1); }
+  Fld wc{};
+  if (nh) {
+    wc = W("wc", npz);
+    CswTransportWD s; s.in[0] = delp; s.in[1] = w; s.in[2] = utf; s.in[3] = vtf; s.in[4] = delpc; s.out[0] = wc;
+    s.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); s.k1 = npz; add_face(P, "c_sw", s, 1);
+  }
   Fld ke_c = W("ke_c", npz), vort_c = W("vort_c", npz);
   { CswKeVortD s; s.in[0] = ua; s.in[1] = va; s.in[2] = uc0; s.in[3] = vc0; s.in[4] = g.face ? u : none; s.in[5] = g.face ? v : none; s.out[0] = ke_c; s.out[1] = vort_c;
     s.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); s.orect[1] = R(is, ie + 1, js, je + 1); s.dt2 = dt2; s.k1 = npz; add_face(P, "c_sw", s, 1); }
@@ -488,12 +546,23 @@ inline void Dycore::build_acoustic() {
   if (opt.nord > 0) add_halo(P, "halo_divgd", H_CORNER, divgd);
   // ---- geopk (C grid) + p_grad_c
   Fld pe_c = W("pe_c", npz + 1), peln_c = W("peln_c", npz + 1), pkc = W("pkc", npz + 1), gz = W("gz", npz + 1);
+  Fld uc = W("uc", npz), vc = W("vc", npz);
+  if (nh) {
+    // interface heights advected with the C-grid fluxes, the vertically implicit solver, pressure gradient (dyn_core_tlm.F90:1860-1960)
+    Fld gz_a = W("gz_a", npz + 1);
+    { UpdateDzCD s; s.in[0] = zh; s.in[1] = utf; s.in[2] = vtf; s.out[0] = gz_a; s.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); s.k1 = npz + 1;
+      add_face(P, "update_dz_c", s, 1); }
+    { NhColArgs a = nh_args(dt2); a.f[0] = gz_a; a.f[1] = wc; a.f[2] = ptc; a.f[3] = delpc; a.f[4] = gz; a.f[5] = pkc;
+      add_col(P, "riem_c", NHC_RIEM_C, a, R(is - 1, ie + 1, js - 1, je + 1)); }
+    PGradCNh s; s.in[0] = pkc; s.in[1] = gz; s.in[2] = uc1; s.in[3] = vc1; s.in[4] = delpc; s.out[0] = uc; s.out[1] = vc;
+    s.orect[0] = R(is, ie + 1, js, je); s.orect[1] = R(is, ie, js, je + 1); s.dt2 = dt2; s.k1 = npz; add(P, "p_grad_c", s);
+  } else {
   { GeopkArgs a; a.g = g; a.R = R(is - 1, ie + 1, js - 1, je + 1); a.delp = delpc; a.pt = ptc; a.pe = pe_c; a.peln = peln_c; a.pk = pkc;
     a.gz = gz; a.pkz = Fld{}; a.hs = hs_dev; a.ptop = opt.ptop; a.akap = opt.akap; a.cp_air = opt.cp_air; a.cg = 1;
     P.push_back(Op{"geopk_c", [a](Exec& e, int mode) { run_geopk(e, mode, a); }}); }
-  Fld uc = W("uc", npz), vc = W("vc", npz);
   { PGradC s; s.in[0] = pkc; s.in[1] = gz; s.in[2] = uc1; s.in[3] = vc1; s.out[0] = uc; s.out[1] = vc;
     s.orect[0] = R(is, ie + 1, js, je); s.orect[1] = R(is, ie, js, je + 1); s.dt2 = dt2; s.k1 = npz; add(P, "p_grad_c", s); }
+  }
   add_halo(P, "halo_uc", H_CVEC, uc, vc);
   // ---- d_sw
   Fld ut = W("ut", npz), crx = W("crx", npz), xfx = W("xfx", npz), vt = W("vt", npz), cry = W("cry", npz), yfx = W("yfx", npz);
@@ -523,9 +592,20 @@ inline void Dycore::build_acoustic() {
   build_tp(P, "d_sw", "tpd", delp, crx, cry, xfx, yfx, rax, ray, xfx, yfx, Fld{}, HORD_DP, DAMP_V, false, fx, fy);
   add_accum(P, "d_sw", cx, crx, R(is, ie + 1, jsd, jed)); add_accum(P, "d_sw", mfx, fx, R(is, ie + 1, js, je));
   add_accum(P, "d_sw", cy, cry, R(isd, ied, js, je + 1)); add_accum(P, "d_sw", mfy, fy, R(is, ie, js, je + 1));
+  Fld w_m{}, dw{}, gxw{}, gyw{};
+  if (nh) {   // w: damping increment and transport with the mass fluxes (sw_core_tlm.F90:3020-3062)
+    Fld d6w = W("del6_w", npz); dw = W("dw", npz); gxw = W("gxw", npz); gyw = W("gyw", npz); w_m = W("w_m", npz);
+    { Del6AD s; s.in[0] = w; s.out[0] = d6w; s.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); s.k1 = npz; add_face(P, "d_sw", s, 1); }
+    { DswDw s; s.in[0] = w; s.in[1] = d6w; s.out[0] = dw; s.orect[0] = R(is, ie, js, je); s.k1 = npz; add(P, "d_sw", s); }
+    build_tp(P, "d_sw", "tpw", w, crx, cry, xfx, yfx, rax, ray, fx, fy, Fld{}, HORD_VT, DAMP_NONE, false, gxw, gyw);
+  }
   build_tp(P, "d_sw", "tpt", pt, crx, cry, xfx, yfx, rax, ray, fx, fy, delp, HORD_TM, DAMP_T, true, gx, gy);
   { DswUpdateDp s; s.in[0] = delp; s.in[1] = pt; s.in[2] = fx; s.in[3] = fy; s.in[4] = gx; s.in[5] = gy; s.out[0] = delp_o; s.out[1] = pt_o;
     s.orect[0] = s.orect[1] = R(is, ie, js, je); s.k1 = npz; add(P, "d_sw", s); }
+  if (nh) {
+    DswUpdateW s; s.in[0] = w; s.in[1] = delp; s.in[2] = delp_o; s.in[3] = gxw; s.in[4] = gyw; s.in[5] = dw; s.out[0] = w_m;
+    s.orect[0] = R(is, ie, js, je); s.k1 = npz; add(P, "d_sw", s);
+  }
   Fld vb = W("vb", npz), ub = W("ub", npz), ke = W("ke", npz);
   { DswKeWindsD s; s.in[0] = uc; s.in[1] = vc; s.in[2] = g.face ? ut : none; s.in[3] = g.face ? vt : none; s.out[0] = vb; s.out[1] = ub; s.orect[0] = s.orect[1] = R(is, ie + 1, js, je + 1); s.dt = dt;
     s.k1 = npz; add_face(P, "d_sw", s, 1); }
@@ -547,6 +627,40 @@ inline void Dycore::build_acoustic() {
   { DswUpdateUV s; s.in[0] = u; s.in[1] = v; s.in[2] = ke2; s.in[3] = fxv; s.in[4] = fyv; s.in[5] = wk; s.in[6] = d6; s.out[0] = u_m; s.out[1] = v_m;
     s.orect[0] = R(is, ie, js, je + 1); s.orect[1] = R(is, ie + 1, js, je); s.k1 = npz; add(P, "d_sw", s); }
   add_halo(P, "halo_dp", H_CELL, delp_o); add_halo(P, "halo_dp", H_CELL, pt_o);
+  if (nh) {
+    // ---- update_dz_d (nh_utils_tlm.F90:590-722): Courant numbers and area fluxes at the interfaces, transport of the heights
+    Fld crx_e = W("crx_e", npz + 1), xfx_e = W("xfx_e", npz + 1), cry_e = W("cry_e", npz + 1), yfx_e = W("yfx_e", npz + 1);
+    { NhColArgs a = nh_args(dt); a.f[0] = crx; a.f[1] = xfx; a.f[2] = crx_e; a.f[3] = xfx_e; add_col(P, "update_dz_d", NHC_EDGE, a, R(is, ie + 1, jsd, jed)); }
+    { NhColArgs a = nh_args(dt); a.f[0] = cry; a.f[1] = yfx; a.f[2] = cry_e; a.f[3] = yfx_e; add_col(P, "update_dz_d", NHC_EDGE, a, R(isd, ied, js, je + 1)); }
+    Fld rax_e = W("ra_x_e", npz + 1), ray_e = W("ra_y_e", npz + 1);
+    { DswRa s; s.in[0] = xfx_e; s.in[1] = yfx_e; s.out[0] = rax_e; s.out[1] = ray_e; s.orect[0] = R(is, ie, jsd, jed); s.orect[1] = R(isd, ied, js, je);
+      s.k1 = npz + 1; add(P, "update_dz_d", s); }
+    Fld fxz = W("fxz", npz + 1), fyz = W("fyz", npz + 1), d6z = W("del6_z", npz + 1), zh_a = W("zh_a", npz + 1);
+    build_tp(P, "update_dz_d", "tpz", zh, crx_e, cry_e, xfx_e, yfx_e, rax_e, ray_e, xfx_e, yfx_e, Fld{}, HORD_TM, DAMP_NONE, false, fxz, fyz, npz + 1);
+    { Del6AD s; s.in[0] = zh; s.out[0] = d6z; s.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); s.k1 = npz + 1; add_face(P, "update_dz_d", s, 1); }
+    { UpdateDzD s; s.in[0] = zh; s.in[1] = d6z; s.in[2] = fxz; s.in[3] = fyz; s.in[4] = rax_e; s.in[5] = ray_e; s.out[0] = zh_a;
+      s.orect[0] = R(is, ie, js, je); s.k1 = npz + 1; add(P, "update_dz_d", s); }
+    // ---- riem_solver3 + halo rings of the pressures + nh_p_grad (dyn_core_tlm.F90:2165-2400)
+    Fld ppe = W("ppe", npz + 1), pk3 = W("pk3", npz + 1);
+    { NhColArgs a = nh_args(dt); a.f[0] = zh_a; a.f[1] = w_m; a.f[2] = pt_o; a.f[3] = delp_o; a.f[4] = w_o; a.f[5] = delz_o; a.f[6] = zh_o; a.f[7] = ppe;
+      a.f[8] = pk3; a.f[9] = pe; a.f[10] = peln; a.f[11] = pk; add_col(P, "riem3", NHC_RIEM3, a, R(is, ie, js, je)); }
+    add_halo(P, "halo_zh", H_CELL, zh_o); add_halo(P, "halo_zh", H_CELL, ppe);
+    { NhColArgs a = nh_args(dt); a.f[0] = delp_o; a.f[1] = pe; a.what = 1;
+      add_col(P, "p_ring", NHC_RING, a, R(is - 1, ie + 1, js - 1, je + 1), R(is, ie, js, je), 2); }
+    { NhColArgs a = nh_args(dt); a.f[0] = delp_o; a.f[1] = pk3; a.what = 0;
+      add_col(P, "p_ring", NHC_RING, a, R(is - 2, ie + 2, js - 2, je + 2), R(is, ie, js, je)); }
+    Fld pp_b = W("pp_b", npz + 1), pk_b = W("pk3_b", npz + 1), zh_b = W("zh_b", npz + 1), dp_b = W("dp_b", npz);
+    build_a2b(P, "nh_p_grad", "a2bpp", ppe, pp_b, npz + 1);
+    build_a2b(P, "nh_p_grad", "a2bpk", pk3, pk_b, npz + 1);
+    build_a2b(P, "nh_p_grad", "a2bzh", zh_o, zh_b, npz + 1);
+    build_a2b(P, "nh_p_grad", "a2bdp", delp_o, dp_b, npz);
+    { NhPGrad s; s.in[0] = u_m; s.in[1] = v_m; s.in[2] = dp_b; s.in[3] = pp_b; s.in[4] = pk_b; s.in[5] = zh_b; s.out[0] = u_o; s.out[1] = v_o;
+      s.orect[0] = R(is, ie, js, je + 1); s.orect[1] = R(is, ie + 1, js, je); s.dt = dt; s.ptk = std::pow(opt.ptop, opt.akap); s.grav = opt.grav; s.k1 = npz;
+      add(P, "nh_p_grad", s); }
+    add_halo(P, "halo_uv", H_DVEC, u_o, v_o, 1); add_halo(P, "halo_uv", H_DEDGE, u_o, v_o, 2);
+    add_halo(P, "halo_w", H_CELL, w_o);      // the reference fills it at the start of the next step (:1741-1748); same data, and the step's
+    return;                                   // checkpointed input then carries a valid halo
+  }
   // ---- geopk (D grid) + one_grad_p
   Fld pkd = pk, gzd = W("gzd", npz + 1);
   { GeopkArgs a; a.g = g; a.R = R(is - 2, ie + 2, js - 2, je + 2); a.delp = delp_o; a.pt = pt_o; a.pe = pe; a.peln = peln; a.pk = pkd;
@@ -567,10 +681,19 @@ inline void Dycore::build_acoustic() {
 // outputs; on exit the adjoint of the inputs.  Trajectory checkpoints must have been stored by a
 // preceding MODE_NL sweep (store_ckpt=true).
 inline void Dycore::dyn_core(int mode) {
-  const char* names[4] = {"u", "v", "delp", "pt"};
-  const char* onames[4] = {"u_o", "v_o", "delp_o", "pt_o"};
+  const std::vector<const char*>&names = st_in, &onames = st_out;
+  const int ns = (int)names.size();
   const char* pnames[4] = {"pe", "peln", "pk", "pkz"};
-  const size_t b3 = n3 * 8;
+  const size_t b3 = n3 * 8, np = (size_t)g.ntile * g.plane;
+  auto bytes = [&](int n) { return (size_t)f(names[n]).nk * np * 8; };
+  auto ck = [&](int a, int n) { double* q_ = ckpt + (size_t)a * ck_stride; for (int m = 0; m < n; ++m) q_ += (size_t)f(names[m]).nk * np; return q_; };
+  // first acoustic step of the call: interface heights from the layer thicknesses, halo filled (dyn_core_tlm.F90:1779-1801)
+  auto zh_init = [&](int md) {
+    NhColArgs a = nh_args(0.); a.f[0] = f("delz"); a.f[1] = f("zh");
+    halo(md, H_CELL, f("w"));
+    if (md != MODE_AD) { run_nh_col(ex, md, a, NHC_ZH_INIT, R(1, g.nx, 1, g.ny), R(1, 0, 1, 0), "zh_init"); halo(md, H_CELL, f("zh")); }
+    else { halo(md, H_CELL, f("zh")); run_nh_col(ex, md, a, NHC_ZH_INIT, R(1, g.nx, 1, g.ny), R(1, 0, 1, 0), "zh_init"); }
+  };
   auto slot_io = [&](int a, bool save) {      // pe, peln, pk, pkz trajectory of step a <-> its slot
     double* q_ = traj_slot_p[a];
     for (int n = 0; n < 4; ++n) {
@@ -581,26 +704,28 @@ inline void Dycore::dyn_core(int mode) {
   };
   if (mode != MODE_AD) {
     for (const char* a : {"mfx", "mfy", "cx", "cy"}) { dev_zero(ex, f(a).t, b3); if (mode == MODE_TL) dev_zero(ex, f(a).p, b3); }
+    if (nh) zh_init(mode);
     for (int it = 0; it < n_split; ++it) {
       const int a = ck_base + it;
       if (mode == MODE_NL) {
-        for (int n = 0; n < 4; ++n) dev_copy(ex, ckpt + ((size_t)a * 4 + n) * n3, f(names[n]).t, b3);
+        for (int n = 0; n < ns; ++n) dev_copy(ex, ck(a, n), f(names[n]).t, bytes(n));
         ex.tshift = has_slot(a) ? traj_slot[a] - work.t : 0;
       }
       last_acoustic = (it == n_split - 1);
       run_group(acoustic, nullptr, mode);
-      for (int n = 0; n < 4; ++n) {
-        dev_copy(ex, f(names[n]).t, ex.sh(f(onames[n])).t, b3);
-        if (mode == MODE_TL) dev_copy(ex, f(names[n]).p, f(onames[n]).p, b3);
+      for (int n = 0; n < ns; ++n) {
+        dev_copy(ex, f(names[n]).t, ex.sh(f(onames[n])).t, bytes(n));
+        if (mode == MODE_TL) dev_copy(ex, f(names[n]).p, f(onames[n]).p, bytes(n));
       }
       if (mode == MODE_NL && has_slot(a)) slot_io(a, true);
       ex.tshift = 0;
     }
   } else {
     // incoming adjoint lives in the input-named buffers; move it to the *_o side of the last step
+    if (nh) dev_zero(ex, f("zh").p, n3p * 8);      // the heights leave dyn_core unused: no incoming adjoint
     for (int it = n_split - 1; it >= 0; --it) {
       const int a = ck_base + it;
-      for (int n = 0; n < 4; ++n) dev_copy(ex, f(names[n]).t, ckpt + ((size_t)a * 4 + n) * n3, b3);
+      for (int n = 0; n < ns; ++n) dev_copy(ex, f(names[n]).t, ck(a, n), bytes(n));
       last_acoustic = (it == n_split - 1);
       if (has_slot(a)) {       // this step's intermediates were kept by the forward sweep
         ex.tshift = traj_slot[a] - work.t;
@@ -610,13 +735,14 @@ inline void Dycore::dyn_core(int mode) {
         run_group(acoustic, nullptr, MODE_NL, true);
       }
       zero_work_adjoint();
-      for (int n = 0; n < 4; ++n) { dev_copy(ex, f(onames[n]).p, f(names[n]).p, b3); dev_zero(ex, f(names[n]).p, b3); }
+      for (int n = 0; n < ns; ++n) { dev_copy(ex, f(onames[n]).p, f(names[n]).p, bytes(n)); dev_zero(ex, f(names[n]).p, bytes(n)); }
       run_group(acoustic, nullptr, MODE_AD);
       // pe, peln, pk, pkz of earlier steps are overwritten by later ones: their adjoint is zero there
       for (const char* a_ : {"pe", "peln", "pk"}) dev_zero(ex, f(a_).p, n3p * 8);
       dev_zero(ex, f("pkz").p, b3);
       ex.tshift = 0;
     }
+    if (nh) zh_init(MODE_AD);
   }
 }
 

@@ -139,6 +139,12 @@ inline bool Dynamics::init2(const double* ak, const double* bk) {
   ak_dev = (double*)dev_alloc((npz + 1) * 8); bk_dev = (double*)dev_alloc((npz + 1) * 8);
   if (ak) h2d(ex, ak_dev, ak, (npz + 1) * 8);
   if (bk) h2d(ex, bk_dev, bk, (npz + 1) * 8);
+  if (nh) {
+    if (!ak || !bk) { err = "non-hydrostatic: ak, bk needed (reference layer thicknesses)"; return false; }
+    for (int k = 1; k <= npz; ++k) lev_host[k - 1].dp_ref = ak[k] - ak[k - 1] + (bk[k] - bk[k - 1]) * 1.e5;
+    lev_host[npz].dp_ref = lev_host[npz - 1].dp_ref;
+    h2d(ex, lev_dev, lev_host.data(), sizeof(LevelParams) * (npz + 1));
+  }
   for (int n = 0; n < nq; ++n) { char nm[16]; std::snprintf(nm, sizeof nm, "q%d", n + 1); q.push_back(S(nm, npz)); }
   dp1 = S("dp1", npz); qc = S("qc", npz); qc_o = S("qc_o", npz);
   pe2 = S("pe2", npz + 1); pu_ad = S("pu_ad", npz + 1); pv_ad = S("pv_ad", npz + 1);

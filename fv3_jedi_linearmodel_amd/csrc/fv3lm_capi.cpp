@@ -66,6 +66,7 @@ int fv3lm_field_get(fv3lm_handle* h, const char* name, int which, double* host) 
 static int status(fv3lm_handle* h) {
   if (h->d.halo_missing) return fail("halo exchange needed before fv3lm_set_exchange provided its table (face mode)");
   if (h->d.tracer_subcycle_error) return fail("tracer_2d: accumulated Courant number > 60: trajectory is not usable");
+  if (h->d.nh_overflow()) return fail("non-hydrostatic column solver: reverse-mode tape overflow (internal sizing error)");
   return 0;
 }
 int fv3lm_set_face_data(fv3lm_handle* h, const double* edge, const double* ecorner) {

@@ -1,0 +1,295 @@
+// fv3lm-hip: column operators of the non-hydrostatic acoustic step, written once on the generic
+// column interface of coltape.h (nonlinear / tangent / taped adjoint):
+//   riem_c_col   UPDATE_DZ_C's monotone-thickness fix and surface velocity (nh_utils_tlm.F90:367-380) + RIEM_SOLVER_C
+//                (:846-933) with SIM1_SOLVER (:2760-2884)
+//   riem3_col    UPDATE_DZ_D's fix and surface velocity (:708-721) + RIEM_SOLVER3 (nh_core_tlm.F90:245-389) with SIM_SOLVER
+//                (nh_utils_tlm.F90:3129-3272), the path of the default a_imp = 0.75
+//   edge_col     EDGE_PROFILE (:3473-3584), layer means of two fields -> interface values
+//   zh_init_col  interface heights from delz at the first acoustic step (dyn_core_tlm.F90:1779-1801)
+//   ring_col     PK3_HALO / PE_HALO (dyn_core_tlm.F90:2716-2778, :2934-2961) on the halo rings
+#pragma once
+#include "coltape.h"
+
+namespace fv3 {
+
+constexpr double NH_DZ_MIN = 2.0;      // nh_utils: dz_min
+constexpr int NH_NF = 12;
+
+struct NhColArgs {
+  Geom g; Fld f[NH_NF];
+  double* ws; size_t ws_stride; TapeMem tape;
+  const double* hs;                    // surface geopotential [ntile][plane]
+  const LevelParams* lev;
+  double dt, akap, ptop, rdgas, grav, a_imp, p_fac, scale_z;
+  int last_call, what;
+};
+
+// common tail of SIM1 / SIM: new layer thickness from the perturbation pressure (nh_utils_tlm.F90:2862-2883, :3241-3265)
+template <class IO>
+HD void nh_new_dz(const IO& io, int km, double rgas, double capa1, double p_fac, const WArr<IO>& pe, const WArr<IO>& bb, const WArr<IO>& g_rat,
+                  const WArr<IO>& dm2, const WArr<IO>& pm2, const WArr<IO>& pt2, const WArr<IO>& dz2) {
+  typedef typename IO::T T;
+  T p1 = (pe(km) + 2. * pe(km + 1)) * (1. / 3.);
+  for (int k = km; k >= 1; --k) {
+    if (k < km) p1 = (pe(k) + bb(k) * pe(k + 1) + g_rat(k) * pe(k + 2)) * (1. / 3.) - g_rat(k) * p1;
+    const T pm = pm2(k);
+    const T lo = p_fac * pm, hi = p1 + pm;
+    const T mx = (val(lo) < val(hi)) ? hi : lo;
+    dz2.set(k, -(dm2(k) * rgas * pt2(k) * dexp(capa1 * dlog(mx))));
+  }
+}
+
+// tridiagonal interpolation of the layer perturbation pressure to the interfaces (first Thomas sweep, :2790-2817 / :3160-3187)
+template <class IO>
+HD void nh_pp_edges(const IO& io, int km, double rgas, double gama, const WArr<IO>& pe, const WArr<IO>& dm2, const WArr<IO>& pm2, const WArr<IO>& dz2,
+                    const WArr<IO>& pt2, const WArr<IO>& g_rat, const WArr<IO>& bb, const WArr<IO>& dd, const WArr<IO>& gam, const WArr<IO>& pp) {
+  typedef typename IO::T T;
+  for (int k = 1; k <= km; ++k) pe.set(k, dexp(gama * dlog(-(dm2(k) / dz2(k) * rgas * pt2(k)))) - pm2(k));
+  for (int k = 1; k <= km - 1; ++k) {
+    const T gr = dm2(k) / dm2(k + 1);
+    g_rat.set(k, gr); bb.set(k, 2. * (1. + gr)); dd.set(k, 3. * (pe(k) + gr * pe(k + 1)));
+  }
+  T bet = bb(1);
+  pp.set(1, io.cst(0.)); pp.set(2, dd(1) / bet);
+  bb.set(km, io.cst(2.)); dd.set(km, 3. * pe(km));
+  for (int k = 2; k <= km; ++k) {
+    const T gm = g_rat(k - 1) / bet;
+    gam.set(k, gm); bet = bb(k) - gm;
+    pp.set(k + 1, (dd(k) - pp(k)) / bet);
+  }
+  for (int k = km; k >= 2; --k) pp.set(k, pp(k) - gam(k) * pp(k + 1));
+}
+
+// workspace slots (in units of T)
+enum { NS_AA = 0, NS_BB, NS_DD, NS_W1, NS_WK, NS_GR, NS_GAM, NS_PP, NS_PE, NS_DM, NS_PM, NS_PEM, NS_W2, NS_DZ, NS_PT, NS_COUNT };
+
+// SIM1_SOLVER: fully implicit
+template <class IO>
+HD void nh_sim1(const IO& io, const ColWs& ws, int km, double dt, double rgas, double gama, double kappa, const typename IO::T& wsfc, double p_fac) {
+  typedef typename IO::T T;
+  WArr<IO> aa{io, ws, NS_AA}, bb{io, ws, NS_BB}, dd{io, ws, NS_DD}, w1{io, ws, NS_W1}, g_rat{io, ws, NS_GR}, gam{io, ws, NS_GAM}, pp{io, ws, NS_PP},
+      pe{io, ws, NS_PE}, dm2{io, ws, NS_DM}, pm2{io, ws, NS_PM}, pem{io, ws, NS_PEM}, w2{io, ws, NS_W2}, dz2{io, ws, NS_DZ}, pt2{io, ws, NS_PT};
+  const double t1g = gama * 2. * dt * dt, rdt = 1. / dt;
+  for (int k = 1; k <= km; ++k) w1.set(k, w2(k));
+  nh_pp_edges(io, km, rgas, gama, pe, dm2, pm2, dz2, pt2, g_rat, bb, dd, gam, pp);
+  for (int k = 2; k <= km; ++k) aa.set(k, t1g / (dz2(k - 1) + dz2(k)) * (pem(k) + pp(k)));
+  T bet = dm2(1) - aa(2);
+  w2.set(1, (dm2(1) * w1(1) + dt * pp(2)) / bet);
+  for (int k = 2; k <= km - 1; ++k) {
+    const T gm = aa(k) / bet;
+    gam.set(k, gm);
+    bet = dm2(k) - (aa(k) + aa(k + 1) + aa(k) * gm);
+    w2.set(k, (dm2(k) * w1(k) + dt * (pp(k + 1) - pp(k)) - aa(k) * w2(k - 1)) / bet);
+  }
+  const T p1 = t1g / dz2(km) * (pem(km + 1) + pp(km + 1));
+  {
+    const T gm = aa(km) / bet;
+    gam.set(km, gm);
+    bet = dm2(km) - (aa(km) + p1 + aa(km) * gm);
+    w2.set(km, (dm2(km) * w1(km) + dt * (pp(km + 1) - pp(km)) - p1 * wsfc - aa(km) * w2(km - 1)) / bet);
+  }
+  for (int k = km - 1; k >= 1; --k) w2.set(k, w2(k) - gam(k + 1) * w2(k + 1));
+  pe.set(1, io.cst(0.));
+  for (int k = 1; k <= km; ++k) pe.set(k + 1, pe(k) + dm2(k) * (w2(k) - w1(k)) * rdt);
+  nh_new_dz(io, km, rgas, kappa - 1., p_fac, pe, bb, g_rat, dm2, pm2, pt2, dz2);
+}
+
+// SIM_SOLVER: semi-implicit with off-centring alpha
+template <class IO>
+HD void nh_sim(const IO& io, const ColWs& ws, int km, double dt, double rgas, double gama, double kappa, const typename IO::T& wsfc, double alpha,
+               double p_fac, double scale_m) {
+  typedef typename IO::T T;
+  WArr<IO> aa{io, ws, NS_AA}, bb{io, ws, NS_BB}, dd{io, ws, NS_DD}, w1{io, ws, NS_W1}, wk{io, ws, NS_WK}, g_rat{io, ws, NS_GR}, gam{io, ws, NS_GAM},
+      pp{io, ws, NS_PP}, pe{io, ws, NS_PE}, dm2{io, ws, NS_DM}, pm2{io, ws, NS_PM}, pem{io, ws, NS_PEM}, w2{io, ws, NS_W2}, dz2{io, ws, NS_DZ},
+      pt2{io, ws, NS_PT};
+  const double beta = 1. - alpha, ra = 1. / alpha, t2 = beta / alpha, t1g = 2. * gama * (alpha * dt) * (alpha * dt), rdt = 1. / dt;
+  for (int k = 1; k <= km; ++k) w1.set(k, w2(k));
+  nh_pp_edges(io, km, rgas, gama, pe, dm2, pm2, dz2, pt2, g_rat, bb, dd, gam, pp);
+  for (int k = 1; k <= km + 1; ++k) pe.set(k, pem(k) + pp(k));
+  for (int k = 2; k <= km; ++k) {
+    const T a = t1g / (dz2(k - 1) + dz2(k)) * pe(k);
+    wk.set(k, t2 * a * (w1(k - 1) - w1(k)));
+    aa.set(k, a - scale_m * dm2(1));
+  }
+  T bet = dm2(1) - aa(2);
+  w2.set(1, (dm2(1) * w1(1) + dt * pp(2) + wk(2)) / bet);
+  for (int k = 2; k <= km - 1; ++k) {
+    const T gm = aa(k) / bet;
+    gam.set(k, gm);
+    bet = dm2(k) - (aa(k) + aa(k + 1) + aa(k) * gm);
+    w2.set(k, (dm2(k) * w1(k) + dt * (pp(k + 1) - pp(k)) + wk(k + 1) - wk(k) - aa(k) * w2(k - 1)) / bet);
+  }
+  {
+    const T wk1 = t1g / dz2(km) * pe(km + 1);
+    const T gm = aa(km) / bet;
+    gam.set(km, gm);
+    bet = dm2(km) - (aa(km) + wk1 + aa(km) * gm);
+    w2.set(km, (dm2(km) * w1(km) + dt * (pp(km + 1) - pp(km)) - wk(km) + wk1 * (t2 * w1(km) - ra * wsfc) - aa(km) * w2(km - 1)) / bet);
+  }
+  for (int k = km - 1; k >= 1; --k) w2.set(k, w2(k) - gam(k + 1) * w2(k + 1));
+  pe.set(1, io.cst(0.));
+  for (int k = 1; k <= km; ++k) pe.set(k + 1, pe(k) + (dm2(k) * (w2(k) - w1(k)) * rdt - beta * (pp(k + 1) - pp(k))) * ra);
+  nh_new_dz(io, km, rgas, kappa - 1., p_fac, pe, bb, g_rat, dm2, pm2, pt2, dz2);
+  for (int k = 1; k <= km + 1; ++k) pe.set(k, pe(k) + beta * (pp(k) - pe(k)));
+}
+
+// C-grid half step.  f: 0 gz_a (advected interface heights, km+1)  1 wc  2 ptc  3 delpc   ->   4 gz_c (geopotential, km+1)  5 pkc (km+1)
+template <class IO>
+HD void riem_c_col(const IO& io, const NhColArgs& a, const ColWs& ws, double hs) {
+  typedef typename IO::T T;
+  const int km = a.g.npz;
+  const double gama = 1. / (1. - a.akap), rgrav = 1. / a.grav;
+  WArr<IO> pe{io, ws, NS_PE}, dm2{io, ws, NS_DM}, pm2{io, ws, NS_PM}, pem{io, ws, NS_PEM}, w2{io, ws, NS_W2}, dz2{io, ws, NS_DZ}, pt2{io, ws, NS_PT};
+  // surface velocity of the terrain-following bottom and the monotone-thickness fix (UPDATE_DZ_C tail)
+  T below = io.ld(0, km + 1);
+  const T wsfc = (hs * rgrav - below) * (1. / a.dt);
+  for (int k = km; k >= 1; --k) {
+    const T z = io.ld(0, k), lim = below + NH_DZ_MIN;
+    const T zk = (val(z) < val(lim)) ? lim : z;
+    dz2.set(k, below - zk);
+    below = zk;
+  }
+  io.st(5, 1, io.cst(a.ptop));
+  pem.set(1, io.cst(a.ptop));
+  for (int k = 1; k <= km; ++k) pem.set(k + 1, pem(k) + io.ld(3, k));
+  for (int k = 1; k <= km; ++k) {
+    const T dp = io.ld(3, k);
+    pm2.set(k, dp / dlog(pem(k + 1) / pem(k)));
+    dm2.set(k, dp * rgrav);
+    w2.set(k, io.ld(1, k)); pt2.set(k, io.ld(2, k));
+  }
+  nh_sim1(io, ws, km, a.dt, a.rdgas, gama, a.akap, wsfc, a.p_fac);
+  for (int k = 2; k <= km + 1; ++k) io.st(5, k, pe(k) + pem(k));
+  T gz = io.cst(hs);
+  io.st(4, km + 1, gz);
+  for (int k = km; k >= 1; --k) { gz = gz - dz2(k) * a.grav; io.st(4, k, gz); }
+}
+
+// D-grid full step.  f: 0 zh_a (advected heights, km+1)  1 w_m  2 pt  3 delp   ->   4 w_o  5 delz_o  6 zh_o (km+1)  7 ppe (km+1)  8 pk3 (km+1)
+//                    and at the last acoustic step 9 pe  10 peln  11 pk (km+1 each)
+template <class IO>
+HD void riem3_col(const IO& io, const NhColArgs& a, const ColWs& ws, double hs) {
+  typedef typename IO::T T;
+  const int km = a.g.npz;
+  const double gama = 1. / (1. - a.akap), rgrav = 1. / a.grav, zs = hs * rgrav;
+  WArr<IO> pe{io, ws, NS_PE}, dm2{io, ws, NS_DM}, pm2{io, ws, NS_PM}, pem{io, ws, NS_PEM}, w2{io, ws, NS_W2}, dz2{io, ws, NS_DZ}, pt2{io, ws, NS_PT},
+      pln{io, ws, NS_AA};     // peln2 borrows the aa slot until the solver starts
+  T below = io.ld(0, km + 1);
+  const T wsfc = (zs - below) * (1. / a.dt);
+  for (int k = km; k >= 1; --k) {
+    const T z = io.ld(0, k), lim = below + NH_DZ_MIN;
+    const T zk = (val(z) < val(lim)) ? lim : z;
+    dz2.set(k, below - zk);      // zh(k+1) - zh(k)
+    below = zk;
+  }
+  pem.set(1, io.cst(a.ptop));
+  const double peln1 = log(a.ptop);
+  pln.set(1, io.cst(peln1));
+  io.st(8, 1, io.cst(exp(a.akap * peln1)));
+  if (a.last_call) { io.st(9, 1, io.cst(a.ptop)); io.st(10, 1, io.cst(peln1)); io.st(11, 1, io.cst(exp(a.akap * peln1))); }
+  for (int k = 1; k <= km; ++k) {
+    const T p = pem(k) + io.ld(3, k), l = dlog(p), pk = dexp(a.akap * l);
+    pem.set(k + 1, p); pln.set(k + 1, l);
+    io.st(8, k + 1, pk);
+    if (a.last_call) { io.st(9, k + 1, p); io.st(10, k + 1, l); io.st(11, k + 1, pk); }
+  }
+  for (int k = 1; k <= km; ++k) {
+    const T dp = io.ld(3, k);
+    pm2.set(k, dp / (pln(k + 1) - pln(k)));
+    dm2.set(k, dp * rgrav);
+    w2.set(k, io.ld(1, k)); pt2.set(k, io.ld(2, k));
+  }
+  nh_sim(io, ws, km, a.dt, a.rdgas, gama, a.akap, wsfc, a.a_imp, a.p_fac, a.scale_z);
+  for (int k = 1; k <= km; ++k) { io.st(4, k, w2(k)); io.st(5, k, dz2(k)); }
+  for (int k = 1; k <= km + 1; ++k) io.st(7, k, pe(k));
+  T z = io.cst(zs);
+  io.st(6, km + 1, z);
+  for (int k = km; k >= 1; --k) { z = z - dz2(k); io.st(6, k, z); }
+}
+
+// EDGE_PROFILE (non-uniform levels, no limiter).  f: 0 q1  1 q2 (km)   ->   2 q1e  3 q2e (km+1)
+template <class IO>
+HD void edge_col(const IO& io, const NhColArgs& a, const ColWs& ws) {
+  typedef typename IO::T T;
+  const int km = a.g.npz;
+  WArr<IO> e1{io, ws, 0}, e2{io, ws, 1};
+  auto dp0 = [&](int k) { return a.lev[k - 1].dp_ref; };
+  // the elimination factors depend on the reference thicknesses only; recomputed on the way back instead of stored
+  const double g0 = dp0(2) / dp0(1);
+  double bet = g0 * (g0 + 0.5), gam = (1. + g0 * (g0 + 1.5)) / bet, gk = g0;
+  const double xt1 = 2. * g0 * (g0 + 1.);
+  e1.set(1, (xt1 * io.ld(0, 1) + io.ld(0, 2)) / bet); e2.set(1, (xt1 * io.ld(1, 1) + io.ld(1, 2)) / bet);
+  // gam(k) depends on the reference thicknesses only: kept as plain doubles in raw workspace slot 8 (e1, e2 use raw 0..3)
+  ColWs wg = ws;
+  wg.at(8, 1) = gam;
+  for (int k = 2; k <= km; ++k) {
+    gk = dp0(k - 1) / dp0(k);
+    bet = 2. + 2. * gk - gam;
+    e1.set(k, (3. * (io.ld(0, k - 1) + gk * io.ld(0, k)) - e1(k - 1)) / bet);
+    e2.set(k, (3. * (io.ld(1, k - 1) + gk * io.ld(1, k)) - e2(k - 1)) / bet);
+    gam = gk / bet;
+    wg.at(8, k) = gam;
+  }
+  const double a_bot = 1. + gk * (gk + 1.5), xb = 2. * gk * (gk + 1.), xt2 = gk * (gk + 0.5) - a_bot * gam;
+  e1.set(km + 1, (xb * io.ld(0, km) + io.ld(0, km - 1) - a_bot * e1(km)) / xt2);
+  e2.set(km + 1, (xb * io.ld(1, km) + io.ld(1, km - 1) - a_bot * e2(km)) / xt2);
+  for (int k = km; k >= 1; --k) { const double gmk = wg.at(8, k); e1.set(k, e1(k) - gmk * e1(k + 1)); e2.set(k, e2(k) - gmk * e2(k + 1)); }
+  for (int k = 1; k <= km + 1; ++k) { io.st(2, k, e1(k)); io.st(3, k, e2(k)); }
+}
+
+// interface heights from the layer thicknesses.  f: 0 delz (km)   ->   1 zh (km+1)
+template <class IO>
+HD void zh_init_col(const IO& io, const NhColArgs& a, double hs) {
+  typename IO::T z = io.cst(hs / a.grav);
+  io.st(1, a.g.npz + 1, z);
+  for (int k = a.g.npz; k >= 1; --k) { z = z - io.ld(0, k); io.st(1, k, z); }
+}
+
+// what = 0: pk3 = p**kappa (PK3_HALO), what = 1: pe (PE_HALO).  f: 0 delp (km)   ->   1 out (km+1), levels 2.. (level 1 is set by the owner)
+template <class IO>
+HD void ring_col(const IO& io, const NhColArgs& a) {
+  typename IO::T p = io.cst(a.ptop);
+  if (a.what == 1) io.st(1, 1, p);
+  for (int k = 1; k <= a.g.npz; ++k) {
+    p = p + io.ld(0, k);
+    if (a.what == 1) io.st(1, k + 1, p); else io.st(1, k + 1, dexp(a.akap * dlog(p)));
+  }
+}
+
+enum NhColKind { NHC_RIEM_C = 0, NHC_RIEM3, NHC_EDGE, NHC_ZH_INIT, NHC_RING };
+struct NhColFn {
+  NhColArgs a; int kind, mode; Rect skip;     // skip: rectangle left out (the rings of NHC_RING are a frame around it)
+  int z0;                                     // first tile of the launch (the adjoint runs tile by tile: the tape holds one tile)
+  template <class IO>
+  HD void body(const IO& io, const ColWs& ws, double hs) const {
+    if (kind == NHC_RIEM_C) riem_c_col(io, a, ws, hs);
+    else if (kind == NHC_RIEM3) riem3_col(io, a, ws, hs);
+    else if (kind == NHC_EDGE) edge_col(io, a, ws);
+    else if (kind == NHC_ZH_INIT) zh_init_col(io, a, hs);
+    else ring_col(io, a);
+  }
+  HD void operator()(int i, int j, int zz) const {
+    const int z = zz + z0;
+    if (kind == NHC_RING && skip.has(i, j)) return;
+    if (a.g.face && (i < 1 || i > a.g.nx) && (j < 1 || j > a.g.ny)) return;   // corner-halo columns hold no data
+    const size_t col = (size_t)z * a.g.plane + a.g.idx(i, j);
+    const ColWs ws{a.ws + col, a.ws_stride, a.g.npz + 2};
+    const double hs = a.hs ? a.hs[col] : 0.;
+    if (mode == MODE_NL) { ColNL io{a.g, a.f, z, i, j, nullptr}; body(io, ws, hs); }
+    else if (mode == MODE_TL) { ColTL io{a.g, a.f, z, i, j, nullptr}; body(io, ws, hs); }
+    else {
+      Tape t{a.tape, (size_t)a.g.idx(i, j), 0};
+      ColAD io{a.g, a.f, z, i, j, &t};
+      body(io, ws, hs);
+      io.reverse();
+    }
+  }
+};
+inline void run_nh_col(Exec& ex, int mode, const NhColArgs& a0, int kind, const Rect& R, const Rect& skip, const char* tag) {
+  NhColArgs a = a0;
+  for (int n = 0; n < NH_NF; ++n) a.f[n] = ex.sh(a.f[n]);
+  if (mode != MODE_AD) { for_points(ex, R, a.g.ntile, NhColFn{a, kind, mode, skip, 0}, tag); return; }
+  for (int z = 0; z < a.g.ntile; ++z) for_points(ex, R, 1, NhColFn{a, kind, mode, skip, z}, tag);
+}
+
+}  // namespace fv3

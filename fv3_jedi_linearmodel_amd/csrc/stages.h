@@ -1028,9 +1028,178 @@ struct OneGradP {
   }
 };
 
+// ===================================================================== non-hydrostatic stages
+// c_sw: w carried by the upwind mass fluxes of delp (sw_core_tlm.F90:758-778, :812-838); corner halo of delp and w through
+// fill_4corners' views like CswTransport.
+struct CswTransportWD {
+  STAGE_BASE("CswTransportW", 5, 1)   // in: delp w utf vtf delpc   out: wc
+  HD static constexpr bool uses(int M, int di, int dj, int) { return M >= 2 || di == 0 || dj == 0; }
+  HD static constexpr unsigned wants(int) { return 0x1u; }
+  HD static constexpr Box box(int M) { return M < 2 ? Box{-1, 1, -1, 1, 0, 0} : M == 2 ? Box{0, 1, 0, 0, 0, 0} : M == 3 ? Box{0, 0, 0, 1, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
+  static constexpr int NALIAS = 2;
+  HD static constexpr int alias_box(int M) { return M; }
+  HD bool alias(const Ctx& c, int M, int i, int j, int n, int& ai, int& aj) const { return M < 2 && fill2_alias(c.g, n + 1, i, j, ai, aj); }
+  template <bool EDGE, int M, class T, class A>
+  HD T rd(const A& a, const Ctx& c, int dir, int i, int j) const { if (EDGE) fill2_map(c.g, dir, i, j); return IN(M, i, j); }
+  template <bool EDGE, class T, class A>
+  HD void eval_e(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+    T fx2[2], fy2[2];
+    for (int d = 0; d < 2; ++d) {
+      T ut = IN(2, i + d, j);
+      const int iu = (val(ut) > 0.) ? i + d - 1 : i + d;
+      fx2[d] = ut * rd<EDGE, 0, T>(a, c, 1, iu, j) * rd<EDGE, 1, T>(a, c, 1, iu, j);
+      T vt = IN(3, i, j + d);
+      const int ju = (val(vt) > 0.) ? j + d - 1 : j + d;
+      fy2[d] = vt * rd<EDGE, 0, T>(a, c, 2, i, ju) * rd<EDGE, 1, T>(a, c, 2, i, ju);
+    }
+    o[0] = (rd<EDGE, 1, T>(a, c, 2, i, j) * rd<EDGE, 0, T>(a, c, 2, i, j) + (fx2[0] - fx2[1] + (fy2[0] - fy2[1])) * MET(rarea, i, j)) / IN(4, i, j);
+  }
+};
+typedef Edged<CswTransportWD, false> CswTransportW;
+// UPDATE_DZ_C, advection part (nh_utils_tlm.F90:247-366): interface heights with the C-grid area fluxes interpolated to
+// the interfaces.  Launched over the npz+1 interfaces; the fluxes have npz levels.
+struct UpdateDzCD {
+  STAGE_BASE("UpdateDzC", 3, 1)   // in: gz (npz+1) utf vtf (npz)   out: gz_a (npz+1)
+  HD static constexpr bool uses(int M, int di, int dj, int) { return M > 0 || di == 0 || dj == 0; }
+  HD static constexpr unsigned wants(int) { return 0x1u; }
+  HD static constexpr Box box(int M) { return M == 0 ? Box{-1, 1, -1, 1, 0, 0} : M == 1 ? Box{0, 1, 0, 0, -2, 1} : Box{0, 0, 0, 1, -2, 1}; }
+  static constexpr int NALIAS = 2;
+  HD static constexpr int alias_box(int M) { return M; }
+  HD bool alias(const Ctx& c, int M, int i, int j, int n, int& ai, int& aj) const { return M == 0 && fill2_alias(c.g, n + 1, i, j, ai, aj); }
+  template <int M, class T, class A>
+  HD T flux(const A& a, const Ctx& c, int i, int j, int k) const {   // area flux at interface k
+    const int km = c.g.npz;
+    auto dp0 = [&](int kk) { return c.lev[kk - 1].dp_ref; };
+    if (k == 1) return IN(M, i, j, 0) + (IN(M, i, j, 0) - IN(M, i, j, 1)) * (dp0(1) / (dp0(1) + dp0(2)));
+    if (k == km + 1) return IN(M, i, j, -1) + (IN(M, i, j, -1) - IN(M, i, j, -2)) * (dp0(km) / (dp0(km - 1) + dp0(km)));
+    return (dp0(k) * IN(M, i, j, -1) + dp0(k - 1) * IN(M, i, j, 0)) * (1. / (dp0(k - 1) + dp0(k)));
+  }
+  template <bool EDGE, class T, class A>
+  HD void eval_e(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+    auto gx = [&](int ii, int jj) -> T { if (EDGE) fill2_map(c.g, 1, ii, jj); return IN(0, ii, jj); };
+    auto gy = [&](int ii, int jj) -> T { if (EDGE) fill2_map(c.g, 2, ii, jj); return IN(0, ii, jj); };
+    T xf[2], yf[2], fx[2], fy[2];
+    for (int d = 0; d < 2; ++d) {
+      xf[d] = flux<1, T>(a, c, i + d, j, k);
+      fx[d] = xf[d] * ((val(xf[d]) > 0.) ? gx(i + d - 1, j) : gx(i + d, j));
+      yf[d] = flux<2, T>(a, c, i, j + d, k);
+      fy[d] = yf[d] * ((val(yf[d]) > 0.) ? gy(i, j + d - 1) : gy(i, j + d));
+    }
+    const double ar = MET(area, i, j);
+    o[0] = (gy(i, j) * ar + (fx[0] - fx[1]) + (fy[0] - fy[1])) / (ar + (xf[0] - xf[1]) + (yf[0] - yf[1]));
+  }
+};
+typedef Edged<UpdateDzCD, false> UpdateDzC;
+// P_GRAD_C, non-hydrostatic (wk = delpc), dyn_core_tlm.F90:3295-3334
+struct PGradCNh {
+  STAGE_BASE("PGradCNh", 5, 2)   // in: pkc gz (npz+1) uc1 vc1 delpc   out: uc2 vc2
+  STAGE_NO_ALIAS
+  double dt2;
+  HD static constexpr bool uses(int M, int di, int dj, int) { return (M >= 2 && M <= 3) || !(di == -1 && dj == -1); }
+  HD static constexpr unsigned wants(int M) { return M == 2 ? 0x1u : M == 3 ? 0x2u : 0x3u; }
+  HD static constexpr Box box(int M) { return M < 2 ? Box{-1, 0, -1, 0, 0, 1} : M == 4 ? Box{-1, 0, -1, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
+  template <class T, class A>
+  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+    o[0] = o[1] = T(0.);
+    T pk00 = IN(0, i, j, 0), pk01 = IN(0, i, j, 1), gz00 = IN(1, i, j, 0), gz01 = IN(1, i, j, 1), wk0 = IN(4, i, j);
+    if ((a.want & 0x1u) && orect[0].has(i, j)) {
+      T pkm0 = IN(0, i - 1, j, 0), pkm1 = IN(0, i - 1, j, 1), gzm0 = IN(1, i - 1, j, 0), gzm1 = IN(1, i - 1, j, 1);
+      o[0] = IN(2, i, j) + dt2 * MET(rdxc, i, j) / (IN(4, i - 1, j) + wk0) * ((gzm1 - gz00) * (pk01 - pkm0) + (gzm0 - gz01) * (pkm1 - pk00));
+    }
+    if ((a.want & 0x2u) && orect[1].has(i, j)) {
+      T pkm0 = IN(0, i, j - 1, 0), pkm1 = IN(0, i, j - 1, 1), gzm0 = IN(1, i, j - 1, 0), gzm1 = IN(1, i, j - 1, 1);
+      o[1] = IN(3, i, j) + dt2 * MET(rdyc, i, j) / (IN(4, i, j - 1) + wk0) * ((gzm1 - gz00) * (pk01 - pkm0) + (gzm0 - gz01) * (pkm1 - pk00));
+    }
+  }
+};
+// del-2 / del-4 damping increment of a cell scalar (DEL6_VT_FLUX with nord <= 1 + its divergence): dw for w in d_sw
+// (sw_core_tlm.F90:3020-3040, damp = (damp_w da_min_c)^(nord_w+1)), and the damping term of UPDATE_DZ_D (:655-667, damp raw).
+template <class T, class A>
+HD T del6_increment(const A& a, const Ctx& c, int tile, int i, int j, int nord, double damp) {
+  // inputs: 0 = q, 1 = inner Laplacian of q (Del6A)
+  T fxa, fxb, fya, fyb;
+  if (nord == 0) {
+    fxa = MET(del6_v, i, j) * (IN(0, i - 1, j) - IN(0, i, j)); fxb = MET(del6_v, i + 1, j) * (IN(0, i, j) - IN(0, i + 1, j));
+    fya = MET(del6_u, i, j) * (IN(0, i, j - 1) - IN(0, i, j)); fyb = MET(del6_u, i, j + 1) * (IN(0, i, j) - IN(0, i, j + 1));
+  } else {
+    fxa = MET(del6_v, i, j) * (IN(1, i, j) - IN(1, i - 1, j)); fxb = MET(del6_v, i + 1, j) * (IN(1, i + 1, j) - IN(1, i, j));
+    fya = MET(del6_u, i, j) * (IN(1, i, j) - IN(1, i, j - 1)); fyb = MET(del6_u, i, j + 1) * (IN(1, i, j + 1) - IN(1, i, j));
+  }
+  return damp * ((fxa - fxb + (fya - fyb)) * MET(rarea, i, j));
+}
+struct DswDw {
+  STAGE_BASE("DswDw", 2, 1)   // in: w d6w   out: dw
+  STAGE_NO_ALIAS
+  HD static constexpr bool uses(int, int di, int dj, int) { return di == 0 || dj == 0; }
+  HD static constexpr unsigned wants(int) { return 0x1u; }
+  HD static constexpr Box box(int) { return Box{-1, 1, -1, 1, 0, 0}; }
+  template <class T, class A>
+  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+    const LevelParams& l = c.lev[k - 1];
+    o[0] = T(0.);
+    if (!(l.damp_w > 1.e-5)) return;
+    double d4 = l.damp_w * c.m.da_min_c;
+    if (l.nord_w == 1) d4 = d4 * d4;
+    o[0] = del6_increment<T>(a, c, tile, i, j, l.nord_w, d4);
+  }
+};
+// w after the transport: back to velocity with the new delp, plus the damping increment (sw_core_tlm.F90:3050-3055, :3305-3330)
+struct DswUpdateW {
+  STAGE_COMMON("DswUpdateW", 6, 1)   // in: w delp delp_n gx gy dw   out: w_n
+  HD static constexpr Box box(int M) { return M == 3 ? Box{0, 1, 0, 0, 0, 0} : M == 4 ? Box{0, 0, 0, 1, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
+  template <class T, class A>
+  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+    o[0] = (IN(1, i, j) * IN(0, i, j) + (IN(3, i, j) - IN(3, i + 1, j) + (IN(4, i, j) - IN(4, i, j + 1))) * MET(rarea, i, j)) / IN(2, i, j) + IN(5, i, j);
+  }
+};
+// UPDATE_DZ_D, update of the interface heights from the transport fluxes + damping (nh_utils_tlm.F90:655-700)
+struct UpdateDzD {
+  STAGE_BASE("UpdateDzD", 6, 1)   // in: zh d6z fx fy ra_x ra_y (all npz+1)   out: zh_a
+  STAGE_NO_ALIAS
+  HD static constexpr bool uses(int M, int di, int dj, int) { return M < 2 ? (di == 0 || dj == 0) : true; }
+  HD static constexpr unsigned wants(int) { return 0x1u; }
+  HD static constexpr Box box(int M) { return M < 2 ? Box{-1, 1, -1, 1, 0, 0} : M == 2 ? Box{0, 1, 0, 0, 0, 0} : M == 3 ? Box{0, 0, 0, 1, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
+  template <class T, class A>
+  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+    const LevelParams& l = c.lev[k - 1];      // entry npz+1 repeats entry npz (ndif(km+1) = ndif(km))
+    const double ar = MET(area, i, j);
+    T z = (IN(0, i, j) * ar + (IN(2, i, j) - IN(2, i + 1, j)) + (IN(3, i, j) - IN(3, i, j + 1))) / (IN(4, i, j) + IN(5, i, j) - ar);
+    if (l.damp_vt > 1.e-5) z = z + del6_increment<T>(a, c, tile, i, j, l.nord_v, l.damp_vt);
+    o[0] = z;
+  }
+};
+// NH_P_GRAD (use_logp = .false.), dyn_core_tlm.F90:3491-3588, from the corner values of pp, pk, zh (a2b_ord4) and delp
+struct NhPGrad {
+  STAGE_BASE("NhPGrad", 6, 2)   // in: u v dp_b (npz)  pp_b pk_b zh_b (npz+1)   out: u_n v_n
+  STAGE_NO_ALIAS
+  double dt, ptk, grav;
+  HD static constexpr bool uses(int M, int di, int dj, int) { return M < 2 || !(di == 1 && dj == 1); }
+  HD static constexpr unsigned wants(int M) { return M == 0 ? 0x1u : M == 1 ? 0x2u : 0x3u; }
+  HD static constexpr Box box(int M) { return M < 2 ? Box{0, 0, 0, 0, 0, 0} : M == 2 ? Box{0, 1, 0, 1, 0, 0} : Box{0, 1, 0, 1, 0, 1}; }
+  template <class T, class A> HD T pp(const A& a, int i, int j, int k, int dk) const { return (k + dk == 1) ? T(0.) : a.template in<3>(i, j, dk); }
+  template <class T, class A> HD T pk(const A& a, int i, int j, int k, int dk) const { return (k + dk == 1) ? T(ptk) : a.template in<4>(i, j, dk); }
+  template <class T, class A>
+  HD T grad(const A& a, int i, int j, int i2, int j2, int k) const {   // between corner (i,j) and (i2,j2)
+    T g00 = grav * IN(5, i, j, 0), g01 = grav * IN(5, i, j, 1), g10 = grav * IN(5, i2, j2, 0), g11 = grav * IN(5, i2, j2, 1);
+    T k00 = pk<T>(a, i, j, k, 0), k01 = pk<T>(a, i, j, k, 1), k10 = pk<T>(a, i2, j2, k, 0), k11 = pk<T>(a, i2, j2, k, 1);
+    T p00 = pp<T>(a, i, j, k, 0), p01 = pp<T>(a, i, j, k, 1), p10 = pp<T>(a, i2, j2, k, 0), p11 = pp<T>(a, i2, j2, k, 1);
+    T du = dt / ((k01 - k00) + (k11 - k10)) * ((g01 - g10) * (k11 - k00) + (g00 - g11) * (k01 - k10));
+    return du + dt / (IN(2, i, j) + IN(2, i2, j2)) * ((g01 - g10) * (p11 - p00) + (g00 - g11) * (p01 - p10));
+  }
+  template <class T, class A>
+  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+    o[0] = o[1] = T(0.);
+    if ((a.want & 0x1u) && orect[0].has(i, j)) o[0] = (IN(0, i, j) + grad<T>(a, i, j, i + 1, j, k)) * MET(rdx, i, j);
+    if ((a.want & 0x2u) && orect[1].has(i, j)) o[1] = (IN(1, i, j) + grad<T>(a, i, j, i, j + 1, k)) * MET(rdy, i, j);
+  }
+};
+
 // level classes for the joint adjoint (exec.h): pkc/gz and pk_b/gz_b carry npz+1 levels, the winds npz
 constexpr int kclass_of(const PGradC*, int M) { return M < 2 ? 1 : 0; }
 constexpr int kclass_of(const OneGradP*, int M) { return M < 2 ? 0 : 1; }
+constexpr int kclass_of(const PGradCNh*, int M) { return M < 2 ? 1 : 0; }
+constexpr int kclass_of(const NhPGrad*, int M) { return M < 3 ? 0 : 1; }
+template <bool E> constexpr int kclass_of(const Edged<UpdateDzCD, E>*, int M) { return M == 0 ? 1 : 0; }
 
 // inputs that only the face-edge formulas of a stage read (bit m = input m): not given to the bulk launch
 template <class D> constexpr unsigned edge_only_inputs(const D*) { return 0u; }

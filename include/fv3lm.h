@@ -45,6 +45,7 @@ typedef struct fv3lm_options {
   double akap, cp, zvir, grav_jedi;                          /* JEDI constants */
   double cp_air, rdgas, rvgas, grav, radius, omega, hlv;     /* FMS constants_mod */
   double ptop;
+  double a_imp, p_fac, scale_z;                              /* non-hydrostatic solver (hydrostatic = 0): off-centering, pressure floor factor, w damping */
 } fv3lm_options;
 
 typedef struct fv3lm_dims {

@@ -1,0 +1,22 @@
+"""Non-hydrostatic acoustic steps: the product's stage + column-tape implementation compiled for the
+host (FV3LM_HOST_EMUL: same kernel bodies, loops instead of launches) against oracle/nh.hpp (checks in nh_checks.py)."""
+import pytest
+from common import Case
+import nh_checks as N
+
+
+@pytest.fixture(scope="module")
+def nhc():
+    return Case(nx=10, ny=8, npz=8, n_split=2, dt=600.0, backend="emul", hord_ks_traj=0, hord_ks_pert=0, hydrostatic=0)
+
+
+def test_nh_dyn_core_tangent_matches_oracle(nhc):
+    N.check_nh_tangent(nhc)
+
+
+def test_nh_dyn_core_adjoint_matches_oracle(nhc):
+    N.check_nh_adjoint(nhc)
+
+
+def test_nh_dot_product(nhc):
+    N.check_nh_dot_product(nhc)
