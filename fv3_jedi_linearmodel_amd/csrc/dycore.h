@@ -148,6 +148,7 @@ struct Dycore {
   ExRemote xr[H_NKIND];               // ... and the part of each exchange that crosses ranks (set_exchange_remote)
   double *edge_dev = nullptr, *ecorner_dev = nullptr;
   bool last_acoustic = false;         // the acoustic step being run is the last of its dyn_core call
+  bool remap_last = false;            // the vertical remap being run is the one of the last k_split step
   bool halo_missing = false;          // an exchange was needed before its table was set
 
   Fld& f(const char* n) {
@@ -356,7 +357,7 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
   if (phis_host) h2d(ex, hs_dev, phis_host, np * 8);
   ctx.g = g; ctx.lev = lev_dev; ctx.nlev = npz;
   n3 = np * npz; n3p = np * (npz + 1);
-  state.init(n3 * (16 + 3 * (size_t)nq + (nh ? 2 : 0)) + n3p * (8 + (nh ? 1 : 0)));
+  state.init(n3 * (16 + 3 * (size_t)nq + (nh ? 6 + (size_t)nq : 0)) + n3p * (8 + (nh ? 1 : 0)) + np);
   work.init(n3 * ((g.face ? 120 : 114) + (nh ? 28 : 0)) + n3p * (14 + (nh ? 44 : 0)));
   if (nh) {
     nh_ws = (double*)dev_alloc((size_t)2 * NS_COUNT * (npz + 2) * np * 8);
@@ -462,16 +463,17 @@ inline void Dycore::destroy() {
 inline NhColArgs Dycore::nh_args(double dt_) const {
   NhColArgs a{};
   a.g = g; a.ws = nh_ws; a.ws_stride = (size_t)g.ntile * g.plane; a.tape = nh_tape; a.hs = hs_dev; a.lev = lev_dev;
+  a.zvir = opt.zvir; a.cp_air = opt.cp_air;
   a.dt = dt_; a.akap = opt.akap; a.ptop = opt.ptop; a.rdgas = opt.rdgas; a.grav = opt.grav; a.a_imp = opt.a_imp; a.p_fac = opt.p_fac; a.scale_z = opt.scale_z;
   return a;
 }
-// column operator of nh.h as a program step.  when: 0 every acoustic step, 2 the last only
+// column operator of nh.h as a program step.  when: 0 every acoustic step, 2 the last only, 3 vertical remap (last_call = last k_split step)
 inline void Dycore::add_col(Program& P, const char* group, int kind, const NhColArgs& a, Rect r, Rect skip, int when) {
   Dycore* self = this;
-  static const char* tags[] = {"riem_c", "riem3", "edge_profile", "zh_init", "p_ring"};
+  static const char* tags[] = {"riem_c", "riem3", "edge_profile", "zh_init", "p_ring", "remap_field_nh", "remap_press_nh"};
   P.push_back(Op{group, [self, kind, a, r, skip, when](Exec& e, int mode) {
     if (when == 2 && !self->last_acoustic) return;
-    NhColArgs b = a; b.last_call = self->last_acoustic ? 1 : 0;
+    NhColArgs b = a; b.last_call = (when == 3 ? self->remap_last : self->last_acoustic) ? 1 : 0;
     run_nh_col(e, mode, b, kind, r, skip, tags[kind]);
   }});
 }
@@ -643,7 +645,7 @@ inline void Dycore::build_acoustic() {
     // ---- riem_solver3 + halo rings of the pressures + nh_p_grad (dyn_core_tlm.F90:2165-2400)
     Fld ppe = W("ppe", npz + 1), pk3 = W("pk3", npz + 1);
     { NhColArgs a = nh_args(dt); a.f[0] = zh_a; a.f[1] = w_m; a.f[2] = pt_o; a.f[3] = delp_o; a.f[4] = w_o; a.f[5] = delz_o; a.f[6] = zh_o; a.f[7] = ppe;
-      a.f[8] = pk3; a.f[9] = pe; a.f[10] = peln; a.f[11] = pk; add_col(P, "riem3", NHC_RIEM3, a, R(is, ie, js, je)); }
+      a.f[8] = pk3; a.f[9] = pe; a.f[10] = peln; a.f[11] = pk; a.f[12] = S("ws", 1); add_col(P, "riem3", NHC_RIEM3, a, R(is, ie, js, je)); }
     add_halo(P, "halo_zh", H_CELL, zh_o); add_halo(P, "halo_zh", H_CELL, ppe);
     { NhColArgs a = nh_args(dt); a.f[0] = delp_o; a.f[1] = pe; a.what = 1;
       add_col(P, "p_ring", NHC_RING, a, R(is - 1, ie + 1, js - 1, je + 1), R(is, ie, js, je), 2); }

@@ -99,6 +99,13 @@ struct Dynamics : Dycore {
   std::vector<Fld> q;
   Fld dp1, qc, qc_o, pe2, pu_ad, pv_ad;
   double *ak_dev = nullptr, *bk_dev = nullptr, *remap_ws = nullptr, *cmax_dev = nullptr;
+  // non-hydrostatic vertical remap (nh.h): column operators into the staging fields, handed back to the state afterwards
+  Program remap_nh;
+  Fld t_m, w_m, dz_m; std::vector<Fld> q_m;
+  double* ck_nh = nullptr;     // per k_split step: delp, w, delz before the remap + ws
+  double* cknh(int km, int n) { return ck_nh + (size_t)km * (3 * n3 + (size_t)g.ntile * g.plane) + (size_t)n * n3; }
+  void build_remap_nh();
+  void remap_nh_run(int mode, int km);
   double* ck_k = nullptr;      // per-k_split checkpoints
   double* ck_0 = nullptr;      // initial T and pkz
   size_t ck_k_stride = 0;
@@ -121,11 +128,12 @@ struct Dynamics : Dycore {
   }
   void tracer_ad();
   void fv_dynamics(int mode);
-  void step_tl() { pressures(MODE_TL); fv_dynamics(MODE_TL); }
-  void step_nl() { pressures(MODE_NL); fv_dynamics(MODE_NL); }
+  // non-hydrostatic: pe, peln, pk come out of the last acoustic step and pkz from the equation of state; nothing to prepare
+  void step_tl() { if (!nh) pressures(MODE_TL); fv_dynamics(MODE_TL); }
+  void step_nl() { if (!nh) pressures(MODE_NL); fv_dynamics(MODE_NL); }
   // after step_nl() has stored the checkpoints.  The backward sweep leaves the initial delp trajectory
   // in place (first acoustic checkpoint), from which the initial pressures are recomputed.
-  void step_ad() { fv_dynamics(MODE_AD); pressures(MODE_NL); pressures(MODE_AD); }
+  void step_ad() { fv_dynamics(MODE_AD); if (!nh) { pressures(MODE_NL); pressures(MODE_AD); } }
 
   double* ckq(int km, int n) { return ck_k + (size_t)km * ck_k_stride + (size_t)n * n3; }                       // q before tracer
   double* ckm(int km, int n) { return ck_k + (size_t)km * ck_k_stride + (size_t)(nq + n) * n3; }                // mfx mfy cx cy
@@ -153,6 +161,13 @@ inline bool Dynamics::init2(const double* ak, const double* bk) {
   tshared.init(n3 * 10); twork.init(n3 * 10);
   tr_ksplt_km.assign(k_split, std::vector<int>(npz, 1)); tr_nsplt_km.assign(k_split, 1);
   build_tracer();
+  if (nh) {
+    DynPtInNh s; s.in[0] = f("pt"); s.in[1] = nq > 0 ? q[0] : Fld{}; if (!s.in[1].t) s.in[1].nk = npz; s.in[2] = f("delp"); s.in[3] = f("delz");
+    s.out[0] = f("pt_o"); s.out[1] = f("pkz"); s.orect[0] = s.orect[1] = R(1, g.nx, 1, g.ny); s.k1 = npz; s.zvir = opt.zvir; s.akap = opt.akap;
+    s.rdg = -opt.rdgas / opt.grav; s.has_q = nq > 0; add(pt_in, "pt_in", s);
+    build_remap_nh();
+    ck_nh = (double*)dev_alloc((3 * n3 + (size_t)g.ntile * g.plane) * k_split * 8);
+  } else
   { DynPtIn s; s.in[0] = f("pt"); s.in[1] = nq > 0 ? q[0] : Fld{}; if (!s.in[1].t) s.in[1].nk = npz; s.in[2] = f("pkz"); s.out[0] = f("pt_o");
     s.orect[0] = R(1, g.nx, 1, g.ny); s.k1 = npz; s.zvir = opt.zvir; s.has_q = nq > 0; add(pt_in, "pt_in", s); }
   ck_k_stride = (size_t)(2 * nq + 7) * n3 + 3 * n3p;
@@ -162,10 +177,51 @@ inline bool Dynamics::init2(const double* ak, const double* bk) {
   return true;
 }
 inline void Dynamics::destroy2() {
-  dev_free(ak_dev); dev_free(bk_dev); dev_free(remap_ws); dev_free(cmax_dev); dev_free(ck_k); dev_free(ck_0);
+  dev_free(ak_dev); dev_free(bk_dev); dev_free(remap_ws); dev_free(cmax_dev); dev_free(ck_k); dev_free(ck_0); dev_free(ck_nh);
   tshared.destroy(); twork.destroy();
   for (double* p : snap) dev_free(p);
   for (auto& kv : sub_ck) dev_free(kv.second);
+}
+
+inline void Dynamics::build_remap_nh() {
+  const int npz = g.npz;
+  const Rect A = R(1, g.nx, 1, g.ny);
+  t_m = S("remap_t", npz); w_m = S("remap_w", npz); dz_m = S("remap_dz", npz);
+  for (int n = 0; n < nq; ++n) { char nm[24]; std::snprintf(nm, sizeof nm, "remap_q%d", n + 1); q_m.push_back(S(nm, npz)); }
+  auto args = [&](int what) { NhColArgs a = nh_args(0.); a.ak = ak_dev; a.bk = bk_dev; a.what = what; return a; };
+  { NhColArgs a = args(0); a.f[0] = f("pe"); a.f[1] = f("peln"); a.f[2] = f("pt"); a.f[3] = f("delp"); a.f[4] = f("delz"); a.f[5] = t_m;
+    add_col(remap_nh, "remap", NHC_RM_FIELD, a, A, Rect{1, 0, 1, 0}, 3); }
+  { NhColArgs a = args(1); a.f[0] = f("pe"); a.f[1] = f("w"); a.f[2] = f("ws"); a.f[3] = w_m; add_col(remap_nh, "remap", NHC_RM_FIELD, a, A, Rect{1, 0, 1, 0}, 3); }
+  { NhColArgs a = args(2); a.f[0] = f("pe"); a.f[1] = f("delz"); a.f[2] = f("delp"); a.f[3] = dz_m; add_col(remap_nh, "remap", NHC_RM_FIELD, a, A, Rect{1, 0, 1, 0}, 3); }
+  for (int n = 0; n < nq; ++n) { NhColArgs a = args(3); a.f[0] = f("pe"); a.f[1] = q[n]; a.f[2] = q_m[n]; add_col(remap_nh, "remap", NHC_RM_FIELD, a, A, Rect{1, 0, 1, 0}, 3); }
+  { NhColArgs a = args(nq > 0 ? 1 : 0); a.f[0] = f("pe"); a.f[1] = f("peln"); a.f[2] = f("pk"); a.f[3] = t_m; a.f[4] = dz_m; a.f[5] = nq > 0 ? q_m[0] : Fld{};
+    a.f[6] = f("delp"); a.f[7] = f("pkz"); a.f[8] = f("pt"); a.f[9] = pe2; add_col(remap_nh, "remap", NHC_RM_PRESS, a, A, Rect{1, 0, 1, 0}, 3);
+    remap_nh.back().accum = true; }     // overwrites delp, peln, pk: left out of the adjoint's trajectory recompute
+}
+// Vertical remap, non-hydrostatic: scalars by the column operators above, winds by the kernels of remap.h.
+// Adjoint: the pre-remap trajectory (pt u v q pe peln pk delp w delz ws) must be in place.
+inline void Dynamics::remap_nh_run(int mode, int km) {
+  const size_t b3 = n3 * 8;
+  RemapArgs ra = remap_args(km == k_split - 1);
+  const Rect A{1, g.nx, 1, g.ny}, U{1, g.nx, 1, g.ny + 1}, V{1, g.nx + 1, 1, g.ny}, H{0, g.nx + 1, 0, g.ny + 1};
+  remap_last = (km == k_split - 1);
+  std::vector<std::pair<Fld, Fld>> back{{f("w"), w_m}, {f("delz"), dz_m}};
+  for (int n = 0; n < nq; ++n) back.push_back({q[n], q_m[n]});
+  if (mode != MODE_AD) {
+    run_group(remap_nh, nullptr, mode);
+    for (auto& pr : back) { dev_copy(ex, pr.first.t, pr.second.t, b3); if (mode == MODE_TL) dev_copy(ex, pr.first.p, pr.second.p, b3); }
+    for_points(ex, U, g.ntile, RemapWindFn{ra, mode, 0}, mode == MODE_TL ? "remap_wind.tl" : "remap_wind.nl");
+    for_points(ex, V, g.ntile, RemapWindFn{ra, mode, 1}, mode == MODE_TL ? "remap_wind.tl" : "remap_wind.nl");
+    for_points(ex, A, g.ntile, RemapPeFn{ra, mode}, "remap_pe");
+    return;
+  }
+  for_points(ex, V, g.ntile, RemapWindFn{ra, mode, 1}, "remap_wind.ad");
+  for_points(ex, U, g.ntile, RemapWindFn{ra, mode, 0}, "remap_wind.ad");
+  for_points(ex, H, g.ntile, RemapGatherFn{ra}, "remap_gather.ad");
+  run_group(remap_nh, nullptr, MODE_NL, true);      // trajectory of the staging fields
+  dev_zero(ex, t_m.p, b3); dev_zero(ex, pe2.p, n3p * 8);     // pe after the remap is not read again (pe2 is only copied into it)
+  for (auto& pr : back) { dev_copy(ex, pr.second.p, pr.first.p, b3); dev_zero(ex, pr.first.p, b3); }
+  run_group(remap_nh, nullptr, MODE_AD);
 }
 
 inline void Dynamics::build_tracer() {
@@ -315,7 +371,13 @@ inline void Dynamics::fv_dynamics(int mode) {
           for (int n = 0; n < 3; ++n) dev_copy(ex, ckr3(km, n), f(r3[n]).t, b3);
           for (int n = 0; n < nq; ++n) dev_copy(ex, ckr3(km, 3 + n), q[n].t, b3);
           for (int n = 0; n < 3; ++n) dev_copy(ex, ckrp(km, n), f(rp[n]).t, b3p);
+          if (nh) {
+            const char* r4[3] = {"delp", "w", "delz"};
+            for (int n = 0; n < 3; ++n) dev_copy(ex, cknh(km, n), f(r4[n]).t, b3);
+            dev_copy(ex, cknh(km, 3), f("ws").t, (size_t)g.ntile * g.plane * 8);
+          }
         }
+        if (nh) remap_nh_run(mode, km); else
         run_remap(ex, mode, remap_args(km == k_split - 1));
       }
     }
@@ -325,6 +387,7 @@ inline void Dynamics::fv_dynamics(int mode) {
   // entry: u,v,pt,delp,q[n] .p = adjoint of the step outputs.  pe..pkz after the last remap are dead.
   for (const char* n : {"pe", "peln", "pk"}) dev_zero(ex, f(n).p, b3p);
   dev_zero(ex, f("pkz").p, b3);
+  if (nh) dev_zero(ex, f("ws").p, (size_t)g.ntile * g.plane * 8);
   for (int km = k_split - 1; km >= 0; --km) {
     if (g.npz > 4) {
       const char* r3[3] = {"pt", "u", "v"}; const char* rp[3] = {"pe", "peln", "pk"};
@@ -332,6 +395,12 @@ inline void Dynamics::fv_dynamics(int mode) {
       for (int n = 0; n < nq; ++n) dev_copy(ex, q[n].t, ckr3(km, 3 + n), b3);
       for (int n = 0; n < 3; ++n) dev_copy(ex, f(rp[n]).t, ckrp(km, n), b3p);
       dev_zero(ex, f("pe").p, b3p);
+      if (nh) {
+        const char* r4[3] = {"delp", "w", "delz"};
+        for (int n = 0; n < 3; ++n) dev_copy(ex, f(r4[n]).t, cknh(km, n), b3);
+        dev_copy(ex, f("ws").t, cknh(km, 3), (size_t)g.ntile * g.plane * 8);
+        remap_nh_run(MODE_AD, km);
+      } else
       run_remap(ex, MODE_AD, remap_args(km == k_split - 1));
     }
     const char* mf[4] = {"mfx", "mfy", "cx", "cy"};
@@ -340,7 +409,7 @@ inline void Dynamics::fv_dynamics(int mode) {
     if (nq > 0) {
       for (int n = 0; n < nq; ++n) dev_copy(ex, q[n].t, ckq(km, n), b3);
       for (int n = 0; n < 4; ++n) dev_copy(ex, f(mf[n]).t, ckm(km, n), b3);
-      dev_copy(ex, dp1.t, ckpt + ((size_t)(km * n_split) * 4 + 2) * n3, b3);   // delp at the start of this k_split step
+      dev_copy(ex, dp1.t, ckpt + (size_t)(km * n_split) * ck_stride + 2 * n3, b3);   // delp at the start of this k_split step
       cur_km = km;
       tracer_ad();
       for (int n = 0; n < nq; ++n) halo(MODE_AD, H_CELL, q[n]);

@@ -13,7 +13,7 @@
 namespace fv3 {
 
 constexpr double NH_DZ_MIN = 2.0;      // nh_utils: dz_min
-constexpr int NH_NF = 12;
+constexpr int NH_NF = 13;
 
 struct NhColArgs {
   Geom g; Fld f[NH_NF];
@@ -21,6 +21,8 @@ struct NhColArgs {
   const double* hs;                    // surface geopotential [ntile][plane]
   const LevelParams* lev;
   double dt, akap, ptop, rdgas, grav, a_imp, p_fac, scale_z;
+  const double *ak, *bk;               // hybrid coefficients, device [npz+1] (vertical remap)
+  double zvir, cp_air;
   int last_call, what;
 };
 
@@ -166,7 +168,7 @@ HD void riem_c_col(const IO& io, const NhColArgs& a, const ColWs& ws, double hs)
 }
 
 // D-grid full step.  f: 0 zh_a (advected heights, km+1)  1 w_m  2 pt  3 delp   ->   4 w_o  5 delz_o  6 zh_o (km+1)  7 ppe (km+1)  8 pk3 (km+1)
-//                    and at the last acoustic step 9 pe  10 peln  11 pk (km+1 each)
+//                    and at the last acoustic step 9 pe  10 peln  11 pk (km+1 each)  12 ws (one level: surface w, lower boundary of the w remap)
 template <class IO>
 HD void riem3_col(const IO& io, const NhColArgs& a, const ColWs& ws, double hs) {
   typedef typename IO::T T;
@@ -176,6 +178,7 @@ HD void riem3_col(const IO& io, const NhColArgs& a, const ColWs& ws, double hs) 
       pln{io, ws, NS_AA};     // peln2 borrows the aa slot until the solver starts
   T below = io.ld(0, km + 1);
   const T wsfc = (zs - below) * (1. / a.dt);
+  if (a.last_call) io.st(12, 1, wsfc);
   for (int k = km; k >= 1; --k) {
     const T z = io.ld(0, k), lim = below + NH_DZ_MIN;
     const T zk = (val(z) < val(lim)) ? lim : z;
@@ -256,7 +259,150 @@ HD void ring_col(const IO& io, const NhColArgs& a) {
   }
 }
 
-enum NhColKind { NHC_RIEM_C = 0, NHC_RIEM3, NHC_EDGE, NHC_ZH_INIT, NHC_RING };
+// ---------------------------------------------------------------- vertical remap, non-hydrostatic (fv_mapz_tlm.F90)
+// One column of map_scalar / map1_ppm / map1_q2 with the "perfectly linear" profile (|kord| > 16, the only one the TL/AD
+// reference implements, fv_mapz_tlm.F90:8653-8666) on the generic column interface.  Inputs staged in the workspace:
+// RS_P1 source interfaces (km+1), RS_Q1 layer means (km), RS_P2 target interfaces (km+1).  iv = -2: vertical velocity, the
+// value qs at the lower boundary is given (:8549-8590).
+enum { RS_P1 = 0, RS_Q1, RS_P2, RS_G, RS_E, RS_COUNT };
+template <class IO, class FOut>
+HD void map_col_io(const IO& io, int km, const ColWs& ws, int iv, const typename IO::T& qs, const FOut& out) {
+  typedef typename IO::T T;
+  WArr<IO> pe1{io, ws, RS_P1}, q1{io, ws, RS_Q1}, pe2{io, ws, RS_P2}, gam{io, ws, RS_G}, qe{io, ws, RS_E};
+  if (iv == -2) {
+    gam.set(2, io.cst(0.5)); qe.set(1, 1.5 * q1(1));
+    for (int k = 2; k <= km - 1; ++k) {
+      const T grat = (pe1(k) - pe1(k - 1)) / (pe1(k + 1) - pe1(k));
+      const T bet = 2. + grat + grat - gam(k);
+      qe.set(k, (3. * (q1(k - 1) + q1(k)) - qe(k - 1)) / bet);
+      gam.set(k + 1, grat / bet);
+    }
+    const T grat = (pe1(km) - pe1(km - 1)) / (pe1(km + 1) - pe1(km));
+    qe.set(km, (3. * (q1(km - 1) + q1(km)) - grat * qs - qe(km - 1)) / (2. + grat + grat - gam(km)));
+    qe.set(km + 1, qs);
+    for (int k = km - 1; k >= 1; --k) qe.set(k, qe(k) - gam(k + 1) * qe(k + 1));
+  } else {
+    const T dpa = pe1(2) - pe1(1), grat = (pe1(3) - pe1(2)) / dpa;
+    T bet = grat * (grat + 0.5);
+    qe.set(1, ((grat + grat) * (grat + 1.) * q1(1) + q1(2)) / bet);
+    gam.set(1, (1. + grat * (grat + 1.5)) / bet);
+    T d4 = grat, dp_prev = dpa;
+    for (int k = 2; k <= km; ++k) {
+      const T dpk = pe1(k + 1) - pe1(k);
+      d4 = dp_prev / dpk;
+      bet = 2. + d4 + d4 - gam(k - 1);
+      qe.set(k, (3. * (q1(k - 1) + d4 * q1(k)) - qe(k - 1)) / bet);
+      gam.set(k, d4 / bet);
+      dp_prev = dpk;
+    }
+    const T a_bot = 1. + d4 * (d4 + 1.5);
+    qe.set(km + 1, (2. * d4 * (d4 + 1.) * q1(km) + q1(km - 1) - a_bot * qe(km)) / (d4 * (d4 + 0.5) - a_bot * gam(km)));
+    for (int k = km; k >= 1; --k) qe.set(k, qe(k) - gam(k) * qe(k + 1));
+  }
+  int k0 = 1;
+  T qsum = io.cst(0.);
+  for (int k = 1; k <= km; ++k) {
+    const T p2t = pe2(k), p2b = pe2(k + 1);
+    int l; bool found = false;
+    for (l = k0; l <= km; ++l)
+      if (val(p2t) >= val(pe1(l)) && val(p2t) <= val(pe1(l + 1))) { found = true; break; }
+    if (found) {
+      const T p1l = pe1(l), p1r = pe1(l + 1), dpl = p1r - p1l;
+      const T a1 = q1(l), a2 = qe(l), a3 = qe(l + 1), a4 = 3. * (2. * a1 - (a2 + a3));
+      const T pl = (p2t - p1l) / dpl;
+      if (val(p2b) <= val(p1r)) {
+        const T pr = (p2b - p1l) / dpl;
+        out(k, a2 + 0.5 * (a4 + a3 - a2) * (pr + pl) - a4 * R3 * (pr * (pr + pl) + pl * pl));
+        k0 = l;
+        continue;
+      }
+      qsum = (p1r - p2t) * (a2 + 0.5 * (a4 + a3 - a2) * (1. + pl) - a4 * (R3 * (1. + pl * (1. + pl))));
+      int m; bool bottom = false;
+      for (m = l + 1; m <= km; ++m) {
+        if (val(p2b) > val(pe1(m + 1))) qsum = qsum + (pe1(m + 1) - pe1(m)) * q1(m);
+        else { bottom = true; break; }
+      }
+      if (bottom) {
+        const T p1m = pe1(m), dpm = pe1(m + 1) - p1m;
+        const T b1 = q1(m), b2 = qe(m), b3 = qe(m + 1), b4 = 3. * (2. * b1 - (b2 + b3));
+        const T dp = p2b - p1m, esl = dp / dpm;
+        qsum = qsum + dp * (b2 + 0.5 * esl * (b3 - b2 + b4 * (1. - R23 * esl)));
+        k0 = m;
+      }
+    }
+    out(k, qsum / (p2b - p2t));
+  }
+}
+// Eulerian target interfaces from the surface pressure (fv_mapz_tlm.F90:1644-1661)
+template <class IO>
+HD void rm_target(const IO& io, const NhColArgs& a, const ColWs& ws, int slot_pe) {
+  typedef typename IO::T T;
+  const int km = a.g.npz;
+  WArr<IO> p2{io, ws, RS_P2};
+  const T ps = io.ld(slot_pe, km + 1);
+  for (int k = 1; k <= km + 1; ++k) {
+    const T p = k == 1 ? io.cst(a.ptop) : k == km + 1 ? ps : a.ak[k - 1] + a.bk[k - 1] * ps;
+    p2.set(k, p);
+  }
+}
+// what: 0 temperature, 1 vertical velocity, 2 layer thickness, 3 tracer.
+//   0  f: 0 pe 1 peln 2 pt 3 delp 4 delz -> 5 T_v on the new levels   (density pt -> density T :1607-1613, map_scalar in log p :1676-1688)
+//   1  f: 0 pe 1 w 2 ws -> 3 w                                         (map1_ppm, iv = -2, :1772-1780)
+//   2  f: 0 pe 1 delz 2 delp -> 3 delz                                 (specific volume / g :1635-1641, map1_ppm :1782-1796)
+//   3  f: 0 pe 1 q -> 2 q                                              (map1_q2 :1746-1763)
+template <class IO>
+HD void remap_field_col_nh(const IO& io, const NhColArgs& a, const ColWs& ws) {
+  typedef typename IO::T T;
+  const int km = a.g.npz;
+  WArr<IO> p1{io, ws, RS_P1}, q1{io, ws, RS_Q1}, p2{io, ws, RS_P2};
+  rm_target(io, a, ws, 0);
+  if (a.what == 0) {
+    const double rrg = -a.rdgas / a.grav, k1k = a.rdgas / (a.cp_air - a.rdgas);
+    for (int k = 1; k <= km + 1; ++k) p1.set(k, io.ld(1, k));
+    for (int k = 2; k <= km; ++k) p2.set(k, dlog(p2(k)));
+    p2.set(1, p1(1)); p2.set(km + 1, p1(km + 1));
+    for (int k = 1; k <= km; ++k) { const T pt = io.ld(2, k); q1.set(k, pt * dexp(k1k * dlog(rrg * io.ld(3, k) / io.ld(4, k) * pt))); }
+    map_col_io(io, km, ws, 1, io.cst(0.), [&](int k, const T& x) { io.st(5, k, x); });
+    return;
+  }
+  for (int k = 1; k <= km + 1; ++k) p1.set(k, io.ld(0, k));
+  if (a.what == 1) {
+    for (int k = 1; k <= km; ++k) q1.set(k, io.ld(1, k));
+    map_col_io(io, km, ws, -2, io.ld(2, 1), [&](int k, const T& x) { io.st(3, k, x); });
+  } else if (a.what == 2) {
+    for (int k = 1; k <= km; ++k) q1.set(k, -(io.ld(1, k) / io.ld(2, k)));
+    map_col_io(io, km, ws, 1, io.cst(0.), [&](int k, const T& x) { io.st(3, k, -(x * (p2(k + 1) - p2(k)))); });
+  } else {
+    for (int k = 1; k <= km; ++k) q1.set(k, io.ld(1, k));
+    map_col_io(io, km, ws, 1, io.cst(0.), [&](int k, const T& x) { io.st(2, k, x); });
+  }
+}
+// New pressures, pkz from the equation of state, and the temperature hand-over (:1644-1661, :1798-1812, :1852-1857, :2203-2250).
+// f: 0 pe  1 peln  2 pk (end interfaces read, interior interfaces written)  3 T_v  4 delz  5 q_v (what = 1)  ->  6 delp  7 pkz  8 pt  9 pe2
+template <class IO>
+HD void remap_press_col_nh(const IO& io, const NhColArgs& a) {
+  typedef typename IO::T T;
+  const int km = a.g.npz;
+  const double rrg = -a.rdgas / a.grav;
+  const T ps = io.ld(0, km + 1), pn_bot = io.ld(1, km + 1), pk_bot = io.ld(2, km + 1);
+  T pe_hi = io.cst(a.ptop), pn_hi = io.ld(1, 1), pk_hi = io.ld(2, 1);
+  io.st(9, 1, pe_hi);
+  for (int k = 1; k <= km; ++k) {
+    T pe_lo, pn_lo, pk_lo;
+    if (k == km) { pe_lo = ps; pn_lo = pn_bot; pk_lo = pk_bot; }
+    else { pe_lo = a.ak[k] + a.bk[k] * ps; pn_lo = dlog(pe_lo); pk_lo = dexp(a.akap * pn_lo); }
+    const T dp = pe_lo - pe_hi, t = io.ld(3, k);
+    const T pkz = dexp(a.akap * dlog(rrg * dp / io.ld(4, k) * t));
+    io.st(6, k, dp); io.st(7, k, pkz);
+    if (a.last_call) { if (a.what) io.st(8, k, t / (1. + a.zvir * io.ld(5, k))); else io.st(8, k, t); }
+    else io.st(8, k, t / pkz);
+    if (k > 1) { io.st(1, k, pn_hi); io.st(2, k, pk_hi); }
+    io.st(9, k + 1, pe_lo);
+    pe_hi = pe_lo; pn_hi = pn_lo; pk_hi = pk_lo;
+  }
+}
+
+enum NhColKind { NHC_RIEM_C = 0, NHC_RIEM3, NHC_EDGE, NHC_ZH_INIT, NHC_RING, NHC_RM_FIELD, NHC_RM_PRESS };
 struct NhColFn {
   NhColArgs a; int kind, mode; Rect skip;     // skip: rectangle left out (the rings of NHC_RING are a frame around it)
   int z0;                                     // first tile of the launch (the adjoint runs tile by tile: the tape holds one tile)
@@ -266,7 +412,9 @@ struct NhColFn {
     else if (kind == NHC_RIEM3) riem3_col(io, a, ws, hs);
     else if (kind == NHC_EDGE) edge_col(io, a, ws);
     else if (kind == NHC_ZH_INIT) zh_init_col(io, a, hs);
-    else ring_col(io, a);
+    else if (kind == NHC_RING) ring_col(io, a);
+    else if (kind == NHC_RM_FIELD) remap_field_col_nh(io, a, ws);
+    else remap_press_col_nh(io, a);
   }
   HD void operator()(int i, int j, int zz) const {
     const int z = zz + z0;

@@ -997,6 +997,19 @@ struct DynPtIn {
     o[0] = IN(0, i, j) * (1. + d) / IN(2, i, j);
   }
 };
+// non-hydrostatic: pkz from the equation of state first (fv_dynamics_tlm.F90:443-466, moist_phys = .true.)
+struct DynPtInNh {
+  STAGE_COMMON("DynPtInNh", 4, 2)   // in: pt(T) qv delp delz   out: pt(theta_v) pkz
+  double zvir, akap, rdg; int has_q;
+  HD static constexpr Box box(int) { return Box{0, 0, 0, 0, 0, 0}; }
+  template <class T, class A>
+  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+    T d = has_q ? zvir * IN(1, i, j) : T(0.);
+    T tv = IN(0, i, j) * (1. + d);
+    T pkz = dexp(akap * dlog(rdg * IN(2, i, j) * tv / IN(3, i, j)));
+    o[0] = tv / pkz; o[1] = pkz;
+  }
+};
 
 // one_grad_p wind update from corner pk, gz (dyn_core_tlm.F90:4128-4157); level 1 of pk is the
 // constant top value (:4068-4072).

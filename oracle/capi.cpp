@@ -300,6 +300,25 @@ void orc_dyn_core_nh(void* hv, int mode, double bdt, int n_split, double a_imp, 
   });
 }
 
+// fv_dynamics, non-hydrostatic.  in: u, v, pt (temperature), delp, w, delz, q[nq]   out: the same
+void orc_fv_dynamics_nh(void* hv, int mode, int nq, double bdt, int n_split, int k_split, double a_imp, double p_fac, double scale_z, double** in_t,
+                        double** in_p, double** out_t, double** out_p) {
+  OrcHandle* h = (OrcHandle*)hv; int npz = h->npz;
+  std::vector<int> nk(6 + nq, npz);
+  auto in = mkio(6 + nq, in_t, in_p, nk.data()); auto out = mkio(6 + nq, out_t, out_p, nk.data());
+  NhOpts nh; nh.a_imp = a_imp; nh.p_fac = p_fac; nh.scale_z = scale_z;
+  drive(mode, h->bd, in, out, [&](auto& x, auto& y) {
+    using T = typename std::decay<decltype(x[0].p[0].d[0])>::type;
+    DynState<T> s; s.init(h->bd, npz, nq);
+    NhState<T> n; n.zh.init(h->bd, npz + 1);
+    s.u = x[0]; s.v = x[1]; s.pt = x[2]; s.delp = x[3]; n.w = x[4]; n.delz = x[5];
+    for (int m = 0; m < nq; ++m) s.q[m] = x[6 + m];
+    fv_dynamics_nh(s, n, h->phis, npz, bdt, n_split, k_split, h->o, h->c, h->ptop, h->ak, h->bk, nh, h->g, h->bd);
+    y[0] = s.u; y[1] = s.v; y[2] = s.pt; y[3] = s.delp; y[4] = n.w; y[5] = n.delz;
+    for (int m = 0; m < nq; ++m) y[6 + m] = s.q[m];
+  });
+}
+
 // tracer_2d.  in: dp1, mfx, mfy, cx, cy, q[nq]   out: q[nq]
 void orc_tracer_2d(void* hv, int mode, int nq, double** in_t, double** in_p, double** out_t, double** out_p) {
   OrcHandle* h = (OrcHandle*)hv; int npz = h->npz;

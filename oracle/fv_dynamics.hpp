@@ -18,8 +18,24 @@ struct RemapOpts { int kord_tm = -17, kord_mt = 17, kord_wz = 17, kord_tr = 17; 
 // scalar_profile / cs_profile, iv != -2, |kord| > 16 (fv_mapz_tlm.F90:8424-8509 == :8592-8666)
 template <class T>
 void cs_profile_linear(std::vector<T>& a1, std::vector<T>& a2, std::vector<T>& a3, std::vector<T>& a4,
-                       const std::vector<T>& delp, int km) {
-  std::vector<T> q(km + 2), gam(km + 1);
+                       const std::vector<T>& delp, int km, int iv = 1, T qs = T(0.)) {
+  std::vector<T> q(km + 2), gam(km + 2);
+  if (iv == -2) {      // vertical velocity: lower boundary value qs given (fv_mapz_tlm.F90:8549-8590)
+    gam[2] = T(0.5);
+    q[1] = 1.5 * a1[1];
+    for (int k = 2; k <= km - 1; ++k) {
+      T grat = delp[k - 1] / delp[k];
+      T bet = 2. + grat + grat - gam[k];
+      q[k] = (3. * (a1[k - 1] + a1[k]) - q[k - 1]) / bet;
+      gam[k + 1] = grat / bet;
+    }
+    T grat = delp[km - 1] / delp[km];
+    q[km] = (3. * (a1[km - 1] + a1[km]) - grat * qs - q[km - 1]) / (2. + grat + grat - gam[km]);
+    q[km + 1] = qs;
+    for (int k = km - 1; k >= 1; --k) q[k] = q[k] - gam[k + 1] * q[k + 1];
+    for (int k = 1; k <= km; ++k) { a2[k] = q[k]; a3[k] = q[k + 1]; a4[k] = 3. * (2. * a1[k] - (a2[k] + a3[k])); }
+    return;
+  }
   T grat = delp[2] / delp[1];
   T bet = grat * (grat + 0.5);
   q[1] = ((grat + grat) * (grat + 1.) * a1[1] + a1[2]) / bet;
@@ -45,11 +61,11 @@ void cs_profile_linear(std::vector<T>& a1, std::vector<T>& a2, std::vector<T>& a
 // -> q2 on pe2 (kn layers).  1-based vectors.
 template <class T>
 void map_col(int km, const std::vector<T>& pe1, const std::vector<T>& q1, int kn, const std::vector<T>& pe2,
-             std::vector<T>& q2) {
+             std::vector<T>& q2, int iv = 1, T qs = T(0.)) {
   const double r3 = 1. / 3., r23 = 2. / 3.;
   std::vector<T> dp1(km + 1), a1(km + 1), a2(km + 1), a3(km + 1), a4(km + 1);
   for (int k = 1; k <= km; ++k) { dp1[k] = pe1[k + 1] - pe1[k]; a1[k] = q1[k]; }
-  cs_profile_linear(a1, a2, a3, a4, dp1, km);
+  cs_profile_linear(a1, a2, a3, a4, dp1, km, iv, qs);
   int k0 = 1;
   T qsum = T(0.);
   for (int k = 1; k <= kn; ++k) {
@@ -155,6 +171,37 @@ void tracer_2d(std::vector<Arr3<T>>& q, Arr3<T>& dp1, Arr3<T>& mfx, Arr3<T>& mfy
   }
 }
 
+// winds of Lagrangian_to_Eulerian: u, v on the pressures averaged across the edge (fv_mapz_tlm.F90:1884-1934); pe is still the
+// Lagrangian one here.
+template <class T>
+void l2e_winds(DynState<T>& s, int km, const std::vector<double>& ak, const std::vector<double>& bk, const Bounds& bd) {
+  const int is = bd.is, ie = bd.ie, js = bd.js, je = bd.je;
+  std::vector<T> q1(km + 1), q2(km + 1), pe0(km + 2), pe3(km + 2);
+  for (int j = js; j <= je + 1; ++j) {
+    // map u (:1884-1909)
+    for (int i = is; i <= ie; ++i) {
+      pe0[1] = s.pe(i, j, 1);
+      for (int k = 2; k <= km + 1; ++k) pe0[k] = 0.5 * (s.pe(i, j - 1, k) + s.pe(i, j, k));
+      for (int k = 1; k <= km + 1; ++k) pe3[k] = ak[k - 1] + (0.5 * bk[k - 1]) * (s.pe(i, j - 1, km + 1) + s.pe(i, j, km + 1));
+      for (int k = 1; k <= km; ++k) q1[k] = s.u(i, j, k);
+      map_col(km, pe0, q1, km, pe3, q2);
+      for (int k = 1; k <= km; ++k) s.u(i, j, k) = q2[k];
+    }
+    if (j < je + 1)     // map v (:1913-1934)
+      for (int i = is; i <= ie + 1; ++i) {
+        pe3[1] = T(ak[0]);
+        pe0[1] = s.pe(i, j, 1);
+        for (int k = 2; k <= km + 1; ++k) {
+          pe0[k] = 0.5 * (s.pe(i - 1, j, k) + s.pe(i, j, k));
+          pe3[k] = ak[k - 1] + (0.5 * bk[k - 1]) * (s.pe(i - 1, j, km + 1) + s.pe(i, j, km + 1));
+        }
+        for (int k = 1; k <= km; ++k) q1[k] = s.v(i, j, k);
+        map_col(km, pe0, q1, km, pe3, q2);
+        for (int k = 1; k <= km; ++k) s.v(i, j, k) = q2[k];
+      }
+  }
+}
+
 // Lagrangian_to_Eulerian, hydrostatic, remap_t (fv_mapz_tlm.F90:1586-1951, :2203-2250).
 // pe must be valid on is-1..ie+1, js-1..je+1 (old Lagrangian pressures); sphum = tracer 0.
 template <class T>
@@ -186,28 +233,8 @@ void lagrangian_to_eulerian(bool last_step, DynState<T>& s, int km, double akap,
         for (int k = 1; k <= km + 1; ++k) { s.pk(i, j, k) = pk2[k]; s.peln(i, j, k) = pn2[k]; pe2s(i, j, k) = pe2[k]; }
         for (int k = 1; k <= km; ++k) s.pkz(i, j, k) = (pk2[k + 1] - pk2[k]) / (akap * (pn2[k + 1] - pn2[k]));
       }
-    // map u (:1884-1909)
-    for (int i = is; i <= ie; ++i) {
-      pe0[1] = s.pe(i, j, 1);
-      for (int k = 2; k <= km + 1; ++k) pe0[k] = 0.5 * (s.pe(i, j - 1, k) + s.pe(i, j, k));
-      for (int k = 1; k <= km + 1; ++k) pe3[k] = ak[k - 1] + (0.5 * bk[k - 1]) * (s.pe(i, j - 1, km + 1) + s.pe(i, j, km + 1));
-      for (int k = 1; k <= km; ++k) q1[k] = s.u(i, j, k);
-      map_col(km, pe0, q1, km, pe3, q2);
-      for (int k = 1; k <= km; ++k) s.u(i, j, k) = q2[k];
-    }
-    if (j < je + 1)     // map v (:1913-1934)
-      for (int i = is; i <= ie + 1; ++i) {
-        pe3[1] = T(ak[0]);
-        pe0[1] = s.pe(i, j, 1);
-        for (int k = 2; k <= km + 1; ++k) {
-          pe0[k] = 0.5 * (s.pe(i - 1, j, k) + s.pe(i, j, k));
-          pe3[k] = ak[k - 1] + (0.5 * bk[k - 1]) * (s.pe(i - 1, j, km + 1) + s.pe(i, j, km + 1));
-        }
-        for (int k = 1; k <= km; ++k) q1[k] = s.v(i, j, k);
-        map_col(km, pe0, q1, km, pe3, q2);
-        for (int k = 1; k <= km; ++k) s.v(i, j, k) = q2[k];
-      }
   }
+  l2e_winds(s, km, ak, bk, bd);
   for (int k = 2; k <= km; ++k)      // :1944-1950
     for (int j = js; j <= je; ++j)
       for (int i = is; i <= ie; ++i) s.pe(i, j, k) = pe2s(i, j, k);

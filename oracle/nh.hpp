@@ -378,7 +378,8 @@ struct NhState { Arr3<T> w, delz, zh; };
 // mpp_update_domains.  ak, bk: hybrid coefficients (dp_ref, :1704-1706).
 template <class T>
 void dyn_core_nh(DynState<T>& s, NhState<T>& n, const Arr2<double>& phis, int npz, double bdt, int n_split, const DampOpts& o, const Consts& c,
-                 double ptop, const std::vector<double>& ak, const std::vector<double>& bk, const NhOpts& nh, const Grid& g, const Bounds& bd) {
+                 double ptop, const std::vector<double>& ak, const std::vector<double>& bk, const NhOpts& nh, const Grid& g, const Bounds& bd,
+                 Arr2<T>* ws_out = nullptr) {
   const double dt = bdt / double(n_split), dt2 = 0.5 * dt, rdt = 1. / dt, rgrav = 1. / c.grav;
   std::vector<double> dp_ref(npz + 2);
   for (int k = 1; k <= npz; ++k) dp_ref[k] = ak[k] - ak[k - 1] + (bk[k] - bk[k - 1]) * 1.e5;
@@ -428,6 +429,89 @@ void dyn_core_nh(DynState<T>& s, NhState<T>& n, const Arr2<double>& phis, int np
         for (int i = bd.is - 2; i <= bd.ie + 2; ++i) gz(i, j, k) = n.zh(i, j, k) * c.grav;
     nh_p_grad(s.u, s.v, pkc, gz, s.delp, pk3, dt, ptop, c.akap, npz, g, bd);
     halo_periodic(s.u, bd); halo_periodic(s.v, bd);
+  }
+  if (ws_out) *ws_out = ws;      // surface vertical velocity of the last acoustic step: lower boundary of the w remap
+}
+
+// Lagrangian_to_Eulerian, non-hydrostatic, remap_t (fv_mapz_tlm.F90:1607-1613 density pt -> density T, :1635-1641 delz ->
+// specific volume / g, :1772-1796 w with kord_wz and the surface value ws, delz, :1852-1857 pkz from the equation of state).
+template <class T>
+void lagrangian_to_eulerian_nh(bool last_step, DynState<T>& s, NhState<T>& n, const Arr2<T>& ws, int km, const Consts& c, double ptop,
+                               const std::vector<double>& ak, const std::vector<double>& bk, const Bounds& bd) {
+  const int is = bd.is, ie = bd.ie, js = bd.js, je = bd.je;
+  const int nq = (int)s.q.size();
+  const double akap = c.akap, rrg = -c.rdgas / c.grav, k1k = c.rdgas / (c.cp_air - c.rdgas);
+  Arr3<T> pe2s(bd, km + 1);
+  std::vector<T> pe1(km + 2), pe2(km + 2), pn1(km + 2), pn2(km + 2), pk2(km + 2), q1(km + 1), q2(km + 1);
+  for (int j = js; j <= je; ++j)
+    for (int i = is; i <= ie; ++i) {
+      for (int k = 1; k <= km + 1; ++k) { pe1[k] = s.pe(i, j, k); pn1[k] = s.peln(i, j, k); }
+      pe2[1] = T(ptop); pe2[km + 1] = s.pe(i, j, km + 1);
+      for (int k = 1; k <= km; ++k) {
+        s.pt(i, j, k) = s.pt(i, j, k) * exp(k1k * log(rrg * s.delp(i, j, k) / n.delz(i, j, k) * s.pt(i, j, k)));
+        n.delz(i, j, k) = -(n.delz(i, j, k) / s.delp(i, j, k));
+      }
+      for (int k = 2; k <= km; ++k) pe2[k] = ak[k - 1] + bk[k - 1] * s.pe(i, j, km + 1);
+      for (int k = 1; k <= km; ++k) s.delp(i, j, k) = pe2[k + 1] - pe2[k];
+      pn2[1] = pn1[1]; pn2[km + 1] = pn1[km + 1]; pk2[1] = s.pk(i, j, 1); pk2[km + 1] = s.pk(i, j, km + 1);
+      for (int k = 2; k <= km; ++k) { pn2[k] = log(pe2[k]); pk2[k] = exp(akap * pn2[k]); }
+      for (int k = 1; k <= km; ++k) q1[k] = s.pt(i, j, k);
+      map_col(km, pn1, q1, km, pn2, q2);
+      for (int k = 1; k <= km; ++k) s.pt(i, j, k) = q2[k];
+      for (int iq = 0; iq < nq; ++iq) {
+        for (int k = 1; k <= km; ++k) q1[k] = s.q[iq](i, j, k);
+        map_col(km, pe1, q1, km, pe2, q2);
+        for (int k = 1; k <= km; ++k) s.q[iq](i, j, k) = q2[k];
+      }
+      for (int k = 1; k <= km; ++k) q1[k] = n.w(i, j, k);
+      map_col(km, pe1, q1, km, pe2, q2, -2, ws(i, j));
+      for (int k = 1; k <= km; ++k) n.w(i, j, k) = q2[k];
+      for (int k = 1; k <= km; ++k) q1[k] = n.delz(i, j, k);
+      map_col(km, pe1, q1, km, pe2, q2);
+      for (int k = 1; k <= km; ++k) n.delz(i, j, k) = -(q2[k] * s.delp(i, j, k));
+      for (int k = 1; k <= km + 1; ++k) { s.pk(i, j, k) = pk2[k]; s.peln(i, j, k) = pn2[k]; pe2s(i, j, k) = pe2[k]; }
+      for (int k = 1; k <= km; ++k) s.pkz(i, j, k) = exp(akap * log(rrg * s.delp(i, j, k) / n.delz(i, j, k) * s.pt(i, j, k)));
+    }
+  l2e_winds(s, km, ak, bk, bd);
+  for (int k = 2; k <= km; ++k)
+    for (int j = js; j <= je; ++j)
+      for (int i = is; i <= ie; ++i) s.pe(i, j, k) = pe2s(i, j, k);
+  for (int k = 1; k <= km; ++k)
+    for (int j = js; j <= je; ++j)
+      for (int i = is; i <= ie; ++i) {
+        if (last_step) s.pt(i, j, k) = s.pt(i, j, k) / (1. + c.zvir * (nq > 0 ? s.q[0](i, j, k) : T(0.)));
+        else           s.pt(i, j, k) = s.pt(i, j, k) / s.pkz(i, j, k);
+      }
+}
+
+// fv_dynamics, non-hydrostatic, moist_phys = .true. (fv_dynamics_tlm.F90:443-466 pkz from the equation of state, :582-590 pt ->
+// virtual potential temperature, :646-860 k_split loop).  On entry pt is temperature; w, delz given.
+template <class T>
+void fv_dynamics_nh(DynState<T>& s, NhState<T>& n, const Arr2<double>& phis, int npz, double bdt, int n_split, int k_split, const DampOpts& o,
+                    const Consts& c, double ptop, const std::vector<double>& ak, const std::vector<double>& bk, const NhOpts& nh, const Grid& g,
+                    const Bounds& bd) {
+  const int nq = (int)s.q.size();
+  const double rdg = -c.rdgas / c.grav;
+  Arr3<T> dp1(bd, npz);
+  Arr2<T> ws(bd);
+  for (int k = 1; k <= npz; ++k)
+    for (int j = bd.js; j <= bd.je; ++j)
+      for (int i = bd.is; i <= bd.ie; ++i) {
+        T d = (nq > 0) ? c.zvir * s.q[0](i, j, k) : T(0.);
+        s.pkz(i, j, k) = exp(c.akap * log(rdg * s.delp(i, j, k) * s.pt(i, j, k) * (1. + d) / n.delz(i, j, k)));
+        s.pt(i, j, k) = s.pt(i, j, k) * (1. + d) / s.pkz(i, j, k);
+      }
+  const double mdt = bdt / double(k_split);
+  for (int n_map = 1; n_map <= k_split; ++n_map) {
+    halo_periodic(s.delp, bd); halo_periodic(s.pt, bd); halo_periodic(s.u, bd); halo_periodic(s.v, bd);
+    for (int k = 1; k <= npz; ++k) dp1.plane(k) = s.delp.plane(k);
+    const bool last_step = (n_map == k_split);
+    dyn_core_nh(s, n, phis, npz, mdt, n_split, o, c, ptop, ak, bk, nh, g, bd, &ws);
+    if (nq > 0) {
+      for (auto& qq : s.q) halo_periodic(qq, bd);
+      tracer_2d(s.q, dp1, s.mfx, s.mfy, s.cx, s.cy, npz, o.hord_tr, g, bd);
+    }
+    if (npz > 4) lagrangian_to_eulerian_nh(last_step, s, n, ws, npz, c, ptop, ak, bk, bd);
   }
 }
 

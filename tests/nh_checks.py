@@ -13,6 +13,7 @@ OUTS = ["u", "v", "pt", "delp", "w", "delz", "pe", "peln", "pk", "zh"]
 def put(c, T, P=None):
     for n in ("mfx", "mfy", "cx", "cy", "pkz"):      # accumulators / leftovers of an earlier sweep: no adjoint comes in through them here
         c.dy.put(n, np.zeros((1, c.npz, c.ny + 7, c.nx + 7)), 1)
+    c.dy.put("ws", np.zeros((1, 1, c.ny + 7, c.nx + 7)), 1)
     for n, t in zip(INS, T):
         c.dy.put(n, t[None], 0)
     if P is not None:
@@ -72,4 +73,74 @@ def check_nh_dot_product(c, tol=1e-11):
     rhs = 0.0
     for n, p in zip(INS, P):
         rhs += float(np.sum(c.dy.get(n, 1)[0] * p))      # the halos of u, v, pt, delp are read as given: independent inputs
+    assert abs(lhs - rhs) <= tol * abs(lhs), (lhs, rhs)
+
+
+# ---- whole time step (fv_dynamics: pkz from the equation of state, k_split x (acoustic steps, tracers, vertical remap))
+def fv_names(c):
+    return ["u", "v", "pt", "delp", "w", "delz"] + ["q%d" % (n + 1) for n in range(c.nq)]
+
+
+def fv_put(c, T, P=None):
+    for n, t in zip(fv_names(c), T):
+        c.dy.put(n, t[None], 0)
+        c.dy.put(n, (P[fv_names(c).index(n)] if P is not None else np.zeros_like(t))[None], 1)
+
+
+def fv_dom(c, n):
+    return c.rect(1, c.nx, 1, c.ny + 1) if n == "u" else c.rect(1, c.nx + 1, 1, c.ny) if n == "v" else c.rect(1, c.nx, 1, c.ny)
+
+
+def check_nh_fv_tangent(c, tol_traj=1e-10, tol=1e-8):
+    from test_oracle_nh import nh_state_fv
+    T, P = nh_state_fv(c)
+    ot, op = c.oracle.fv_dynamics_nh(TL, c.nq, c.dims.dt, c.dims.n_split, c.dims.k_split, T, P)
+    fv_put(c, T, P)
+    c.dy.fv_dynamics(TL)
+    for n, a, b in zip(fv_names(c), ot, op):
+        A = fv_dom(c, n)
+        e1, e2 = relerr(c.dy.get(n, 0)[0][A], a[A]), relerr(c.dy.get(n, 1)[0][A], b[A])
+        assert e1 < tol_traj, (n, "traj", e1)
+        assert e2 < tol, (n, "tl", e2)
+
+
+def fv_seeds(c, rng, like):
+    seeds = []
+    for n, y in zip(fv_names(c), like):
+        s = np.zeros_like(y)
+        A = fv_dom(c, n)
+        s[A] = rng.standard_normal(y[A].shape)
+        seeds.append(s)
+    return seeds
+
+
+def check_nh_fv_adjoint(c, tol=1e-8):
+    from test_oracle_nh import nh_state_fv
+    T, P = nh_state_fv(c)
+    seeds = fv_seeds(c, np.random.default_rng(13), T)
+    _, iad = c.oracle.fv_dynamics_nh(AD, c.nq, c.dims.dt, c.dims.n_split, c.dims.k_split, T, None, seeds)
+    fv_put(c, T)
+    c.dy.fv_dynamics(NL)
+    for n, s in zip(fv_names(c), seeds):
+        c.dy.put(n, s[None], 1)
+    c.dy.fv_dynamics(AD)
+    for n, a in zip(fv_names(c), iad):
+        e = relerr(c.dy.get(n, 1)[0], a)
+        assert e < tol, (n, "ad", e)
+
+
+def check_nh_fv_dot_product(c, tol=1e-11):
+    from test_oracle_nh import nh_state_fv
+    T, P = nh_state_fv(c)
+    fv_put(c, T, P)
+    c.dy.fv_dynamics(TL)
+    y = {n: c.dy.get(n, 1)[0].copy() for n in fv_names(c)}
+    lhs = sum(float(np.sum(y[n][fv_dom(c, n)] ** 2)) for n in fv_names(c))
+    fv_put(c, T)
+    c.dy.fv_dynamics(NL)
+    for n in fv_names(c):
+        s = np.zeros_like(y[n]); A = fv_dom(c, n); s[A] = y[n][A]
+        c.dy.put(n, s[None], 1)
+    c.dy.fv_dynamics(AD)
+    rhs = sum(float(np.sum(c.dy.get(n, 1)[0] * p)) for n, p in zip(fv_names(c), P))
     assert abs(lhs - rhs) <= tol * abs(lhs), (lhs, rhs)

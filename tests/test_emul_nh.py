@@ -20,3 +20,20 @@ def test_nh_dyn_core_adjoint_matches_oracle(nhc):
 
 def test_nh_dot_product(nhc):
     N.check_nh_dot_product(nhc)
+
+
+@pytest.fixture(scope="module")
+def nhfv():
+    return Case(nx=10, ny=8, npz=8, n_split=2, k_split=2, dt=1200.0, nq=2, backend="emul", hord_ks_traj=0, hord_ks_pert=0, hydrostatic=0)
+
+
+def test_nh_fv_dynamics_tangent_matches_oracle(nhfv):
+    N.check_nh_fv_tangent(nhfv)
+
+
+def test_nh_fv_dynamics_adjoint_matches_oracle(nhfv):
+    N.check_nh_fv_adjoint(nhfv)
+
+
+def test_nh_fv_dynamics_dot_product(nhfv):
+    N.check_nh_fv_dot_product(nhfv)

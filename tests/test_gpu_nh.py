@@ -30,3 +30,29 @@ def test_nh_dot_product_c48l72():
     from common import Case
     c = Case(nx=48, ny=48, npz=72, n_split=3, dt=300.0, backend="hip", oracle=False, hord_ks_traj=0, hord_ks_pert=0, hydrostatic=0)
     N.check_nh_dot_product(c)
+
+
+@pytest.fixture(scope="module")
+def nhfv():
+    from common import Case
+    return Case(nx=10, ny=8, npz=8, n_split=2, k_split=2, dt=1200.0, nq=2, backend="hip", hord_ks_traj=0, hord_ks_pert=0, hydrostatic=0)
+
+
+def test_nh_fv_dynamics_tangent_matches_oracle(nhfv):
+    N.check_nh_fv_tangent(nhfv)
+
+
+def test_nh_fv_dynamics_adjoint_matches_oracle(nhfv):
+    N.check_nh_fv_adjoint(nhfv)
+
+
+def test_nh_fv_dynamics_dot_product(nhfv):
+    N.check_nh_fv_dot_product(nhfv)
+
+
+def test_nh_fv_dynamics_dot_product_c48l72():
+    """whole non-hydrostatic step at BASELINE config-2 size (k_split 2, n_split 3, 3 tracers): dot-product identity, no oracle"""
+    from common import Case
+    c = Case(nx=48, ny=48, npz=72, n_split=3, k_split=2, dt=600.0, nq=3, backend="hip", oracle=False, hord_ks_traj=0, hord_ks_pert=0,
+             hydrostatic=0)
+    N.check_nh_fv_dot_product(c)

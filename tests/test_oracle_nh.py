@@ -25,6 +25,21 @@ def nh_state(c, seed=5):
     return T, P
 
 
+def nh_state_fv(c, seed=5):
+    """fv_dynamics-level state: pt is temperature; delz hydrostatically balanced for T_v; tracers from the case"""
+    o = c.opt
+    delp = c.traj["delp"][0]
+    pe = np.concatenate([np.full_like(delp[:1], o.ptop), o.ptop + np.cumsum(delp, axis=0)], axis=0)
+    qv = c.qtraj[0][0] if c.nq > 0 else 0.0
+    pkz = np.diff(pe ** o.akap, axis=0) / (o.akap * np.diff(np.log(pe), axis=0))
+    tt = c.traj["pt"][0] * pkz / (1.0 + o.zvir * qv)          # the case's pt is theta_v; the time step takes temperature
+    delz = -(o.rdgas / o.grav) * tt * (1.0 + o.zvir * qv) * np.diff(np.log(pe), axis=0)
+    T0, P0 = nh_state(c, seed)
+    T = [c.traj["u"][0], c.traj["v"][0], tt, delp, T0[4], delz] + [q[0] for q in c.qtraj]
+    P = P0[:2] + [20.0 * P0[2]] + P0[3:6] + [q[0] for q in c.qpert]
+    return T, P
+
+
 @pytest.fixture(scope="module")
 def nhcase():
     return Case(nx=10, ny=8, npz=8, n_split=2, dt=600.0, backend="none", hord_ks_traj=0, hord_ks_pert=0)
@@ -78,4 +93,45 @@ def test_nh_adjoint_dot_product(nhcase):
     _, ad = c.oracle.dyn_core_nh(AD, c.dims.dt, c.dims.n_split, T, None, seeds)
     lhs = sum(float(np.sum(a * s)) for a, s in zip(tl, seeds))
     rhs = sum(float(np.sum(a * p)) for a, p in zip(ad, P))
+    assert abs(lhs - rhs) <= 1e-10 * abs(lhs), (lhs, rhs)
+
+
+@pytest.fixture(scope="module")
+def nhcase_fv():
+    return Case(nx=10, ny=8, npz=8, n_split=2, k_split=2, dt=1200.0, nq=2, backend="none", hord_ks_traj=0, hord_ks_pert=0, do_vort_damp=0,
+                do_vort_damp_pert=0)
+
+
+def test_nh_fv_dynamics_tangent_matches_finite_differences(nhcase_fv):
+    """whole non-hydrostatic time step (pkz from the equation of state, k_split x (acoustic steps, tracers, remap of T, w, delz))"""
+    c = nhcase_fv
+    T, P = nh_state_fv(c)
+    a = (c.nq, c.dims.dt, c.dims.n_split, c.dims.k_split)
+    nl, tl = c.oracle.fv_dynamics_nh(TL, *a, T, P)
+    A = c.rect(1, c.nx, 1, c.ny)
+    assert np.max(np.abs(nl[5][A] / T[5][A] - 1.0)) < 0.25          # layer thickness: remapped to the reference levels, changes moderately
+    eps = 1e-6
+    up, _ = c.oracle.fv_dynamics_nh(NL, *a, [t + eps * p for t, p in zip(T, P)])
+    dn, _ = c.oracle.fv_dynamics_nh(NL, *a, [t - eps * p for t, p in zip(T, P)])
+    for n in range(len(T)):
+        fd = (up[n][A] - dn[n][A]) / (2 * eps)
+        scale = max(1e-30, np.max(np.abs(tl[n][A])))
+        assert np.max(np.abs(fd - tl[n][A])) / scale < 5e-5, n
+
+
+def test_nh_fv_dynamics_adjoint_dot_product(nhcase_fv):
+    c = nhcase_fv
+    T, P = nh_state_fv(c)
+    a = (c.nq, c.dims.dt, c.dims.n_split, c.dims.k_split)
+    _, tl = c.oracle.fv_dynamics_nh(TL, *a, T, P)
+    rng = np.random.default_rng(9)
+    A = c.rect(1, c.nx, 1, c.ny)
+    seeds = []
+    for y in tl:
+        s = np.zeros_like(y)
+        s[A] = rng.standard_normal(y[A].shape) / max(1e-30, np.max(np.abs(y[A])))
+        seeds.append(s)
+    _, ad = c.oracle.fv_dynamics_nh(AD, *a, T, None, seeds)
+    lhs = sum(float(np.sum(y * s)) for y, s in zip(tl, seeds))
+    rhs = sum(float(np.sum(x * p)) for x, p in zip(ad, P))
     assert abs(lhs - rhs) <= 1e-10 * abs(lhs), (lhs, rhs)
