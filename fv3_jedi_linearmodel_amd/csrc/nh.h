@@ -419,7 +419,8 @@ struct NhColFn {
   HD void operator()(int i, int j, int zz) const {
     const int z = zz + z0;
     if (kind == NHC_RING && skip.has(i, j)) return;
-    if (a.g.face && (i < 1 || i > a.g.nx) && (j < 1 || j > a.g.ny)) return;   // corner-halo columns hold no data
+    // corner-halo columns of a face hold no data (cell-centred operators; the flux points of NHC_EDGE all touch a valid cell)
+    if (kind != NHC_EDGE && a.g.face && (i < 1 || i > a.g.nx) && (j < 1 || j > a.g.ny)) return;
     const size_t col = (size_t)z * a.g.plane + a.g.idx(i, j);
     const ColWs ws{a.ws + col, a.ws_stride, a.g.npz + 2};
     const double hs = a.hs ? a.hs[col] : 0.;

@@ -450,4 +450,28 @@ void orc_cube_fv_dynamics(void* cv, int mode, int nq, double bdt, int n_split, i
   });
 }
 
+// six faces, non-hydrostatic.  in / out: u, v, pt (temperature), delp, w, delz, q[nq]
+void orc_cube_fv_dynamics_nh(void* cv, int mode, int nq, double bdt, int n_split, int k_split, double a_imp, double p_fac, double scale_z,
+                             double** in_t, double** in_p, double** out_t, double** out_p) {
+  OrcCube* c = (OrcCube*)cv; OrcHandle* h = c->f[0]; const int npz = h->npz;
+  const size_t np = (size_t)h->bd.pi() * h->bd.pj();
+  std::vector<int> nk(6 + nq, npz);
+  auto in = mkio6(6 + nq, in_t, in_p, nk.data(), np); auto out = mkio6(6 + nq, out_t, out_p, nk.data(), np);
+  NhOpts nh; nh.a_imp = a_imp; nh.p_fac = p_fac; nh.scale_z = scale_z;
+  drive(mode, h->bd, in, out, [&](auto& x, auto& y) {
+    using T = typename std::decay<decltype(x[0].p[0].d[0])>::type;
+    std::vector<DynState<T>> S(6); std::vector<NhState<T>> N(6);
+    for (int t = 0; t < 6; ++t) {
+      DynState<T>& s = S[t]; s.init(h->bd, npz, nq); N[t].zh.init(h->bd, npz + 1);
+      s.u = x[0 * 6 + t]; s.v = x[1 * 6 + t]; s.pt = x[2 * 6 + t]; s.delp = x[3 * 6 + t]; N[t].w = x[4 * 6 + t]; N[t].delz = x[5 * 6 + t];
+      for (int n = 0; n < nq; ++n) s.q[n] = x[(6 + n) * 6 + t];
+    }
+    fv_dynamics_nh_cube(S, N, c->phis, npz, bdt, n_split, k_split, h->o, h->c, h->ptop, h->ak, h->bk, nh, c->G, h->bd, c->X);
+    for (int t = 0; t < 6; ++t) {
+      y[0 * 6 + t] = S[t].u; y[1 * 6 + t] = S[t].v; y[2 * 6 + t] = S[t].pt; y[3 * 6 + t] = S[t].delp; y[4 * 6 + t] = N[t].w; y[5 * 6 + t] = N[t].delz;
+      for (int n = 0; n < nq; ++n) y[(6 + n) * 6 + t] = S[t].q[n];
+    }
+  });
+}
+
 }  // extern "C"

@@ -8,7 +8,7 @@
 // Path restated: a_imp in (0.5, 0.999] (default 0.75): SIM_SOLVER in RIEM_SOLVER3, SIM1_SOLVER in RIEM_SOLVER_C;
 // use_logp = .false., beta = 0, d_con = 0, do_f3d = .false., not nested.  "Parity unpinned" like the rest of the path.
 #pragma once
-#include "dyn_core.hpp"
+#include "cube.hpp"
 
 namespace orc {
 
@@ -512,6 +512,121 @@ void fv_dynamics_nh(DynState<T>& s, NhState<T>& n, const Arr2<double>& phis, int
       tracer_2d(s.q, dp1, s.mfx, s.mfy, s.cx, s.cy, npz, o.hord_tr, g, bd);
     }
     if (npz > 4) lagrangian_to_eulerian_nh(last_step, s, n, ws, npz, c, ptop, ak, bk, bd);
+  }
+}
+
+// ---- six faces (cube.hpp): the same per-face routines between the halo exchanges of the non-hydrostatic flow
+// (dyn_core_tlm.F90:1771-1773 w, :1800-1802 gz, :2210-2216 zh and pkc, :2432-2434 u, v).
+template <class T>
+void dyn_core_nh_cube(std::vector<DynState<T>>& S, std::vector<NhState<T>>& N, const std::vector<Arr2<double>>& phis, int npz, double bdt,
+                      int n_split, const DampOpts& o, const Consts& c, double ptop, const std::vector<double>& ak, const std::vector<double>& bk,
+                      const NhOpts& nh, const std::vector<Grid>& G, const Bounds& bd, const CubeTables& X, std::vector<Arr2<T>>* ws_out = nullptr) {
+  const int nt = (int)S.size();
+  const double dt = bdt / double(n_split), dt2 = 0.5 * dt, rdt = 1. / dt, rgrav = 1. / c.grav;
+  const std::vector<Arr3<T>*> none;
+  std::vector<double> dp_ref(npz + 2);
+  for (int k = 1; k <= npz; ++k) dp_ref[k] = ak[k] - ak[k - 1] + (bk[k] - bk[k - 1]) * 1.e5;
+  std::vector<Arr2<double>> zs(nt, Arr2<double>(bd));
+  for (int t = 0; t < nt; ++t)
+    for (int j = bd.jsd; j <= bd.jed; ++j) for (int i = bd.isd; i <= bd.ied; ++i) zs[t](i, j) = phis[t](i, j) * rgrav;
+  auto mk = [&](int nk) { return std::vector<Arr3<T>>(nt, Arr3<T>(bd, nk)); };
+  auto gz = mk(npz + 1), pkc = mk(npz + 1), pk3 = mk(npz + 1), ptc = mk(npz), delpc = mk(npz), uc = mk(npz), vc = mk(npz), ua = mk(npz), va = mk(npz),
+       ut = mk(npz), vt = mk(npz), divgd = mk(npz), crx = mk(npz), cry = mk(npz), xfx = mk(npz), yfx = mk(npz), wc = mk(npz);
+  std::vector<Arr2<T>> ws3(nt, Arr2<T>(bd)), ws(nt, Arr2<T>(bd));
+  auto fld = [&](Arr3<T> NhState<T>::*m) { std::vector<Arr3<T>*> v; for (auto& n : N) v.push_back(&(n.*m)); return v; };
+  for (auto& s : S)
+    for (int k = 1; k <= npz; ++k) { s.mfx.plane(k).fill(T(0.)); s.mfy.plane(k).fill(T(0.)); s.cx.plane(k).fill(T(0.)); s.cy.plane(k).fill(T(0.)); }
+  std::vector<int> ndif(npz + 2); std::vector<double> dampv(npz + 2);
+  for (int k = 1; k <= npz; ++k) { LevelParams lp; level_params(o, k, npz, lp); ndif[k] = lp.nord_v; dampv[k] = lp.damp_vt; }
+  for (int it = 1; it <= n_split; ++it) {
+    const bool remap_step = (it == n_split);
+    exchange(X.rows[X_CELL], fld(&NhState<T>::w), none);
+    if (it == 1) {
+      for (int t = 0; t < nt; ++t)
+        for (int j = bd.js; j <= bd.je; ++j)
+          for (int i = bd.is; i <= bd.ie; ++i) {
+            gz[t](i, j, npz + 1) = T(zs[t](i, j));
+            for (int k = npz; k >= 1; --k) gz[t](i, j, k) = gz[t](i, j, k + 1) - N[t].delz(i, j, k);
+          }
+      exchange(X.rows[X_CELL], ptrs(gz), none);
+    }
+    for (int t = 0; t < nt; ++t)
+      for (int k = 1; k <= npz; ++k)
+        c_sw(delpc[t].plane(k), S[t].delp.plane(k), ptc[t].plane(k), S[t].pt.plane(k), S[t].u.plane(k), S[t].v.plane(k), uc[t].plane(k),
+             vc[t].plane(k), ua[t].plane(k), va[t].plane(k), ut[t].plane(k), vt[t].plane(k), divgd[t].plane(k), o.nord, dt2, G[t], bd,
+             &N[t].w.plane(k), &wc[t].plane(k));
+    if (o.nord > 0) exchange(X.rows[X_CORNER], ptrs(divgd), none);
+    for (int t = 0; t < nt; ++t) {
+      if (it == 1) N[t].zh = gz[t]; else gz[t] = N[t].zh;
+      update_dz_c(npz, dt2, dp_ref, zs[t], ut[t], vt[t], gz[t], ws3[t], G[t], bd);
+      riem_solver_c(dt2, npz, c.akap, ptop, phis[t], wc[t], ptc[t], delpc[t], gz[t], pkc[t], ws3[t], c, nh, bd);
+      p_grad_c_nh(dt2, npz, delpc[t], pkc[t], gz[t], uc[t], vc[t], G[t], bd);
+    }
+    exchange(X.rows[X_CVEC], ptrs(uc), ptrs(vc));
+    for (int t = 0; t < nt; ++t)
+      for (int k = 1; k <= npz; ++k) {
+        LevelParams lp;
+        if (!level_params(o, k, npz, lp)) { std::fprintf(stderr, "oracle: split hord at level %d not restated\n", k); std::abort(); }
+        d_sw(S[t].delp.plane(k), S[t].pt.plane(k), S[t].u.plane(k), S[t].v.plane(k), uc[t].plane(k), vc[t].plane(k), ua[t].plane(k),
+             va[t].plane(k), divgd[t].plane(k), S[t].mfx.plane(k), S[t].mfy.plane(k), S[t].cx.plane(k), S[t].cy.plane(k), crx[t].plane(k),
+             cry[t].plane(k), xfx[t].plane(k), yfx[t].plane(k), dt, lp, o.dddmp, o.d4_bg, G[t], bd, &N[t].w.plane(k));
+      }
+    exchange(X.rows[X_CELL], per_tile(S, [](DynState<T>& s) -> Arr3<T>& { return s.delp; }), none);
+    exchange(X.rows[X_CELL], per_tile(S, [](DynState<T>& s) -> Arr3<T>& { return s.pt; }), none);
+    for (int t = 0; t < nt; ++t) {
+      update_dz_d(ndif, dampv, o.hord_tm, npz, dp_ref, zs[t], N[t].zh, crx[t], cry[t], xfx[t], yfx[t], ws[t], rdt, G[t], bd);
+      riem_solver3(dt, npz, c.akap, ptop, zs[t], N[t].w, N[t].delz, S[t].pt, S[t].delp, N[t].zh, S[t].pe, pkc[t], pk3[t], S[t].pk, S[t].peln, ws[t],
+                   remap_step, c, nh, bd);
+    }
+    exchange(X.rows[X_CELL], fld(&NhState<T>::zh), none);
+    exchange(X.rows[X_CELL], ptrs(pkc), none);
+    for (int t = 0; t < nt; ++t) {
+      if (remap_step) pe_halo(npz, ptop, S[t].pe, S[t].delp, bd);
+      pk3_halo(npz, ptop, c.akap, pk3[t], S[t].delp, bd);
+      for (int k = 1; k <= npz + 1; ++k)
+        for (int j = bd.js - 2; j <= bd.je + 2; ++j)
+          for (int i = bd.is - 2; i <= bd.ie + 2; ++i) gz[t](i, j, k) = N[t].zh(i, j, k) * c.grav;
+      nh_p_grad(S[t].u, S[t].v, pkc[t], gz[t], S[t].delp, pk3[t], dt, ptop, c.akap, npz, G[t], bd);
+    }
+    auto us = per_tile(S, [](DynState<T>& s) -> Arr3<T>& { return s.u; }), vs = per_tile(S, [](DynState<T>& s) -> Arr3<T>& { return s.v; });
+    if (it == n_split) exchange(X.rows[X_DEDGE], us, vs); else exchange(X.rows[X_DVEC], us, vs);
+  }
+  if (ws_out) *ws_out = ws;
+}
+
+template <class T>
+void fv_dynamics_nh_cube(std::vector<DynState<T>>& S, std::vector<NhState<T>>& N, const std::vector<Arr2<double>>& phis, int npz, double bdt,
+                         int n_split, int k_split, const DampOpts& o, const Consts& c, double ptop, const std::vector<double>& ak,
+                         const std::vector<double>& bk, const NhOpts& nh, const std::vector<Grid>& G, const Bounds& bd, const CubeTables& X) {
+  const int nt = (int)S.size(), nq = (int)S[0].q.size();
+  const std::vector<Arr3<T>*> none;
+  const double rdg = -c.rdgas / c.grav;
+  std::vector<Arr3<T>> dp1(nt, Arr3<T>(bd, npz));
+  std::vector<Arr2<T>> ws;
+  for (int t = 0; t < nt; ++t)
+    for (int k = 1; k <= npz; ++k)
+      for (int j = bd.js; j <= bd.je; ++j)
+        for (int i = bd.is; i <= bd.ie; ++i) {
+          DynState<T>& s = S[t];
+          T d = (nq > 0) ? c.zvir * s.q[0](i, j, k) : T(0.);
+          s.pkz(i, j, k) = exp(c.akap * log(rdg * s.delp(i, j, k) * s.pt(i, j, k) * (1. + d) / N[t].delz(i, j, k)));
+          s.pt(i, j, k) = s.pt(i, j, k) * (1. + d) / s.pkz(i, j, k);
+        }
+  const double mdt = bdt / double(k_split);
+  for (int n_map = 1; n_map <= k_split; ++n_map) {
+    exchange(X.rows[X_DVEC], per_tile(S, [](DynState<T>& s) -> Arr3<T>& { return s.u; }), per_tile(S, [](DynState<T>& s) -> Arr3<T>& { return s.v; }));
+    exchange(X.rows[X_CELL], per_tile(S, [](DynState<T>& s) -> Arr3<T>& { return s.delp; }), none);
+    exchange(X.rows[X_CELL], per_tile(S, [](DynState<T>& s) -> Arr3<T>& { return s.pt; }), none);
+    for (int t = 0; t < nt; ++t) for (int k = 1; k <= npz; ++k) dp1[t].plane(k) = S[t].delp.plane(k);
+    dyn_core_nh_cube(S, N, phis, npz, mdt, n_split, o, c, ptop, ak, bk, nh, G, bd, X, &ws);
+    if (nq > 0) {
+      for (int n = 0; n < nq; ++n) {
+        std::vector<Arr3<T>*> qs; for (auto& s : S) qs.push_back(&s.q[n]);
+        exchange(X.rows[X_CELL], qs, none);
+      }
+      tracer_2d_cube(S, dp1, npz, o.hord_tr, G, bd, X);
+    }
+    if (npz > 4) for (int t = 0; t < nt; ++t) lagrangian_to_eulerian_nh(n_map == k_split, S[t], N[t], ws[t], npz, c, ptop, ak, bk, bd);
   }
 }
 

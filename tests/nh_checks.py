@@ -144,3 +144,70 @@ def check_nh_fv_dot_product(c, tol=1e-11):
     c.dy.fv_dynamics(AD)
     rhs = sum(float(np.sum(c.dy.get(n, 1)[0] * p)) for n, p in zip(fv_names(c), P))
     assert abs(lhs - rhs) <= tol * abs(lhs), (lhs, rhs)
+
+
+# ---- six faces (tests/common.py CubeCase, oracle/nh.hpp fv_dynamics_nh_cube)
+def cube_nh_state(c):
+    from groups import cube_step_state
+    from fv3_jedi_linearmodel_amd import cube
+    T0, P0 = cube_step_state(c)
+    o = c.opt
+    qv = c.qtraj[0] if c.nq else 0.0
+    delz = -(o.rdgas / o.grav) * T0["pt"] * (1.0 + o.zvir * qv) * np.diff(T0["peln"], axis=1)
+    aux = cube.cube_fields(c.n, c.npz, c.geo, 20250135, "pert")
+    aux2 = cube.cube_fields(c.n, c.npz, c.geo, 20250136, "pert")
+    w = 0.05 * aux["pt"]; w_p = 0.01 * aux2["pt"]; dz_p = 1e-3 * aux2["delp"]
+    names = ["u", "v", "pt", "delp"]
+    T = [T0[n] for n in names] + [w, delz] + [T0["q%d" % (n + 1)] for n in range(c.nq)]
+    P = [P0[n] for n in names] + [w_p, dz_p] + [P0["q%d" % (n + 1)] for n in range(c.nq)]
+    return T, P
+
+
+def cube_put(c, T, P=None):
+    for n, t in zip(fv_names(c), T):
+        c.dy.put(n, t, 0)
+        c.dy.put(n, P[fv_names(c).index(n)] if P is not None else np.zeros_like(t), 1)
+
+
+def cube_check_nh_fv(c, mode, tol_traj=1e-10, tol=1e-8):
+    T, P = cube_nh_state(c)
+    a = (c.nq, c.dims.dt, c.dims.n_split, c.dims.k_split)
+    if mode == TL:
+        ot, op = c.oracle.fv_dynamics_nh(TL, *a, T, P)
+        cube_put(c, T, P)
+        c.dy.fv_dynamics(TL)
+        for n, x, y in zip(fv_names(c), ot, op):
+            A = fv_dom(c, n)
+            e1, e2 = relerr(c.dy.get(n, 0)[A], x[A]), relerr(c.dy.get(n, 1)[A], y[A])
+            assert e1 < tol_traj, (n, "traj", e1)
+            assert e2 < tol, (n, "tl", e2)
+        return
+    seeds = fv_seeds(c, np.random.default_rng(17), T)
+    _, iad = c.oracle.fv_dynamics_nh(AD, *a, T, None, seeds)
+    cube_put(c, T)
+    c.dy.fv_dynamics(NL)
+    for n, s in zip(fv_names(c), seeds):
+        c.dy.put(n, s, 1)
+    c.dy.fv_dynamics(AD)
+    for n, x in zip(fv_names(c), iad):
+        e = relerr(c.dy.get(n, 1), x)
+        assert e < tol, (n, "ad", e)
+
+
+def cube_check_nh_dot_product(c, tol=1e-11):
+    T, P = cube_nh_state(c)
+    dx = []
+    for n, p in zip(fv_names(c), P):           # the halos are overwritten by the exchange: perturb the compute domain only
+        s = np.zeros_like(p); A = fv_dom(c, n); s[A] = p[A]; dx.append(s)
+    cube_put(c, T, dx)
+    c.dy.fv_dynamics(TL)
+    y = {n: c.dy.get(n, 1).copy() for n in fv_names(c)}
+    lhs = sum(float(np.sum(y[n][fv_dom(c, n)] ** 2)) for n in fv_names(c))
+    cube_put(c, T)
+    c.dy.fv_dynamics(NL)
+    for n in fv_names(c):
+        s = np.zeros_like(y[n]); A = fv_dom(c, n); s[A] = y[n][A]
+        c.dy.put(n, s, 1)
+    c.dy.fv_dynamics(AD)
+    rhs = sum(float(np.sum(c.dy.get(n, 1) * p)) for n, p in zip(fv_names(c), dx))
+    assert abs(lhs - rhs) <= tol * abs(lhs), (lhs, rhs)

@@ -180,3 +180,7 @@ class CubeOracle:
     def fv_dynamics(self, mode, nq, bdt, n_split, k_split, ins, ins_p=None, outs_p=None):
         return self._call("orc_cube_fv_dynamics", mode, [C.c_int(nq), C.c_double(bdt), C.c_int(n_split), C.c_int(k_split)], ins, ins_p,
                           [self.npz] * (4 + nq), outs_p)
+
+    def fv_dynamics_nh(self, mode, nq, bdt, n_split, k_split, ins, ins_p=None, outs_p=None, a_imp=0.75, p_fac=0.05, scale_z=0.0):
+        return self._call("orc_cube_fv_dynamics_nh", mode, [C.c_int(nq), C.c_double(bdt), C.c_int(n_split), C.c_int(k_split), C.c_double(a_imp),
+                                                            C.c_double(p_fac), C.c_double(scale_z)], ins, ins_p, [self.npz] * (6 + nq), outs_p)

@@ -37,3 +37,23 @@ def test_nh_fv_dynamics_adjoint_matches_oracle(nhfv):
 
 def test_nh_fv_dynamics_dot_product(nhfv):
     N.check_nh_fv_dot_product(nhfv)
+
+
+@pytest.fixture(scope="module")
+def nhcube():
+    from common import CubeCase
+    return CubeCase(n=12, npz=6, n_split=2, k_split=2, dt=1200.0, nq=2, backend="emul", oracle=True, hord_ks_traj=0, hord_ks_pert=0, hydrostatic=0)
+
+
+def test_nh_cube_tangent_matches_oracle(nhcube):
+    from oracle import TL
+    N.cube_check_nh_fv(nhcube, TL)
+
+
+def test_nh_cube_adjoint_matches_oracle(nhcube):
+    from oracle import AD
+    N.cube_check_nh_fv(nhcube, AD)
+
+
+def test_nh_cube_dot_product(nhcube):
+    N.cube_check_nh_dot_product(nhcube)

@@ -56,3 +56,30 @@ def test_nh_fv_dynamics_dot_product_c48l72():
     c = Case(nx=48, ny=48, npz=72, n_split=3, k_split=2, dt=600.0, nq=3, backend="hip", oracle=False, hord_ks_traj=0, hord_ks_pert=0,
              hydrostatic=0)
     N.check_nh_fv_dot_product(c)
+
+
+@pytest.fixture(scope="module")
+def nhcube():
+    from common import CubeCase
+    return CubeCase(n=12, npz=6, n_split=2, k_split=2, dt=1200.0, nq=2, backend="hip", oracle=True, hord_ks_traj=0, hord_ks_pert=0, hydrostatic=0)
+
+
+def test_nh_cube_tangent_matches_oracle(nhcube):
+    from oracle import TL
+    N.cube_check_nh_fv(nhcube, TL)
+
+
+def test_nh_cube_adjoint_matches_oracle(nhcube):
+    from oracle import AD
+    N.cube_check_nh_fv(nhcube, AD)
+
+
+def test_nh_cube_dot_product(nhcube):
+    N.cube_check_nh_dot_product(nhcube)
+
+
+def test_nh_cube_dot_product_c48l72():
+    """six faces of C48 L72, whole non-hydrostatic step: dot-product identity, no oracle"""
+    from common import CubeCase
+    c = CubeCase(n=48, npz=72, n_split=3, k_split=2, dt=600.0, nq=3, backend="hip", hord_ks_traj=0, hord_ks_pert=0, hydrostatic=0)
+    N.cube_check_nh_dot_product(c)
