@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--dt", type=float, default=450.0)
     ap.add_argument("--nq", type=int, default=4)
     ap.add_argument("--tiles", choices=["cube", "periodic"], default="cube")
+    ap.add_argument("--nonhydrostatic", action="store_true",
+                    help="BASELINE config 3: w, delz prognostic, nh_core active (hydrostatic = 0); not the headline workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-host-transport", action="store_true",
                     help="multi-rank rehearsal on ONE GPU (RCCL refuses two ranks per device): gloo process group, halo messages staged "
@@ -170,16 +172,21 @@ def main():
                 set_allreduce_callback(lib, allmax)
         active = len(cube.faces_of(rank, world)) > 0
         if active:
+            nhkw = dict(hydrostatic=0, hord_ks_traj=0, hord_ks_pert=0) if args.nonhydrostatic else {}
             c = CubeCase(n=args.nx, npz=args.npz, n_split=args.n_split, k_split=args.k_split, dt=args.dt, backend="hip", nq=args.nq,
-                         rank=rank, world=world)
+                         rank=rank, world=world, **nhkw)
             T, P = cube_step_state(c)
+            if args.nonhydrostatic:
+                import nh_checks
+                Tn, Pn = nh_checks.cube_nh_state(c)
+                T.update(w=Tn[4], delz=Tn[5]); P.update(w=Pn[4], delz=Pn[5])
     else:
         c = Case(nx=args.nx, ny=args.nx, npz=args.npz, n_split=args.n_split, k_split=args.k_split, dt=args.dt, backend="hip",
                  oracle=False, nq=args.nq, seed=20250114 + rank)
         T, P = step_state(c)
         T = {k: v[None] for k, v in T.items()}; P = {k: v[None] for k, v in P.items()}
     if active:
-        names = ["u", "v", "pt", "delp"] + ["q%d" % (n + 1) for n in range(c.nq)]
+        names = ["u", "v", "pt", "delp"] + (["w", "delz"] if args.nonhydrostatic else []) + ["q%d" % (n + 1) for n in range(c.nq)]
         for n in names:
             c.dy.put(n, T[n], 0); c.dy.put(n, P[n], 1)
         c.dy.state_save()
@@ -237,9 +244,9 @@ def main():
             "metric": "column-updates/s per TL+AD dyn step", "value": value, "unit": "column-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong" if cube_mode else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C%dL%d hydrostatic TL+AD, %s (%d columns per GPU), "
+            "config": {"workload": "C%dL%d %s TL+AD, %s (%d columns per GPU), "
                                    "k_split=%d n_split=%d dt=%gs nq=%d, hord=2 (1 in the sponge), kord=17, nord=1"
-                                   % (args.nx, args.npz, ("six cube faces dealt over %d GPU(s) (%s faces per rank), table-driven face exchange%s"
+                                   % (args.nx, args.npz, "non-hydrostatic" if args.nonhydrostatic else "hydrostatic", ("six cube faces dealt over %d GPU(s) (%s faces per rank), table-driven face exchange%s"
                                                            % (world, "/".join(str(len(cube.faces_of(r, world))) for r in range(world)),
                                                               ", RCCL point-to-point between ranks" if world > 1 else "")) if cube_mode
                                       else "1 doubly-periodic tile per GPU", cols_rank, args.k_split, args.n_split, args.dt, args.nq),

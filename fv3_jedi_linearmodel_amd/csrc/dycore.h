@@ -361,7 +361,15 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
   work.init(n3 * ((g.face ? 120 : 114) + (nh ? 28 : 0)) + n3p * (14 + (nh ? 44 : 0)));
   if (nh) {
     nh_ws = (double*)dev_alloc((size_t)2 * NS_COUNT * (npz + 2) * np * 8);
-    nh_tape.stride = g.plane; nh_tape.cap = 104 * (npz + 2);
+    nh_tape.cap = 104 * (npz + 2);
+    int tape_tiles = ntile;                   // as many tiles per adjoint launch as a third of the free HBM holds (32 B per entry)
+#ifndef FV3LM_HOST_EMUL
+    { size_t fr = 0, tot = 0;
+      if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = 0;
+      const size_t per_tile = (size_t)nh_tape.cap * g.plane * 32;
+      tape_tiles = (int)std::max<size_t>(1, std::min<size_t>((size_t)ntile, fr / 3 / per_tile)); }
+#endif
+    nh_tape.stride = (size_t)tape_tiles * g.plane;
     nh_tape.part = (double*)dev_alloc((size_t)2 * nh_tape.cap * nh_tape.stride * 8);
     nh_tape.idx = (int*)dev_alloc((size_t)2 * nh_tape.cap * nh_tape.stride * 4);
     nh_tape.adj = (double*)dev_alloc((size_t)nh_tape.cap * nh_tape.stride * 8);

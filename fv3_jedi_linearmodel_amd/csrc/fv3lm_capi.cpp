@@ -170,6 +170,7 @@ int fv3lm_set_device(int dev) {
 // Device-side snapshot / restore of the prognostic state (trajectory and perturbation of u v pt delp q*).
 int fv3lm_state_save(fv3lm_handle* h) {
   Dynamics& d = h->d; std::vector<Fld> fs{d.f("u"), d.f("v"), d.f("pt"), d.f("delp")};
+  if (d.nh) { fs.push_back(d.f("w")); fs.push_back(d.f("delz")); }
   for (auto& q : d.q) fs.push_back(q);
   if (d.snap.size() != fs.size() * 2) { for (double* p : d.snap) dev_free(p); d.snap.clear(); for (size_t n = 0; n < fs.size() * 2; ++n) d.snap.push_back((double*)dev_alloc(d.n3 * 8)); }
   for (size_t n = 0; n < fs.size(); ++n) { dev_copy(d.ex, d.snap[2 * n], fs[n].t, d.n3 * 8); dev_copy(d.ex, d.snap[2 * n + 1], fs[n].p, d.n3 * 8); }
@@ -177,6 +178,7 @@ int fv3lm_state_save(fv3lm_handle* h) {
 }
 int fv3lm_state_restore(fv3lm_handle* h) {
   Dynamics& d = h->d; std::vector<Fld> fs{d.f("u"), d.f("v"), d.f("pt"), d.f("delp")};
+  if (d.nh) { fs.push_back(d.f("w")); fs.push_back(d.f("delz")); }
   for (auto& q : d.q) fs.push_back(q);
   if (d.snap.size() != fs.size() * 2) return fail("fv3lm_state_restore: no snapshot");
   for (size_t n = 0; n < fs.size(); ++n) { dev_copy(d.ex, fs[n].t, d.snap[2 * n], d.n3 * 8); dev_copy(d.ex, fs[n].p, d.snap[2 * n + 1], d.n3 * 8); }

@@ -405,7 +405,7 @@ HD void remap_press_col_nh(const IO& io, const NhColArgs& a) {
 enum NhColKind { NHC_RIEM_C = 0, NHC_RIEM3, NHC_EDGE, NHC_ZH_INIT, NHC_RING, NHC_RM_FIELD, NHC_RM_PRESS };
 struct NhColFn {
   NhColArgs a; int kind, mode; Rect skip;     // skip: rectangle left out (the rings of NHC_RING are a frame around it)
-  int z0;                                     // first tile of the launch (the adjoint runs tile by tile: the tape holds one tile)
+  int z0;                                     // first tile of the launch (the adjoint runs in chunks of tiles: as many as the tape holds)
   template <class IO>
   HD void body(const IO& io, const ColWs& ws, double hs) const {
     if (kind == NHC_RIEM_C) riem_c_col(io, a, ws, hs);
@@ -427,7 +427,7 @@ struct NhColFn {
     if (mode == MODE_NL) { ColNL io{a.g, a.f, z, i, j, nullptr}; body(io, ws, hs); }
     else if (mode == MODE_TL) { ColTL io{a.g, a.f, z, i, j, nullptr}; body(io, ws, hs); }
     else {
-      Tape t{a.tape, (size_t)a.g.idx(i, j), 0};
+      Tape t{a.tape, (size_t)zz * a.g.plane + a.g.idx(i, j), 0};
       ColAD io{a.g, a.f, z, i, j, &t};
       body(io, ws, hs);
       io.reverse();
@@ -438,7 +438,8 @@ inline void run_nh_col(Exec& ex, int mode, const NhColArgs& a0, int kind, const 
   NhColArgs a = a0;
   for (int n = 0; n < NH_NF; ++n) a.f[n] = ex.sh(a.f[n]);
   if (mode != MODE_AD) { for_points(ex, R, a.g.ntile, NhColFn{a, kind, mode, skip, 0}, tag); return; }
-  for (int z = 0; z < a.g.ntile; ++z) for_points(ex, R, 1, NhColFn{a, kind, mode, skip, z}, tag);
+  const int chunk = (int)(a.tape.stride / a.g.plane);       // tiles the tape holds at once (dycore.h sizes it from the free HBM)
+  for (int z = 0; z < a.g.ntile; z += chunk) for_points(ex, R, std::min(chunk, a.g.ntile - z), NhColFn{a, kind, mode, skip, z}, tag);
 }
 
 }  // namespace fv3

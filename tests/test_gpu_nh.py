@@ -83,3 +83,10 @@ def test_nh_cube_dot_product_c48l72():
     from common import CubeCase
     c = CubeCase(n=48, npz=72, n_split=3, k_split=2, dt=600.0, nq=3, backend="hip", hord_ks_traj=0, hord_ks_pert=0, hydrostatic=0)
     N.cube_check_nh_dot_product(c)
+
+
+def test_nh_cube_dot_product_c96l127():
+    """BASELINE config 3: C96 L127 non-hydrostatic TL+AD on one MI355X (six faces resident), dot-product identity"""
+    from common import CubeCase
+    c = CubeCase(n=96, npz=127, n_split=6, k_split=1, dt=225.0, nq=0, backend="hip", hord_ks_traj=0, hord_ks_pert=0, hydrostatic=0)
+    N.cube_check_nh_dot_product(c)
