@@ -16,9 +16,11 @@
 
 namespace fv3 {
 
+struct TapePart { double a, b; };
+struct TapeIdx { int a, b; };
 struct TapeMem {
-  double* part = nullptr;   // [2*cap][stride] partial derivatives
-  int* idx = nullptr;       // [2*cap][stride] operand ids (>= 0 variable, -1 none, <= -2 leaf: field slot, level)
+  TapePart* part = nullptr; // [cap][stride] the two partial derivatives of an entry (one 16-byte store per lane)
+  TapeIdx* idx = nullptr;   // [cap][stride] operand ids (>= 0 variable, -1 none, <= -2 leaf: field slot, level)
   double* adj = nullptr;    // [cap][stride]
   int* overflow = nullptr;  // device flag
   size_t stride = 0; int cap = 0;
@@ -28,9 +30,9 @@ struct Tape {
   HD int push(int ia, int ib, double pa, double pb) {
     if (n >= m.cap) { *m.overflow = 1; return -1; }
     const int id = n++;
-    const size_t e = (size_t)(2 * id) * m.stride + col;
-    m.part[e] = pa; m.part[e + m.stride] = pb; m.idx[e] = ia; m.idx[e + m.stride] = ib;
-    m.adj[(size_t)id * m.stride + col] = 0.;
+    const size_t e = (size_t)id * m.stride + col;
+    m.part[e] = TapePart{pa, pb}; m.idx[e] = TapeIdx{ia, ib};
+    m.adj[e] = 0.;
     return id;
   }
   HD double& ad(int id) const { return m.adj[(size_t)id * m.stride + col]; }
@@ -110,13 +112,15 @@ struct ColAD {
   // walk the tape backwards; leaves hand their adjoint to the fields
   HD void reverse() const {
     for (int id = tape->n - 1; id >= 0; --id) {
-      const size_t e = (size_t)(2 * id) * tape->m.stride + tape->col;
+      const size_t e = (size_t)id * tape->m.stride + tape->col;
       const double a = tape->ad(id);
-      const int ia = tape->m.idx[e], ib = tape->m.idx[e + tape->m.stride];
+      const TapeIdx ix = tape->m.idx[e];
+      const int ia = ix.a, ib = ix.b;
       if (ia <= -2) { const int slot = -2 - ia; f[slot].p[fidx(g, f[slot], tile, i, j, ib)] += a; continue; }
       if (a == 0.) continue;
-      if (ia >= 0) tape->ad(ia) += tape->m.part[e] * a;
-      if (ib >= 0) tape->ad(ib) += tape->m.part[e + tape->m.stride] * a;
+      const TapePart pt = tape->m.part[e];
+      if (ia >= 0) tape->ad(ia) += pt.a * a;
+      if (ib >= 0) tape->ad(ib) += pt.b * a;
     }
   }
 };

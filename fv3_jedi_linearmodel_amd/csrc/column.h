@@ -81,14 +81,15 @@ HD void geopk_col_ad(const GeopkArgs& a, int i, int j, int tile) {
     carry = p_ad;
   }
 }
+template <int MODE>      // one kernel per mode: separate register allocations
 struct GeopkFn {
-  GeopkArgs a; int mode;
+  GeopkArgs a;
   HD void operator()(int i, int j, int z) const {
     // the corner-halo cells of a cube face hold no exchanged data (the reference integrates whatever the halo
     // buffers contain there and never reads the result)
     if (a.g.face && (i < 1 || i > a.g.nx) && (j < 1 || j > a.g.ny)) return;
-    if (mode == MODE_NL) geopk_col<double>(a, i, j, z);
-    else if (mode == MODE_TL) geopk_col<Dual>(a, i, j, z);
+    if (MODE == MODE_NL) geopk_col<double>(a, i, j, z);
+    else if (MODE == MODE_TL) geopk_col<Dual>(a, i, j, z);
     else geopk_col_ad(a, i, j, z);
   }
 };
@@ -98,7 +99,9 @@ inline void run_geopk(Exec& ex, int mode, const GeopkArgs& a0) {
   // algorithmic bytes: delp, pt in; pe, peln, pk, gz (+pkz) out; x2 for TL; adjoint reads/updates the same set
   const double cells = double(a.R.i1 - a.R.i0 + 1) * (a.R.j1 - a.R.j0 + 1) * a.g.ntile * a.g.npz;
   const double per = (a.cg ? 6. : 7.) * (mode == MODE_NL ? 1. : mode == MODE_TL ? 2. : 3.);
-  for_points(ex, a.R, a.g.ntile, GeopkFn{a, mode}, mode == MODE_AD ? "geopk.ad" : mode == MODE_TL ? "geopk.tl" : "geopk.nl", 8. * per * cells);
+  if (mode == MODE_NL) for_points(ex, a.R, a.g.ntile, GeopkFn<MODE_NL>{a}, "geopk.nl", 8. * per * cells);
+  else if (mode == MODE_TL) for_points(ex, a.R, a.g.ntile, GeopkFn<MODE_TL>{a}, "geopk.tl", 8. * per * cells);
+  else for_points(ex, a.R, a.g.ntile, GeopkFn<MODE_AD>{a}, "geopk.ad", 8. * per * cells);
 }
 
 // ---------------------------------------------------------------- doubly-periodic halo fill

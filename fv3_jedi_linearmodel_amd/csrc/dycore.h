@@ -370,8 +370,8 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
       tape_tiles = (int)std::max<size_t>(1, std::min<size_t>((size_t)ntile, fr / 3 / per_tile)); }
 #endif
     nh_tape.stride = (size_t)tape_tiles * g.plane;
-    nh_tape.part = (double*)dev_alloc((size_t)2 * nh_tape.cap * nh_tape.stride * 8);
-    nh_tape.idx = (int*)dev_alloc((size_t)2 * nh_tape.cap * nh_tape.stride * 4);
+    nh_tape.part = (TapePart*)dev_alloc((size_t)nh_tape.cap * nh_tape.stride * sizeof(TapePart));
+    nh_tape.idx = (TapeIdx*)dev_alloc((size_t)nh_tape.cap * nh_tape.stride * sizeof(TapeIdx));
     nh_tape.adj = (double*)dev_alloc((size_t)nh_tape.cap * nh_tape.stride * 8);
     nh_tape.overflow = (int*)dev_alloc(8);
   }

@@ -203,20 +203,18 @@ inline void Dynamics::build_remap_nh() {
 inline void Dynamics::remap_nh_run(int mode, int km) {
   const size_t b3 = n3 * 8;
   RemapArgs ra = remap_args(km == k_split - 1);
-  const Rect A{1, g.nx, 1, g.ny}, U{1, g.nx, 1, g.ny + 1}, V{1, g.nx + 1, 1, g.ny}, H{0, g.nx + 1, 0, g.ny + 1};
+  const Rect A{1, g.nx, 1, g.ny}, H{0, g.nx + 1, 0, g.ny + 1};
   remap_last = (km == k_split - 1);
   std::vector<std::pair<Fld, Fld>> back{{f("w"), w_m}, {f("delz"), dz_m}};
   for (int n = 0; n < nq; ++n) back.push_back({q[n], q_m[n]});
   if (mode != MODE_AD) {
     run_group(remap_nh, nullptr, mode);
     for (auto& pr : back) { dev_copy(ex, pr.first.t, pr.second.t, b3); if (mode == MODE_TL) dev_copy(ex, pr.first.p, pr.second.p, b3); }
-    for_points(ex, U, g.ntile, RemapWindFn{ra, mode, 0}, mode == MODE_TL ? "remap_wind.tl" : "remap_wind.nl");
-    for_points(ex, V, g.ntile, RemapWindFn{ra, mode, 1}, mode == MODE_TL ? "remap_wind.tl" : "remap_wind.nl");
+    run_remap_winds(ex, mode, ra);
     for_points(ex, A, g.ntile, RemapPeFn{ra, mode}, "remap_pe");
     return;
   }
-  for_points(ex, V, g.ntile, RemapWindFn{ra, mode, 1}, "remap_wind.ad");
-  for_points(ex, U, g.ntile, RemapWindFn{ra, mode, 0}, "remap_wind.ad");
+  run_remap_winds(ex, MODE_AD, ra);
   for_points(ex, H, g.ntile, RemapGatherFn{ra}, "remap_gather.ad");
   run_group(remap_nh, nullptr, MODE_NL, true);      // trajectory of the staging fields
   dev_zero(ex, t_m.p, b3); dev_zero(ex, pe2.p, n3p * 8);     // pe after the remap is not read again (pe2 is only copied into it)

@@ -51,15 +51,18 @@ HD void nh_pp_edges(const IO& io, int km, double rgas, double gama, const WArr<I
     const T gr = dm2(k) / dm2(k + 1);
     g_rat.set(k, gr); bb.set(k, 2. * (1. + gr)); dd.set(k, 3. * (pe(k) + gr * pe(k + 1)));
   }
+  // recurrences carried in registers: a value just stored is not read back through memory
   T bet = bb(1);
-  pp.set(1, io.cst(0.)); pp.set(2, dd(1) / bet);
+  T ppk = dd(1) / bet;
+  pp.set(1, io.cst(0.)); pp.set(2, ppk);
   bb.set(km, io.cst(2.)); dd.set(km, 3. * pe(km));
   for (int k = 2; k <= km; ++k) {
     const T gm = g_rat(k - 1) / bet;
     gam.set(k, gm); bet = bb(k) - gm;
-    pp.set(k + 1, (dd(k) - pp(k)) / bet);
+    ppk = (dd(k) - ppk) / bet;
+    pp.set(k + 1, ppk);
   }
-  for (int k = km; k >= 2; --k) pp.set(k, pp(k) - gam(k) * pp(k + 1));
+  for (int k = km; k >= 2; --k) { ppk = pp(k) - gam(k) * ppk; pp.set(k, ppk); }
 }
 
 // workspace slots (in units of T)
@@ -76,23 +79,27 @@ HD void nh_sim1(const IO& io, const ColWs& ws, int km, double dt, double rgas, d
   nh_pp_edges(io, km, rgas, gama, pe, dm2, pm2, dz2, pt2, g_rat, bb, dd, gam, pp);
   for (int k = 2; k <= km; ++k) aa.set(k, t1g / (dz2(k - 1) + dz2(k)) * (pem(k) + pp(k)));
   T bet = dm2(1) - aa(2);
-  w2.set(1, (dm2(1) * w1(1) + dt * pp(2)) / bet);
+  T wk_ = (dm2(1) * w1(1) + dt * pp(2)) / bet;
+  w2.set(1, wk_);
   for (int k = 2; k <= km - 1; ++k) {
-    const T gm = aa(k) / bet;
+    const T ak_ = aa(k), gm = ak_ / bet;
     gam.set(k, gm);
-    bet = dm2(k) - (aa(k) + aa(k + 1) + aa(k) * gm);
-    w2.set(k, (dm2(k) * w1(k) + dt * (pp(k + 1) - pp(k)) - aa(k) * w2(k - 1)) / bet);
+    bet = dm2(k) - (ak_ + aa(k + 1) + ak_ * gm);
+    wk_ = (dm2(k) * w1(k) + dt * (pp(k + 1) - pp(k)) - ak_ * wk_) / bet;
+    w2.set(k, wk_);
   }
   const T p1 = t1g / dz2(km) * (pem(km + 1) + pp(km + 1));
   {
-    const T gm = aa(km) / bet;
+    const T ak_ = aa(km), gm = ak_ / bet;
     gam.set(km, gm);
-    bet = dm2(km) - (aa(km) + p1 + aa(km) * gm);
-    w2.set(km, (dm2(km) * w1(km) + dt * (pp(km + 1) - pp(km)) - p1 * wsfc - aa(km) * w2(km - 1)) / bet);
+    bet = dm2(km) - (ak_ + p1 + ak_ * gm);
+    wk_ = (dm2(km) * w1(km) + dt * (pp(km + 1) - pp(km)) - p1 * wsfc - ak_ * wk_) / bet;
+    w2.set(km, wk_);
   }
-  for (int k = km - 1; k >= 1; --k) w2.set(k, w2(k) - gam(k + 1) * w2(k + 1));
-  pe.set(1, io.cst(0.));
-  for (int k = 1; k <= km; ++k) pe.set(k + 1, pe(k) + dm2(k) * (w2(k) - w1(k)) * rdt);
+  for (int k = km - 1; k >= 1; --k) { wk_ = w2(k) - gam(k + 1) * wk_; w2.set(k, wk_); }
+  T pek = io.cst(0.);
+  pe.set(1, pek);
+  for (int k = 1; k <= km; ++k) { pek = pek + dm2(k) * (w2(k) - w1(k)) * rdt; pe.set(k + 1, pek); }
   nh_new_dz(io, km, rgas, kappa - 1., p_fac, pe, bb, g_rat, dm2, pm2, pt2, dz2);
 }
 
@@ -114,23 +121,27 @@ HD void nh_sim(const IO& io, const ColWs& ws, int km, double dt, double rgas, do
     aa.set(k, a - scale_m * dm2(1));
   }
   T bet = dm2(1) - aa(2);
-  w2.set(1, (dm2(1) * w1(1) + dt * pp(2) + wk(2)) / bet);
+  T wv = (dm2(1) * w1(1) + dt * pp(2) + wk(2)) / bet;
+  w2.set(1, wv);
   for (int k = 2; k <= km - 1; ++k) {
-    const T gm = aa(k) / bet;
+    const T ak_ = aa(k), gm = ak_ / bet;
     gam.set(k, gm);
-    bet = dm2(k) - (aa(k) + aa(k + 1) + aa(k) * gm);
-    w2.set(k, (dm2(k) * w1(k) + dt * (pp(k + 1) - pp(k)) + wk(k + 1) - wk(k) - aa(k) * w2(k - 1)) / bet);
+    bet = dm2(k) - (ak_ + aa(k + 1) + ak_ * gm);
+    wv = (dm2(k) * w1(k) + dt * (pp(k + 1) - pp(k)) + wk(k + 1) - wk(k) - ak_ * wv) / bet;
+    w2.set(k, wv);
   }
   {
     const T wk1 = t1g / dz2(km) * pe(km + 1);
-    const T gm = aa(km) / bet;
+    const T ak_ = aa(km), gm = ak_ / bet;
     gam.set(km, gm);
-    bet = dm2(km) - (aa(km) + wk1 + aa(km) * gm);
-    w2.set(km, (dm2(km) * w1(km) + dt * (pp(km + 1) - pp(km)) - wk(km) + wk1 * (t2 * w1(km) - ra * wsfc) - aa(km) * w2(km - 1)) / bet);
+    bet = dm2(km) - (ak_ + wk1 + ak_ * gm);
+    wv = (dm2(km) * w1(km) + dt * (pp(km + 1) - pp(km)) - wk(km) + wk1 * (t2 * w1(km) - ra * wsfc) - ak_ * wv) / bet;
+    w2.set(km, wv);
   }
-  for (int k = km - 1; k >= 1; --k) w2.set(k, w2(k) - gam(k + 1) * w2(k + 1));
-  pe.set(1, io.cst(0.));
-  for (int k = 1; k <= km; ++k) pe.set(k + 1, pe(k) + (dm2(k) * (w2(k) - w1(k)) * rdt - beta * (pp(k + 1) - pp(k))) * ra);
+  for (int k = km - 1; k >= 1; --k) { wv = w2(k) - gam(k + 1) * wv; w2.set(k, wv); }
+  T pek = io.cst(0.);
+  pe.set(1, pek);
+  for (int k = 1; k <= km; ++k) { pek = pek + (dm2(k) * (w2(k) - w1(k)) * rdt - beta * (pp(k + 1) - pp(k))) * ra; pe.set(k + 1, pek); }
   nh_new_dz(io, km, rgas, kappa - 1., p_fac, pe, bb, g_rat, dm2, pm2, pt2, dz2);
   for (int k = 1; k <= km + 1; ++k) pe.set(k, pe(k) + beta * (pp(k) - pe(k)));
 }
@@ -152,13 +163,15 @@ HD void riem_c_col(const IO& io, const NhColArgs& a, const ColWs& ws, double hs)
     below = zk;
   }
   io.st(5, 1, io.cst(a.ptop));
-  pem.set(1, io.cst(a.ptop));
-  for (int k = 1; k <= km; ++k) pem.set(k + 1, pem(k) + io.ld(3, k));
+  T pk_ = io.cst(a.ptop);
+  pem.set(1, pk_);
   for (int k = 1; k <= km; ++k) {
-    const T dp = io.ld(3, k);
-    pm2.set(k, dp / dlog(pem(k + 1) / pem(k)));
+    const T dp = io.ld(3, k), pn = pk_ + dp;
+    pem.set(k + 1, pn);
+    pm2.set(k, dp / dlog(pn / pk_));
     dm2.set(k, dp * rgrav);
     w2.set(k, io.ld(1, k)); pt2.set(k, io.ld(2, k));
+    pk_ = pn;
   }
   nh_sim1(io, ws, km, a.dt, a.rdgas, gama, a.akap, wsfc, a.p_fac);
   for (int k = 2; k <= km + 1; ++k) io.st(5, k, pe(k) + pem(k));
@@ -174,8 +187,7 @@ HD void riem3_col(const IO& io, const NhColArgs& a, const ColWs& ws, double hs) 
   typedef typename IO::T T;
   const int km = a.g.npz;
   const double gama = 1. / (1. - a.akap), rgrav = 1. / a.grav, zs = hs * rgrav;
-  WArr<IO> pe{io, ws, NS_PE}, dm2{io, ws, NS_DM}, pm2{io, ws, NS_PM}, pem{io, ws, NS_PEM}, w2{io, ws, NS_W2}, dz2{io, ws, NS_DZ}, pt2{io, ws, NS_PT},
-      pln{io, ws, NS_AA};     // peln2 borrows the aa slot until the solver starts
+  WArr<IO> pe{io, ws, NS_PE}, dm2{io, ws, NS_DM}, pm2{io, ws, NS_PM}, pem{io, ws, NS_PEM}, w2{io, ws, NS_W2}, dz2{io, ws, NS_DZ}, pt2{io, ws, NS_PT};
   T below = io.ld(0, km + 1);
   const T wsfc = (zs - below) * (1. / a.dt);
   if (a.last_call) io.st(12, 1, wsfc);
@@ -187,20 +199,18 @@ HD void riem3_col(const IO& io, const NhColArgs& a, const ColWs& ws, double hs) 
   }
   pem.set(1, io.cst(a.ptop));
   const double peln1 = log(a.ptop);
-  pln.set(1, io.cst(peln1));
   io.st(8, 1, io.cst(exp(a.akap * peln1)));
   if (a.last_call) { io.st(9, 1, io.cst(a.ptop)); io.st(10, 1, io.cst(peln1)); io.st(11, 1, io.cst(exp(a.akap * peln1))); }
+  T p_ = io.cst(a.ptop), l_ = io.cst(peln1);
   for (int k = 1; k <= km; ++k) {
-    const T p = pem(k) + io.ld(3, k), l = dlog(p), pk = dexp(a.akap * l);
-    pem.set(k + 1, p); pln.set(k + 1, l);
+    const T dp = io.ld(3, k), p = p_ + dp, l = dlog(p), pk = dexp(a.akap * l);
+    pem.set(k + 1, p);
     io.st(8, k + 1, pk);
     if (a.last_call) { io.st(9, k + 1, p); io.st(10, k + 1, l); io.st(11, k + 1, pk); }
-  }
-  for (int k = 1; k <= km; ++k) {
-    const T dp = io.ld(3, k);
-    pm2.set(k, dp / (pln(k + 1) - pln(k)));
+    pm2.set(k, dp / (l - l_));
     dm2.set(k, dp * rgrav);
     w2.set(k, io.ld(1, k)); pt2.set(k, io.ld(2, k));
+    p_ = p; l_ = l;
   }
   nh_sim(io, ws, km, a.dt, a.rdgas, gama, a.akap, wsfc, a.a_imp, a.p_fac, a.scale_z);
   for (int k = 1; k <= km; ++k) { io.st(4, k, w2(k)); io.st(5, k, dz2(k)); }
@@ -221,23 +231,29 @@ HD void edge_col(const IO& io, const NhColArgs& a, const ColWs& ws) {
   const double g0 = dp0(2) / dp0(1);
   double bet = g0 * (g0 + 0.5), gam = (1. + g0 * (g0 + 1.5)) / bet, gk = g0;
   const double xt1 = 2. * g0 * (g0 + 1.);
-  e1.set(1, (xt1 * io.ld(0, 1) + io.ld(0, 2)) / bet); e2.set(1, (xt1 * io.ld(1, 1) + io.ld(1, 2)) / bet);
+  T c1 = (xt1 * io.ld(0, 1) + io.ld(0, 2)) / bet, c2 = (xt1 * io.ld(1, 1) + io.ld(1, 2)) / bet;
+  e1.set(1, c1); e2.set(1, c2);
   // gam(k) depends on the reference thicknesses only: kept as plain doubles in raw workspace slot 8 (e1, e2 use raw 0..3)
   ColWs wg = ws;
   wg.at(8, 1) = gam;
   for (int k = 2; k <= km; ++k) {
     gk = dp0(k - 1) / dp0(k);
     bet = 2. + 2. * gk - gam;
-    e1.set(k, (3. * (io.ld(0, k - 1) + gk * io.ld(0, k)) - e1(k - 1)) / bet);
-    e2.set(k, (3. * (io.ld(1, k - 1) + gk * io.ld(1, k)) - e2(k - 1)) / bet);
+    c1 = (3. * (io.ld(0, k - 1) + gk * io.ld(0, k)) - c1) / bet;
+    c2 = (3. * (io.ld(1, k - 1) + gk * io.ld(1, k)) - c2) / bet;
+    e1.set(k, c1); e2.set(k, c2);
     gam = gk / bet;
     wg.at(8, k) = gam;
   }
   const double a_bot = 1. + gk * (gk + 1.5), xb = 2. * gk * (gk + 1.), xt2 = gk * (gk + 0.5) - a_bot * gam;
-  e1.set(km + 1, (xb * io.ld(0, km) + io.ld(0, km - 1) - a_bot * e1(km)) / xt2);
-  e2.set(km + 1, (xb * io.ld(1, km) + io.ld(1, km - 1) - a_bot * e2(km)) / xt2);
-  for (int k = km; k >= 1; --k) { const double gmk = wg.at(8, k); e1.set(k, e1(k) - gmk * e1(k + 1)); e2.set(k, e2(k) - gmk * e2(k + 1)); }
-  for (int k = 1; k <= km + 1; ++k) { io.st(2, k, e1(k)); io.st(3, k, e2(k)); }
+  c1 = (xb * io.ld(0, km) + io.ld(0, km - 1) - a_bot * c1) / xt2;
+  c2 = (xb * io.ld(1, km) + io.ld(1, km - 1) - a_bot * c2) / xt2;
+  io.st(2, km + 1, c1); io.st(3, km + 1, c2);
+  for (int k = km; k >= 1; --k) {
+    const double gmk = wg.at(8, k);
+    c1 = e1(k) - gmk * c1; c2 = e2(k) - gmk * c2;
+    io.st(2, k, c1); io.st(3, k, c2);
+  }
 }
 
 // interface heights from the layer thicknesses.  f: 0 delz (km)   ->   1 zh (km+1)
@@ -284,20 +300,22 @@ HD void map_col_io(const IO& io, int km, const ColWs& ws, int iv, const typename
   } else {
     const T dpa = pe1(2) - pe1(1), grat = (pe1(3) - pe1(2)) / dpa;
     T bet = grat * (grat + 0.5);
-    qe.set(1, ((grat + grat) * (grat + 1.) * q1(1) + q1(2)) / bet);
-    gam.set(1, (1. + grat * (grat + 1.5)) / bet);
+    T qf = ((grat + grat) * (grat + 1.) * q1(1) + q1(2)) / bet, gm = (1. + grat * (grat + 1.5)) / bet;
+    qe.set(1, qf); gam.set(1, gm);
     T d4 = grat, dp_prev = dpa;
     for (int k = 2; k <= km; ++k) {
       const T dpk = pe1(k + 1) - pe1(k);
       d4 = dp_prev / dpk;
-      bet = 2. + d4 + d4 - gam(k - 1);
-      qe.set(k, (3. * (q1(k - 1) + d4 * q1(k)) - qe(k - 1)) / bet);
-      gam.set(k, d4 / bet);
+      bet = 2. + d4 + d4 - gm;
+      qf = (3. * (q1(k - 1) + d4 * q1(k)) - qf) / bet;
+      gm = d4 / bet;
+      qe.set(k, qf); gam.set(k, gm);
       dp_prev = dpk;
     }
     const T a_bot = 1. + d4 * (d4 + 1.5);
-    qe.set(km + 1, (2. * d4 * (d4 + 1.) * q1(km) + q1(km - 1) - a_bot * qe(km)) / (d4 * (d4 + 0.5) - a_bot * gam(km)));
-    for (int k = km; k >= 1; --k) qe.set(k, qe(k) - gam(k) * qe(k + 1));
+    qf = (2. * d4 * (d4 + 1.) * q1(km) + q1(km - 1) - a_bot * qf) / (d4 * (d4 + 0.5) - a_bot * gm);
+    qe.set(km + 1, qf);
+    for (int k = km; k >= 1; --k) { qf = qe(k) - gam(k) * qf; qe.set(k, qf); }
   }
   int k0 = 1;
   T qsum = io.cst(0.);
@@ -403,29 +421,32 @@ HD void remap_press_col_nh(const IO& io, const NhColArgs& a) {
 }
 
 enum NhColKind { NHC_RIEM_C = 0, NHC_RIEM3, NHC_EDGE, NHC_ZH_INIT, NHC_RING, NHC_RM_FIELD, NHC_RM_PRESS };
+// One kernel per (operator, mode): each gets its own register allocation (the taped remap needs ~250 VGPRs, the nonlinear
+// solvers a fraction of that).
+template <int KIND, int MODE>
 struct NhColFn {
-  NhColArgs a; int kind, mode; Rect skip;     // skip: rectangle left out (the rings of NHC_RING are a frame around it)
+  NhColArgs a; Rect skip;                     // skip: rectangle left out (the rings of NHC_RING are a frame around it)
   int z0;                                     // first tile of the launch (the adjoint runs in chunks of tiles: as many as the tape holds)
   template <class IO>
   HD void body(const IO& io, const ColWs& ws, double hs) const {
-    if (kind == NHC_RIEM_C) riem_c_col(io, a, ws, hs);
-    else if (kind == NHC_RIEM3) riem3_col(io, a, ws, hs);
-    else if (kind == NHC_EDGE) edge_col(io, a, ws);
-    else if (kind == NHC_ZH_INIT) zh_init_col(io, a, hs);
-    else if (kind == NHC_RING) ring_col(io, a);
-    else if (kind == NHC_RM_FIELD) remap_field_col_nh(io, a, ws);
+    if (KIND == NHC_RIEM_C) riem_c_col(io, a, ws, hs);
+    else if (KIND == NHC_RIEM3) riem3_col(io, a, ws, hs);
+    else if (KIND == NHC_EDGE) edge_col(io, a, ws);
+    else if (KIND == NHC_ZH_INIT) zh_init_col(io, a, hs);
+    else if (KIND == NHC_RING) ring_col(io, a);
+    else if (KIND == NHC_RM_FIELD) remap_field_col_nh(io, a, ws);
     else remap_press_col_nh(io, a);
   }
   HD void operator()(int i, int j, int zz) const {
     const int z = zz + z0;
-    if (kind == NHC_RING && skip.has(i, j)) return;
+    if (KIND == NHC_RING && skip.has(i, j)) return;
     // corner-halo columns of a face hold no data (cell-centred operators; the flux points of NHC_EDGE all touch a valid cell)
-    if (kind != NHC_EDGE && a.g.face && (i < 1 || i > a.g.nx) && (j < 1 || j > a.g.ny)) return;
+    if (KIND != NHC_EDGE && a.g.face && (i < 1 || i > a.g.nx) && (j < 1 || j > a.g.ny)) return;
     const size_t col = (size_t)z * a.g.plane + a.g.idx(i, j);
     const ColWs ws{a.ws + col, a.ws_stride, a.g.npz + 2};
     const double hs = a.hs ? a.hs[col] : 0.;
-    if (mode == MODE_NL) { ColNL io{a.g, a.f, z, i, j, nullptr}; body(io, ws, hs); }
-    else if (mode == MODE_TL) { ColTL io{a.g, a.f, z, i, j, nullptr}; body(io, ws, hs); }
+    if (MODE == MODE_NL) { ColNL io{a.g, a.f, z, i, j, nullptr}; body(io, ws, hs); }
+    else if (MODE == MODE_TL) { ColTL io{a.g, a.f, z, i, j, nullptr}; body(io, ws, hs); }
     else {
       Tape t{a.tape, (size_t)zz * a.g.plane + a.g.idx(i, j), 0};
       ColAD io{a.g, a.f, z, i, j, &t};
@@ -434,12 +455,30 @@ struct NhColFn {
     }
   }
 };
+template <int KIND, int MODE>
+inline void run_nh_col_km(Exec& ex, const NhColArgs& a, const Rect& R, const Rect& skip, const char* tag) {
+  if (MODE != MODE_AD) { for_points(ex, R, a.g.ntile, NhColFn<KIND, MODE>{a, skip, 0}, tag); return; }
+  const int chunk = (int)(a.tape.stride / a.g.plane);       // tiles the tape holds at once (dycore.h sizes it from the free HBM)
+  for (int z = 0; z < a.g.ntile; z += chunk) for_points(ex, R, std::min(chunk, a.g.ntile - z), NhColFn<KIND, MODE>{a, skip, z}, tag);
+}
+template <int KIND>
+inline void run_nh_col_k(Exec& ex, int mode, const NhColArgs& a, const Rect& R, const Rect& skip, const char* tag) {
+  if (mode == MODE_NL) run_nh_col_km<KIND, MODE_NL>(ex, a, R, skip, tag);
+  else if (mode == MODE_TL) run_nh_col_km<KIND, MODE_TL>(ex, a, R, skip, tag);
+  else run_nh_col_km<KIND, MODE_AD>(ex, a, R, skip, tag);
+}
 inline void run_nh_col(Exec& ex, int mode, const NhColArgs& a0, int kind, const Rect& R, const Rect& skip, const char* tag) {
   NhColArgs a = a0;
   for (int n = 0; n < NH_NF; ++n) a.f[n] = ex.sh(a.f[n]);
-  if (mode != MODE_AD) { for_points(ex, R, a.g.ntile, NhColFn{a, kind, mode, skip, 0}, tag); return; }
-  const int chunk = (int)(a.tape.stride / a.g.plane);       // tiles the tape holds at once (dycore.h sizes it from the free HBM)
-  for (int z = 0; z < a.g.ntile; z += chunk) for_points(ex, R, std::min(chunk, a.g.ntile - z), NhColFn{a, kind, mode, skip, z}, tag);
+  switch (kind) {
+    case NHC_RIEM_C: run_nh_col_k<NHC_RIEM_C>(ex, mode, a, R, skip, tag); break;
+    case NHC_RIEM3: run_nh_col_k<NHC_RIEM3>(ex, mode, a, R, skip, tag); break;
+    case NHC_EDGE: run_nh_col_k<NHC_EDGE>(ex, mode, a, R, skip, tag); break;
+    case NHC_ZH_INIT: run_nh_col_k<NHC_ZH_INIT>(ex, mode, a, R, skip, tag); break;
+    case NHC_RING: run_nh_col_k<NHC_RING>(ex, mode, a, R, skip, tag); break;
+    case NHC_RM_FIELD: run_nh_col_k<NHC_RM_FIELD>(ex, mode, a, R, skip, tag); break;
+    default: run_nh_col_k<NHC_RM_PRESS>(ex, mode, a, R, skip, tag); break;
+  }
 }
 
 }  // namespace fv3

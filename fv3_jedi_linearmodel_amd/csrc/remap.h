@@ -527,35 +527,46 @@ HD void remap_ad_k3(const RemapArgs& a, int i, int j, int tile, size_t col) {
   }
 }
 
+// one kernel per mode (separate register allocations)
+template <int MODE>
 struct RemapFieldFn {      // z = tile * nf + field
-  RemapArgs a; int mode, nf;
+  RemapArgs a; int nf;
   HD void operator()(int i, int j, int z) const {
     const int tile = z / nf, field = z % nf;
     const size_t col = (size_t)tile * a.g.plane + a.g.idx(i, j);
-    if (mode == MODE_NL) remap_field_col<double>(a, field, i, j, tile, col);
-    else if (mode == MODE_TL) remap_field_col<Dual>(a, field, i, j, tile, col);
+    if (MODE == MODE_NL) remap_field_col<double>(a, field, i, j, tile, col);
+    else if (MODE == MODE_TL) remap_field_col<Dual>(a, field, i, j, tile, col);
     else remap_ad_k2(a, field, i, j, tile, col);
   }
 };
+template <int MODE>        // MODE_AD: stage 1 of the adjoint; 3: stage 3
 struct RemapPressFn {
-  RemapArgs a; int mode;     // MODE_AD: stage 1 of the adjoint; mode 3: stage 3
+  RemapArgs a;
   HD void operator()(int i, int j, int z) const {
     const size_t col = (size_t)z * a.g.plane + a.g.idx(i, j);
-    if (mode == MODE_NL) remap_press_col<double>(a, i, j, z);
-    else if (mode == MODE_TL) remap_press_col<Dual>(a, i, j, z);
-    else if (mode == MODE_AD) remap_ad_k1(a, i, j, z, col);
+    if (MODE == MODE_NL) remap_press_col<double>(a, i, j, z);
+    else if (MODE == MODE_TL) remap_press_col<Dual>(a, i, j, z);
+    else if (MODE == MODE_AD) remap_ad_k1(a, i, j, z, col);
     else remap_ad_k3(a, i, j, z, col);
   }
 };
+template <int MODE>
 struct RemapWindFn {
-  RemapArgs a; int mode, dir;
+  RemapArgs a; int dir;
   HD void operator()(int i, int j, int z) const {
     const size_t col = (size_t)z * a.g.plane + a.g.idx(i, j);
-    if (mode == MODE_NL) remap_wind_col<double>(a, dir, i, j, z, col);
-    else if (mode == MODE_TL) remap_wind_col<Dual>(a, dir, i, j, z, col);
+    if (MODE == MODE_NL) remap_wind_col<double>(a, dir, i, j, z, col);
+    else if (MODE == MODE_TL) remap_wind_col<Dual>(a, dir, i, j, z, col);
     else remap_wind_col_ad(a, dir, i, j, z, col);
   }
 };
+inline void run_remap_winds(Exec& ex, int mode, const RemapArgs& a, double bytes = 0.) {
+  const Geom& g = a.g;
+  const Rect U{1, g.nx, 1, g.ny + 1}, V{1, g.nx + 1, 1, g.ny};
+  if (mode == MODE_NL) { for_points(ex, U, g.ntile, RemapWindFn<MODE_NL>{a, 0}, "remap_wind.nl", bytes); for_points(ex, V, g.ntile, RemapWindFn<MODE_NL>{a, 1}, "remap_wind.nl", bytes); }
+  else if (mode == MODE_TL) { for_points(ex, U, g.ntile, RemapWindFn<MODE_TL>{a, 0}, "remap_wind.tl", bytes); for_points(ex, V, g.ntile, RemapWindFn<MODE_TL>{a, 1}, "remap_wind.tl", bytes); }
+  else { for_points(ex, V, g.ntile, RemapWindFn<MODE_AD>{a, 1}, "remap_wind.ad", bytes); for_points(ex, U, g.ntile, RemapWindFn<MODE_AD>{a, 0}, "remap_wind.ad", bytes); }
+}
 struct RemapGatherFn {
   RemapArgs a;
   HD void operator()(int i, int j, int z) const { remap_pe_gather_ad(a, i, j, z); }
@@ -576,25 +587,28 @@ struct RemapPeFn {
 inline int remap_ws_slots(int nq) { return RemapAdSlots::FBASE + RemapAdSlots::FN * (1 + nq); }
 inline void run_remap(Exec& ex, int mode, const RemapArgs& a) {
   const Geom& g = a.g;
-  const Rect A{1, g.nx, 1, g.ny}, U{1, g.nx, 1, g.ny + 1}, V{1, g.nx + 1, 1, g.ny}, H{0, g.nx + 1, 0, g.ny + 1};
+  const Rect A{1, g.nx, 1, g.ny}, H{0, g.nx + 1, 0, g.ny + 1};
   if (mode != MODE_AD) {
     const double cells = double(g.nx) * g.ny * g.ntile * g.npz, w = mode == MODE_TL ? 2. : 1.;
     // algorithmic bytes: scalars read pe,peln,pk,pt,q[nq]; write pt,q[nq],delp,pk,peln,pkz,pe2; winds read pe x2, u|v; write u|v
     const int nf = 1 + a.nq;
-    for_points(ex, A, g.ntile * nf, RemapFieldFn{a, mode, nf}, mode == MODE_TL ? "remap_fields.tl" : "remap_fields.nl", 8. * w * (5. + 2. * a.nq) * cells);
-    for_points(ex, A, g.ntile, RemapPressFn{a, mode}, mode == MODE_TL ? "remap_press.tl" : "remap_press.nl", 8. * w * (5. + 7.) * cells);
-    for_points(ex, U, g.ntile, RemapWindFn{a, mode, 0}, mode == MODE_TL ? "remap_wind.tl" : "remap_wind.nl", 8. * w * 4. * cells);
-    for_points(ex, V, g.ntile, RemapWindFn{a, mode, 1}, mode == MODE_TL ? "remap_wind.tl" : "remap_wind.nl", 8. * w * 4. * cells);
+    if (mode == MODE_TL) {
+      for_points(ex, A, g.ntile * nf, RemapFieldFn<MODE_TL>{a, nf}, "remap_fields.tl", 8. * w * (5. + 2. * a.nq) * cells);
+      for_points(ex, A, g.ntile, RemapPressFn<MODE_TL>{a}, "remap_press.tl", 8. * w * (5. + 7.) * cells);
+    } else {
+      for_points(ex, A, g.ntile * nf, RemapFieldFn<MODE_NL>{a, nf}, "remap_fields.nl", 8. * w * (5. + 2. * a.nq) * cells);
+      for_points(ex, A, g.ntile, RemapPressFn<MODE_NL>{a}, "remap_press.nl", 8. * w * (5. + 7.) * cells);
+    }
+    run_remap_winds(ex, mode, a, 8. * w * 4. * cells);
     for_points(ex, A, g.ntile, RemapPeFn{a, mode}, "remap_pe");
   } else {
     const double cells = double(g.nx) * g.ny * g.ntile * g.npz;
-    for_points(ex, V, g.ntile, RemapWindFn{a, mode, 1}, "remap_wind.ad", 8. * 7. * cells);
-    for_points(ex, U, g.ntile, RemapWindFn{a, mode, 0}, "remap_wind.ad", 8. * 7. * cells);
+    run_remap_winds(ex, MODE_AD, a, 8. * 7. * cells);
     for_points(ex, H, g.ntile, RemapGatherFn{a}, "remap_gather.ad", 8. * 4. * cells);
     const int nf = 1 + a.nq;
-    for_points(ex, A, g.ntile, RemapPressFn{a, MODE_AD}, "remap_scalars1.ad", 8. * 12. * cells);
-    for_points(ex, A, g.ntile * nf, RemapFieldFn{a, MODE_AD, nf}, "remap_fields.ad", 8. * (4. + 3. * a.nq) * cells);
-    for_points(ex, A, g.ntile, RemapPressFn{a, 3}, "remap_scalars3.ad", 8. * 8. * cells);
+    for_points(ex, A, g.ntile, RemapPressFn<MODE_AD>{a}, "remap_scalars1.ad", 8. * 12. * cells);
+    for_points(ex, A, g.ntile * nf, RemapFieldFn<MODE_AD>{a, nf}, "remap_fields.ad", 8. * (4. + 3. * a.nq) * cells);
+    for_points(ex, A, g.ntile, RemapPressFn<3>{a}, "remap_scalars3.ad", 8. * 8. * cells);
   }
 }
 
