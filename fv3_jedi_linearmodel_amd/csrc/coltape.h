@@ -37,44 +37,54 @@ struct Tape {
   }
   HD double& ad(int id) const { return m.adj[(size_t)id * m.stride + col]; }
 };
+// A taped value is (value, scale, id): its derivative with respect to tape variable `id` is `scale`.  Sums with and multiples
+// of untaped numbers only change value and scale, so they cost no tape entry.
 struct TV {
-  double v; int id; Tape* t;
-  HD TV() : v(0.), id(-1), t(nullptr) {}
-  HD TV(double v_) : v(v_), id(-1), t(nullptr) {}
-  HD TV(double v_, int id_, Tape* t_) : v(v_), id(id_), t(t_) {}
+  double v, s; int id; Tape* t;
+  HD TV() : v(0.), s(1.), id(-1), t(nullptr) {}
+  HD TV(double v_) : v(v_), s(1.), id(-1), t(nullptr) {}
+  HD TV(double v_, double s_, int id_, Tape* t_) : v(v_), s(s_), id(id_), t(t_) {}
 };
-HD Tape* tape_of(const TV& a, const TV& b) { return a.t ? a.t : b.t; }
-HD TV tv2(const TV& a, const TV& b, double v, double pa, double pb) {
-  Tape* t = tape_of(a, b);
-  if (!t || (a.id < 0 && b.id < 0)) return TV(v);
-  return TV(v, t->push(a.id, b.id, pa, pb), t);
+HD TV tv2(const TV& a, const TV& b, double v, double pa, double pb) {     // pa, pb: partials with respect to the VALUES of a, b
+  if (a.id >= 0 && b.id >= 0) return TV(v, 1., a.t->push(a.id, b.id, pa * a.s, pb * b.s), a.t);
+  if (a.id >= 0) return TV(v, pa * a.s, a.id, a.t);
+  if (b.id >= 0) return TV(v, pb * b.s, b.id, b.t);
+  return TV(v);
 }
-HD TV tv1(const TV& a, double v, double pa) {
-  if (!a.t || a.id < 0) return TV(v);
-  return TV(v, a.t->push(a.id, -1, pa, 0.), a.t);
+HD TV tv1n(const TV& a, double v, double pa) {                            // nonlinear function of one taped value: always an entry
+  if (a.id < 0) return TV(v);
+  return TV(v, 1., a.t->push(a.id, -1, pa * a.s, 0.), a.t);
 }
+HD TV tv1l(const TV& a, double v, double pa) { return a.id < 0 ? TV(v) : TV(v, pa * a.s, a.id, a.t); }   // affine: folded into the scale
 HD TV operator+(const TV& a, const TV& b) { return tv2(a, b, a.v + b.v, 1., 1.); }
 HD TV operator-(const TV& a, const TV& b) { return tv2(a, b, a.v - b.v, 1., -1.); }
 HD TV operator*(const TV& a, const TV& b) { return tv2(a, b, a.v * b.v, b.v, a.v); }
-HD TV operator/(const TV& a, const TV& b) { const double r = 1. / b.v, q = a.v * r; return tv2(a, b, q, r, -q * r); }
-HD TV operator-(const TV& a) { return tv1(a, -a.v, -1.); }
-HD TV operator+(const TV& a, double b) { return tv1(a, a.v + b, 1.); }
-HD TV operator+(double a, const TV& b) { return tv1(b, a + b.v, 1.); }
-HD TV operator-(const TV& a, double b) { return tv1(a, a.v - b, 1.); }
-HD TV operator-(double a, const TV& b) { return tv1(b, a - b.v, -1.); }
-HD TV operator*(const TV& a, double b) { return tv1(a, a.v * b, b); }
-HD TV operator*(double a, const TV& b) { return tv1(b, a * b.v, a); }
-HD TV operator/(const TV& a, double b) { return tv1(a, a.v / b, 1. / b); }
-HD TV operator/(double a, const TV& b) { const double q = a / b.v; return tv1(b, q, -q / b.v); }
-HD TV dlog(const TV& a) { return tv1(a, log(a.v), 1. / a.v); }
-HD TV dexp(const TV& a) { const double e = exp(a.v); return tv1(a, e, e); }
+HD TV operator/(const TV& a, const TV& b) {
+  const double r = 1. / b.v, q = a.v * r;
+  if (b.id < 0) return tv1l(a, q, r);
+  if (a.id < 0) return tv1n(b, q, -q * r);
+  return tv2(a, b, q, r, -q * r);
+}
+HD TV operator-(const TV& a) { return tv1l(a, -a.v, -1.); }
+HD TV operator+(const TV& a, double b) { return tv1l(a, a.v + b, 1.); }
+HD TV operator+(double a, const TV& b) { return tv1l(b, a + b.v, 1.); }
+HD TV operator-(const TV& a, double b) { return tv1l(a, a.v - b, 1.); }
+HD TV operator-(double a, const TV& b) { return tv1l(b, a - b.v, -1.); }
+HD TV operator*(const TV& a, double b) { return tv1l(a, a.v * b, b); }
+HD TV operator*(double a, const TV& b) { return tv1l(b, a * b.v, a); }
+HD TV operator/(const TV& a, double b) { return tv1l(a, a.v / b, 1. / b); }
+HD TV operator/(double a, const TV& b) { const double q = a / b.v; return tv1n(b, q, -q / b.v); }
+HD TV dlog(const TV& a) { return tv1n(a, log(a.v), 1. / a.v); }
+HD TV dexp(const TV& a) { const double e = exp(a.v); return tv1n(a, e, e); }
 HD double val(const TV& a) { return a.v; }
+// scale 1 form (what the workspace stores)
+HD TV tv_unit(const TV& x) { return (x.id < 0 || x.s == 1.) ? x : TV(x.v, 1., x.t->push(x.id, -1, x.s, 0.), x.t); }
 
 // workspace storage of a taped scalar: value + id (as a double)
 template <> struct WsIO<TV> {
   static constexpr int W = 2;
-  HD static TV get(const ColWs& w, int s, int k, Tape* t) { return TV(w.at(2 * s, k), (int)w.at(2 * s + 1, k), t); }
-  HD static void set(const ColWs& w, int s, int k, const TV& x) { w.at(2 * s, k) = x.v; w.at(2 * s + 1, k) = (double)x.id; }
+  HD static TV get(const ColWs& w, int s, int k, Tape* t) { return TV(w.at(2 * s, k), 1., (int)w.at(2 * s + 1, k), t); }
+  HD static void set(const ColWs& w, int s, int k, const TV& x0) { const TV x = tv_unit(x0); w.at(2 * s, k) = x.v; w.at(2 * s + 1, k) = (double)x.id; }
 };
 
 // ---- the three ways a column operator touches its fields: f[slot] element (i, j, k) of the thread's column
@@ -99,11 +109,11 @@ struct ColTL {
 struct ColAD {
   typedef TV T;
   const Geom& g; const Fld* f; int tile, i, j; Tape* tape;
-  HD TV ld(int slot, int k) const { return TV(f[slot].t[fidx(g, f[slot], tile, i, j, k)], tape->push(-2 - slot, k, 0., 0.), tape); }
+  HD TV ld(int slot, int k) const { return TV(f[slot].t[fidx(g, f[slot], tile, i, j, k)], 1., tape->push(-2 - slot, k, 0., 0.), tape); }
   // trajectory is NOT rewritten (the backward sweep must not disturb it); the field's incoming adjoint moves onto the variable
   HD void st(int slot, int k, const TV& x) const {
     const size_t n = fidx(g, f[slot], tile, i, j, k);
-    if (x.id >= 0) tape->ad(x.id) += f[slot].p[n];
+    if (x.id >= 0) tape->ad(x.id) += x.s * f[slot].p[n];
     f[slot].p[n] = 0.;
   }
   HD TV wget(const ColWs& w, int s, int k) const { return WsIO<TV>::get(w, s, k, tape); }

@@ -478,11 +478,13 @@ inline NhColArgs Dycore::nh_args(double dt_) const {
 // column operator of nh.h as a program step.  when: 0 every acoustic step, 2 the last only, 3 vertical remap (last_call = last k_split step)
 inline void Dycore::add_col(Program& P, const char* group, int kind, const NhColArgs& a, Rect r, Rect skip, int when) {
   Dycore* self = this;
-  static const char* tags[] = {"riem_c", "riem3", "edge_profile", "zh_init", "p_ring", "remap_field_nh", "remap_press_nh"};
+  static const char* tags[][3] = {{"riem_c.nl", "riem_c.tl", "riem_c.ad"}, {"riem3.nl", "riem3.tl", "riem3.ad"}, {"edge_profile.nl", "edge_profile.tl", "edge_profile.ad"},
+                                  {"zh_init.nl", "zh_init.tl", "zh_init.ad"}, {"p_ring.nl", "p_ring.tl", "p_ring.ad"},
+                                  {"remap_field_nh.nl", "remap_field_nh.tl", "remap_field_nh.ad"}, {"remap_press_nh.nl", "remap_press_nh.tl", "remap_press_nh.ad"}};
   P.push_back(Op{group, [self, kind, a, r, skip, when](Exec& e, int mode) {
     if (when == 2 && !self->last_acoustic) return;
     NhColArgs b = a; b.last_call = (when == 3 ? self->remap_last : self->last_acoustic) ? 1 : 0;
-    run_nh_col(e, mode, b, kind, r, skip, tags[kind]);
+    run_nh_col(e, mode, b, kind, r, skip, tags[kind][mode]);
   }});
 }
 inline bool Dycore::nh_overflow() {

@@ -256,6 +256,51 @@ HD void edge_col(const IO& io, const NhColArgs& a, const ColWs& ws) {
   }
 }
 
+// EDGE_PROFILE is linear with coefficients that depend on the reference thicknesses only: its adjoint is the transposed
+// solve, written out instead of taped.  Consumes f[2].p, f[3].p (zeroed), accumulates into f[0].p, f[1].p.
+HD void edge_col_ad(const NhColArgs& a, const ColWs& ws, int tile, int i, int j) {
+  const Geom& g = a.g; const int km = g.npz;
+  auto dp0 = [&](int k) { return a.lev[k - 1].dp_ref; };
+  // raw workspace slots: 0 bet(k), 1 gam(k), 2 ratio gk(k), 3/4 the two adjoint vectors
+  const double g0 = dp0(2) / dp0(1), bet1 = g0 * (g0 + 0.5), xt1 = 2. * g0 * (g0 + 1.);
+  double gam = (1. + g0 * (g0 + 1.5)) / bet1, gk = g0;
+  ws.at(0, 1) = bet1; ws.at(1, 1) = gam;
+  for (int k = 2; k <= km; ++k) {
+    gk = dp0(k - 1) / dp0(k);
+    const double bet = 2. + 2. * gk - gam;
+    gam = gk / bet;
+    ws.at(0, k) = bet; ws.at(1, k) = gam; ws.at(2, k) = gk;
+  }
+  const double a_bot = 1. + gk * (gk + 1.5), xb = 2. * gk * (gk + 1.), xt2 = gk * (gk + 0.5) - a_bot * gam;
+  for (int m = 0; m < 2; ++m) {
+    const Fld &fi = a.f[m], &fo = a.f[2 + m];
+    // incoming adjoint, then the transposed back-substitution (k ascending)
+    double prev = fo.p[fidx(g, fo, tile, i, j, 1)];
+    fo.p[fidx(g, fo, tile, i, j, 1)] = 0.;
+    ws.at(3, 1) = prev;
+    for (int k = 1; k <= km; ++k) {
+      const size_t n = fidx(g, fo, tile, i, j, k + 1);
+      const double cur = fo.p[n] - ws.at(1, k) * prev;
+      fo.p[n] = 0.;
+      ws.at(3, k + 1) = cur; prev = cur;
+    }
+    // bottom closure, then the transposed elimination (k descending); q_ad(k) collects up to three contributions
+    const double eb = prev;                       // adjoint of e(km+1)
+    double ek = ws.at(3, km) - a_bot / xt2 * eb;  // adjoint of e(km) before the closure
+    double qk = xb / xt2 * eb, qkm1 = eb / xt2;   // contributions to q(km), q(km-1)
+    for (int k = km; k >= 2; --k) {
+      const double bet = ws.at(0, k), gkk = ws.at(2, k);
+      qk += 3. * gkk / bet * ek;
+      fi.p[fidx(g, fi, tile, i, j, k)] += qk;
+      qk = qkm1 + 3. / bet * ek; qkm1 = 0.;
+      ek = ws.at(3, k - 1) - ek / bet;
+    }
+    // here qk holds the pending contribution to q(1); k = 1: e(1) = (xt1 q(1) + q(2)) / bet1
+    fi.p[fidx(g, fi, tile, i, j, 1)] += qk + xt1 / bet1 * ek;
+    fi.p[fidx(g, fi, tile, i, j, 2)] += ek / bet1;
+  }
+}
+
 // interface heights from the layer thicknesses.  f: 0 delz (km)   ->   1 zh (km+1)
 template <class IO>
 HD void zh_init_col(const IO& io, const NhColArgs& a, double hs) {
@@ -445,6 +490,7 @@ struct NhColFn {
     const size_t col = (size_t)z * a.g.plane + a.g.idx(i, j);
     const ColWs ws{a.ws + col, a.ws_stride, a.g.npz + 2};
     const double hs = a.hs ? a.hs[col] : 0.;
+    if (KIND == NHC_EDGE && MODE == MODE_AD) { edge_col_ad(a, ws, z, i, j); return; }
     if (MODE == MODE_NL) { ColNL io{a.g, a.f, z, i, j, nullptr}; body(io, ws, hs); }
     else if (MODE == MODE_TL) { ColTL io{a.g, a.f, z, i, j, nullptr}; body(io, ws, hs); }
     else {
