@@ -17,7 +17,10 @@ def main():
     from common import CubeCase
     from groups import cube_step_state, masked
     from fv3_jedi_linearmodel_amd._lib import set_transport_callback, set_allreduce_callback
+    nh = os.environ.get("FV3LM_DIST_NH", "0") == "1"      # non-hydrostatic: w, delz prognostic; w / heights / pressures join the exchanges
     kw = dict(n=8, npz=6, n_split=2, k_split=2, backend="emul", nq=2)
+    if nh:
+        kw.update(hydrostatic=0, hord_ks_traj=0, hord_ks_pert=0, dt=1200.0)
     ref = CubeCase(**kw)                       # whole cube in this process
     c = CubeCase(rank=rank, world=world, **kw)   # this rank's faces
 
@@ -40,8 +43,12 @@ def main():
     set_allreduce_callback(c.lib, allmax)
 
     F = c.faces
-    names = ["u", "v", "pt", "delp"] + ["q%d" % (n + 1) for n in range(c.nq)]
+    names = ["u", "v", "pt", "delp"] + (["w", "delz"] if nh else []) + ["q%d" % (n + 1) for n in range(c.nq)]
     T, P = cube_step_state(ref)
+    if nh:
+        import nh_checks
+        Tn, Pn = nh_checks.cube_nh_state(ref)
+        T.update(w=Tn[4], delz=Tn[5]); P.update(w=Pn[4], delz=Pn[5])
     rk = {"u": "U", "v": "V"}
     rng = np.random.default_rng(13)
     dy = {n: masked(ref, rng.standard_normal(T[n].shape), rk.get(n, "A")) for n in names}
