@@ -508,6 +508,8 @@ struct MetY { const double* p; const Ctx& c; int tile, i; HD double operator()(i
 // launch; EDGE = true: the strips next to the face edges (and the single-tile periodic case never uses it).
 template <bool EDGE>
 struct TpPpmX_ {
+  static constexpr bool LDS_TILE = !EDGE;     // bulk launch: tile + halo staged through LDS (exec.h)
+  static constexpr int LDS_BY = 4;
   STAGE_BASE(EDGE ? "TpPpmXe" : "TpPpmX", 2, 1)   // in: q crx   out: flux
   STAGE_DEFAULTS_ON
   int hsel; int cdir = 0;        // cdir = 1: the inner sweep, which covers the halo rows (copy_corners(q,1), :162-171)
@@ -524,6 +526,8 @@ struct TpPpmX_ {
 };
 template <bool EDGE>
 struct TpPpmY_ {
+  static constexpr bool LDS_TILE = !EDGE;     // bulk launch: tile + halo staged through LDS (exec.h)
+  static constexpr int LDS_BY = 16;
   STAGE_BASE(EDGE ? "TpPpmYe" : "TpPpmY", 2, 1)   // in: q cry   out: flux
   STAGE_DEFAULTS_ON
   int hsel; int cdir = 0;        // cdir = 2: the inner sweep, which covers the halo columns (copy_corners(q,2), :138-147)

@@ -52,8 +52,24 @@ def pmc(dbf, dbw, out):
     print("wrote", out, "kernels:", len(rows))
 
 
+def counters(db, out):
+    """any --pmc pass: per kernel, dispatch count and the average of every collected counter per dispatch"""
+    cur = sqlite3.connect(db).cursor()
+    names = [r[0] for r in cur.execute("select distinct counter_name from counters_collection order by 1")]
+    tab = {}
+    for k, c, n, v in cur.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name"):
+        tab.setdefault(k, {})[c] = (n, v)
+    with open(out, "w") as f:
+        f.write("kernel,dispatches," + ",".join(names) + "\n")
+        for k in sorted(tab, key=lambda k: -sum(n * v for n, v in tab[k].values())):
+            f.write("%s,%d,%s\n" % (short(k), max(n for n, _ in tab[k].values()), ",".join("%.4g" % tab[k].get(c, (0, 0.0))[1] for c in names)))
+    print("wrote", out, "kernels:", len(tab))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "counters":
+        counters(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
