@@ -348,12 +348,15 @@ __global__ void __launch_bounds__(BX* BY) k_stage_tl(S s, Ctx c, Rect R, int tr)
   if (i <= R.i1 && j <= R.j1) body_tl(s, c, i, j, blockIdx.z);
 }
 // ---- LDS-staged forward launch (nonlinear / tangent) ----------------------------------------------------------------------
-// A stage opts in with `static constexpr bool LDS_TILE = true` (bulk stencil stages whose reads stay inside their declared
+// A stage opts in with `static constexpr bool LDS_FW / LDS_AD = true` (bulk stencil stages whose reads stay inside their declared
 // box).  Every input with a horizontal stencil is loaded ONCE per block — tile + halo, all lanes issuing their loads
 // back to back — into LDS; the stencil then reads LDS.  A 64x4 block of a 6-point y-stencil goes from 7 global loads per
 // point to 2.25, of an x-stencil to 1.1.  The block is 64 x S::LDS_BY (taller for y-stencils: less halo per output row).
-template <class S, class = void> struct lds_tile { static constexpr bool value = false; };
-template <class S> struct lds_tile<S, typename std::enable_if<S::LDS_TILE>::type> { static constexpr bool value = true; };
+// opt-in per stage and per mode (measured: small-box stages with many inputs lose occupancy to their tiles in the adjoint)
+template <class S, class = void> struct lds_fw { static constexpr bool value = false; };
+template <class S> struct lds_fw<S, typename std::enable_if<S::LDS_FW>::type> { static constexpr bool value = true; };
+template <class S, class = void> struct lds_ad { static constexpr bool value = false; };
+template <class S> struct lds_ad<S, typename std::enable_if<S::LDS_AD>::type> { static constexpr bool value = true; };
 template <class S>
 struct TileLayout {
   HD static constexpr bool staged(int M) { return (S::box(M).di0 != 0 || S::box(M).di1 != 0 || S::box(M).dj0 != 0 || S::box(M).dj1 != 0) && S::box(M).dk0 == 0 && S::box(M).dk1 == 0; }
@@ -394,7 +397,7 @@ struct TileLoad {
       constexpr int W = L::w(M), N = W * L::h(M);
       for (int e = tid; e < N; e += BX * S::LDS_BY) {
         const int gi = bi0 + S::box(M).di0 + e % W, gj = bj0 + S::box(M).dj0 + e / W;
-        if (gi >= c.g.isd() && gi <= c.g.ied() + 1 && gj >= c.g.jsd() && gj <= c.g.jed() + 1) {
+        if (f.t && gi >= c.g.isd() && gi <= c.g.ied() + 1 && gj >= c.g.jsd() && gj <= c.g.jed() + 1) {   // f.t null: input not handed to this instance
           const size_t n = base + c.g.idx(gi, gj);
           lds[L::off(M) + e] = f.t[n];
           if constexpr (TL) lds[L::total + L::off(M) + e] = f.p ? f.p[n] : 0.0;
@@ -573,7 +576,7 @@ template <class S>
 void run_tl(Exec& ex, const S& s, const Ctx& c) {
   Rect R = rect_union(s.orect, S::NOUT);
   ex.mark_begin(S::name(), ".tl", stage_bytes(s, c, R, MODE_TL));
-  if constexpr (lds_tile<S>::value) { if (strip_tr(R) == 0) {
+  if constexpr (lds_fw<S>::value) if constexpr (TileLayout<S>::total > 0 && TileLayout<S>::total * 16 <= 60000) { if (strip_tr(R) == 0) {
     launch_fw_lds<S, true>(ex, s, c, R);
     ex.mark_end(); ex.launches++; return; } }
   hipLaunchKernelGGL(k_stage_tl<S>, grid_for(R, c.g.ntile * (s.k1 - s.k0 + 1), strip_tr(R)), dim3(BX, BY), 0, ex.stream, s, c, R, strip_tr(R));
@@ -587,7 +590,7 @@ void run_ad(Exec& ex, const S& s, const Ctx& c) {
   int nkmax = 0;
   for (int m = 0; m < S::NIN; ++m) if (s.in[m].nk > nkmax) nkmax = s.in[m].nk;
   ex.mark_begin(S::name(), ".ad", stage_bytes(s, c, R, MODE_AD));
-  if constexpr (lds_tile<S>::value) if constexpr (TileLayoutAd<S>::ok()) { if (strip_tr(Q) == 0) {
+  if constexpr (lds_ad<S>::value) if constexpr (TileLayoutAd<S>::ok() && TileLayoutAd<S>::total * 8 <= 60000) { if (strip_tr(Q) == 0) {
     bool same = true;
     for (int m = 0; m < S::NIN; ++m) if (s.in[m].nk != s.in[0].nk) same = false;
     if (same) {

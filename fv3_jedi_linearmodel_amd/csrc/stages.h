@@ -5,6 +5,7 @@
 // reference; used with the doubly-periodic single tile), 1 = whole cube face with all the
 // `is .EQ. 1` / `j .EQ. npy` / corner branches of the reference (helpers in edges.h).
 #pragma once
+#include <type_traits>
 #include "exec.h"
 #include "edges.h"
 
@@ -39,8 +40,15 @@ namespace fv3 {
 // A stage body written with `template <bool EDGE, ...> eval_e` becomes two stage types: Edged<D,false> for the bulk launch
 // (no face edge within reach of its outputs: every edge branch and corner view compiled out) and Edged<D,true> for the
 // strips next to the face edges (dycore.h add_face).
+template <class D, class = void> struct d_lds_fw { static constexpr bool v = false; };
+template <class D> struct d_lds_fw<D, typename std::enable_if<D::LDS_FW_OK>::type> { static constexpr bool v = true; };
+template <class D, class = void> struct d_lds_ad { static constexpr bool v = false; };
+template <class D> struct d_lds_ad<D, typename std::enable_if<D::LDS_AD_OK>::type> { static constexpr bool v = true; };
 template <class D, bool EDGE>
 struct Edged : D {
+  // bulk launch: tiles + halos staged through LDS for the stages and modes where that measured faster (exec.h)
+  static constexpr bool LDS_FW = !EDGE && d_lds_fw<D>::v, LDS_AD = !EDGE && d_lds_ad<D>::v;
+  static constexpr int LDS_BY = 8;
   Edged() = default;
   Edged(const D& d) : D(d) {}
   static constexpr int NALIAS = EDGE ? D::NALIAS : 0;
@@ -219,6 +227,7 @@ typedef Edged<CswDivgD, true> CswDivgE;
 // first-order upwind transport of delp, pt on the C grid (sw_core_tlm.F90:739-808); the corner halo of
 // delp/pt is read through fill2_4corners' x-view for the x-fluxes and y-view otherwise.
 struct CswTransportD {
+  static constexpr bool LDS_AD_OK = true;
   STAGE_BASE("CswTransport", 4, 2)   // in: delp pt utf vtf   out: delpc ptc
   HD static constexpr bool uses(int M, int di, int dj, int) { return M >= 2 || di == 0 || dj == 0; }
   HD static constexpr unsigned wants(int M) { return M == 1 ? 0x2u : 0x3u; }
@@ -391,6 +400,7 @@ struct DswWinds {
 // (:2717-2751, :2768-2776, :2795-2803, :2821-2830).  ut on the two rows next to a south/north edge is
 // left 0 here (pass B).
 struct DswWindsAD {
+  static constexpr bool LDS_FW_OK = true;
   STAGE_COMMON("DswWindsA", 2, 2)   // in: uc vc   out: ut_a vt_a
   double dt;
   HD static constexpr Box box(int M) { return M == 0 ? Box{0, 1, -1, 0, 0, 0} : Box{-1, 0, 0, 1, 0, 0}; }
@@ -508,7 +518,7 @@ struct MetY { const double* p; const Ctx& c; int tile, i; HD double operator()(i
 // launch; EDGE = true: the strips next to the face edges (and the single-tile periodic case never uses it).
 template <bool EDGE>
 struct TpPpmX_ {
-  static constexpr bool LDS_TILE = !EDGE;     // bulk launch: tile + halo staged through LDS (exec.h)
+  static constexpr bool LDS_FW = !EDGE, LDS_AD = !EDGE;     // bulk launch: tile + halo staged through LDS (exec.h)
   static constexpr int LDS_BY = 4;
   STAGE_BASE(EDGE ? "TpPpmXe" : "TpPpmX", 2, 1)   // in: q crx   out: flux
   STAGE_DEFAULTS_ON
@@ -526,7 +536,7 @@ struct TpPpmX_ {
 };
 template <bool EDGE>
 struct TpPpmY_ {
-  static constexpr bool LDS_TILE = !EDGE;     // bulk launch: tile + halo staged through LDS (exec.h)
+  static constexpr bool LDS_FW = !EDGE, LDS_AD = !EDGE;     // bulk launch: tile + halo staged through LDS (exec.h)
   static constexpr int LDS_BY = 16;
   STAGE_BASE(EDGE ? "TpPpmYe" : "TpPpmY", 2, 1)   // in: q cry   out: flux
   STAGE_DEFAULTS_ON
@@ -580,6 +590,7 @@ HD void damp_of(const LevelParams& l, int sel, int& nord, double& damp_c) {
   else { nord = -1; damp_c = 0.; }
 }
 struct TpD2D {
+  static constexpr bool LDS_FW_OK = true;
   STAGE_BASE("TpD2", 1, 1)   // in: q   out: d2b  (is-1..ie+1, js-1..je+1); zero where the level does not use nord=1
   HD static constexpr bool uses(int, int di, int dj, int) { return di == 0 || dj == 0; }
   HD static constexpr unsigned wants(int) { return 0x1u; }
@@ -682,6 +693,7 @@ typedef Edged<DswKeWindsD, false> DswKeWinds;
 typedef Edged<DswKeWindsD, true> DswKeWindsE;
 // KE = 0.5*(vb*ytp_v + ub*xtp_u), face corners from the edge-normal winds (sw_core_tlm.F90:3197-3273)
 struct DswKeD {
+  static constexpr bool LDS_FW_OK = true;
   STAGE_COMMON("DswKe", 6, 1)   // in: vb ub u v ut vt   out: ke
   double dt;
   HD static constexpr Box box(int M) { return M < 2 ? Box{0, 0, 0, 0, 0, 0} : M == 2 ? Box{-3, 2, 0, 0, 0, 0} : M == 3 ? Box{0, 0, -3, 2, 0, 0} : M == 4 ? Box{0, 0, -1, 0, 0, 0} : Box{-1, 0, 0, 0, 0, 0}; }
@@ -771,6 +783,7 @@ typedef Edged<DdBD, true> DdBE;
 // a2b_ord4 (a2b_edge_tlm.F90:48-542): (A) the x- and y-interpolated edge-centred values qx, qy
 template <bool EDGE>
 struct A2bA_ {
+  static constexpr bool LDS_FW = !EDGE, LDS_AD = false; static constexpr int LDS_BY = 8;
   STAGE_BASE(EDGE ? "A2bAe" : "A2bA", 1, 2)   // in: q   out: qx qy
   STAGE_NO_ALIAS
   HD static constexpr bool uses(int, int di, int dj, int) { return di == 0 || dj == 0; }
@@ -892,6 +905,7 @@ struct DdC {   // Smagorinsky-type coefficient and damping term added to KE (:79
 };
 // del6_vt_flux inner Laplacian without the damp factor (sw_core_tlm.F90:3747-3776, nord_v = 1)
 struct Del6AD {
+  static constexpr bool LDS_FW_OK = true;
   STAGE_BASE("Del6A", 1, 1)   // in: wk   out: d2b
   HD static constexpr bool uses(int, int di, int dj, int) { return di == 0 || dj == 0; }
   HD static constexpr unsigned wants(int) { return 0x1u; }
