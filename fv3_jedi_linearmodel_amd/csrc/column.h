@@ -37,6 +37,7 @@ HD void geopk_col(const GeopkArgs& a, int i, int j, int tile) {
   const double ptk = pow(a.ptop, a.akap), peln1 = log(a.ptop);
   st(a.pe, b1, p1d); st(a.peln, b1, T(peln1)); st(a.pk, b1, T(ptk));
   T pkm = T(ptk), lnm = T(peln1);
+#pragma unroll 4
   for (int k = 2; k <= km + 1; ++k) {
     p1d = p1d + ld(a.delp, b0 + (size_t)(k - 2) * pl);
     T lp = dlog(p1d), pkk = dexp(a.akap * lp);
@@ -46,10 +47,13 @@ HD void geopk_col(const GeopkArgs& a, int i, int j, int tile) {
   }
   T g1d = T(a.hs[(size_t)tile * pl + o]);
   st(a.gz, b1 + (size_t)km * pl, g1d);
+  T pk1 = pkm;                                     // pk(km+1), still in a register; pk(k) is loaded once per level
+#pragma unroll 4
   for (int k = km; k >= 1; --k) {
-    T pk1 = ld(a.pk, b1 + (size_t)k * pl), pk0 = ld(a.pk, b1 + (size_t)(k - 1) * pl);
+    const T pk0 = ld(a.pk, b1 + (size_t)(k - 1) * pl);
     g1d = g1d + a.cp_air * ld(a.pt, b0 + (size_t)(k - 1) * pl) * (pk1 - pk0);
     st(a.gz, b1 + (size_t)(k - 1) * pl, g1d);
+    pk1 = pk0;
   }
 }
 // adjoint: consumes gz.p, pk.p, pe.p, peln.p, pkz.p; accumulates into delp.p, pt.p

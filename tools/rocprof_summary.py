@@ -17,7 +17,13 @@ def short(name):
     m = re.search(r"k_stage_(nl|tl|ad_alias|ad)<fv3::([A-Za-z0-9_]+(?:<[a-z]+>)?)", name)
     if m:
         return "%s.%s" % (m.group(2).replace("_<true>", "e").replace("_<false>", ""), m.group(1))
-    m = re.search(r"k_points<fv3::([A-Za-z0-9_]+)", name)
+    m = re.search(r"k_stage_fw_lds<fv3::(?:Edged<fv3::)?([A-Za-z0-9_]+?)D?(?:_?<|,)[^>]*?(true|false)\s*>*\s*,\s*(true|false)>", name)
+    if m:       # LDS-staged forward launch of a bulk stage: last template argument true = tangent, false = nonlinear
+        return "%s.%s(lds)" % (m.group(1).rstrip("_"), "tl" if m.group(3) == "true" else "nl")
+    m = re.search(r"k_stage_ad_lds<fv3::(?:Edged<fv3::)?([A-Za-z0-9_]+?)D?(?:_?<|,)", name)
+    if m:
+        return "%s.ad(lds)" % m.group(1).rstrip("_")
+    m = re.search(r"k_points<fv3::([A-Za-z0-9_]+(?:<[^>]*>)?)", name)
     if m:
         return "points<%s>" % m.group(1)
     return name.split("(")[0][:60]
