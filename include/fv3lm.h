@@ -129,7 +129,9 @@ int fv3lm_dyn_core(fv3lm_handle* h, int mode);   /* DYN_CORE_TLM dyn_core_tlm.F9
  *                  (which=1) at t; out: both advanced to t+dt.
  *  fv3lm_step_nl : nonlinear sweep that also stores the stage checkpoints (FV_DYNAMICS_FWD role, :507).
  *  fv3lm_step_ad : FV_DYNAMICS_BWD + compute_fv3_pressures_bwd (:615-638); call after fv3lm_step_nl on the
- *                  same trajectory.  In: adjoint of the state at t+dt (which=1); out: adjoint at t. */
+ *                  same trajectory.  In: adjoint of the state at t+dt (which=1); out: adjoint at t.  The forward
+ *                  sweep's checkpoints stay valid: further fv3lm_step_ad calls on the same trajectory need no new
+ *                  fv3lm_step_nl (the role of cp_iter, utils/tapenade/tapenade_iter.F90). */
 int fv3lm_step_tl(fv3lm_handle* h);
 int fv3lm_step_nl(fv3lm_handle* h);
 int fv3lm_step_ad(fv3lm_handle* h);

@@ -580,3 +580,32 @@ def cube_check_tracer(c, mode, tol, scale=1.0):
     for n, a in zip(ins_n, iad):
         e = relerr(c.dy.get(n, 1), a)
         assert e < tol, (n, "ad", e)
+
+
+def repeated_adjoint(c, seed=17):
+    """One forward sweep (step_nl), several backward sweeps: the checkpoints and trajectory slots of the forward sweep stay
+    valid, so further adjoint applications on the same trajectory need no new forward sweep (the role of cp_iter in the
+    reference, utils/tapenade/tapenade_iter.F90).  Returns the worst relative difference between the second backward sweep
+    and a fresh step_nl + step_ad with the same adjoint input."""
+    T, _ = step_state(c)
+    names = ["u", "v", "pt", "delp"] + ["q%d" % (n + 1) for n in range(c.nq)]
+    rk = {"u": "U", "v": "V"}
+    rng = np.random.default_rng(seed)
+    ya = {n: masked(c, rng.standard_normal(T[n].shape), rk.get(n, "A")) for n in names}
+    yb = {n: masked(c, rng.standard_normal(T[n].shape), rk.get(n, "A")) for n in names}
+
+    def backward(y):
+        for n in names:
+            c.dy.put(n, y[n][None], 1)
+        c.dy.step_ad()
+        return {n: c.dy.get(n, 1)[0].copy() for n in names}
+    for n in names:
+        c.dy.put(n, T[n][None], 0)
+    c.dy.step_nl()
+    backward(ya)
+    second = backward(yb)           # no step_nl in between
+    for n in names:
+        c.dy.put(n, T[n][None], 0)
+    c.dy.step_nl()
+    fresh = backward(yb)
+    return max(relerr(second[n], fresh[n]) for n in names)

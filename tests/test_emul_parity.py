@@ -99,6 +99,11 @@ def test_dot_product_step(case_q):
     assert abs(lhs - rhs) <= 1e-12 * abs(lhs), (lhs, rhs)
 
 
+def test_repeated_adjoint_on_one_forward_sweep(case_q):
+    from groups import repeated_adjoint
+    assert repeated_adjoint(case_q) < 1e-13
+
+
 def test_tracer_subcycling(case_q):
     """accumulated Courant number >= 1: nsplt = 2 with per-level sub-step counts (fv_tracer2d_tlm.F90:1306-1345)"""
     check_tracer(case_q, TL, 1e-11, scale=10.0)

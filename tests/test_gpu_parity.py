@@ -65,6 +65,11 @@ def case_q():
     return Case(nx=12, ny=10, npz=10, n_split=2, k_split=2, dt=1800.0, backend="hip", nq=3)
 
 
+def test_repeated_adjoint_on_one_forward_sweep(case_q):
+    from groups import repeated_adjoint
+    assert repeated_adjoint(case_q) < 1e-13
+
+
 @pytest.mark.parametrize("mode", [TL, AD])
 def test_tracer_2d(case_q, mode):
     from groups import check_tracer
