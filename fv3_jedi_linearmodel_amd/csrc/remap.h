@@ -130,7 +130,8 @@ HD void map_col_ad(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const 
     ws.at(S.SF, km + 1) = qe; ws.at(S.SE, km + 1) = qe;
     for (int k = km; k >= 1; --k) { qe = ws.at(S.SF, k) - ws.at(S.SG, k) * qe; ws.at(S.SE, k) = qe; }
   }
-  for (int k = 0; k <= km + 1; ++k) { ws.at(S.SDP, k) = 0.; ws.at(S.SGA, k) = 0.; ws.at(S.SFA, k) = 0.; ws.at(S.SEA, k) = 0.; ws.at(S.SDA, k) = 0.; }
+  // accumulated by the mapping loop; SFA / SGA are written before they are read, the sweeps below carry their recurrences in registers
+  for (int k = 0; k <= km + 1; ++k) { ws.at(S.SDP, k) = 0.; ws.at(S.SEA, k) = 0.; }
   // ---- reverse of the mapping loop (targets are independent; the search is replayed in order)
   auto addq = [&](int l, double a1_ad, double a2_ad, double a3_ad, double a4_ad) {   // a4 = 3(2 a1 - a2 - a3)
     ws.at(S.SQ1, l) += a1_ad + 6. * a4_ad;
@@ -194,53 +195,59 @@ HD void map_col_ad(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const 
     ws.at(S.SP2, k) += pl_ad / dpl; ws.at(S.SP1, l) -= pl_ad / dpl; ws.at(S.SDP, l) -= pl * pl_ad / dpl;
   }
   // ---- reverse of the back substitution  qe(k) = qf(k) - gam(k) qe(k+1), k = km..1
-  for (int k = 1; k <= km; ++k) {
-    const double e = ws.at(S.SEA, k);
-    ws.at(S.SFA, k) += e;
-    ws.at(S.SGA, k) -= ws.at(S.SE, k + 1) * e;
-    ws.at(S.SEA, k + 1) -= ws.at(S.SG, k) * e;
+  double fa_bot;
+  {
+    double carry = 0.;     // pending update of qe_ad(k) from level k-1
+    for (int k = 1; k <= km; ++k) {
+      const double e = ws.at(S.SEA, k) + carry;
+      ws.at(S.SFA, k) = e;
+      ws.at(S.SGA, k) = -ws.at(S.SE, k + 1) * e;
+      carry = -ws.at(S.SG, k) * e;
+    }
+    fa_bot = ws.at(S.SEA, km + 1) + carry;     // adjoint of qf(km+1)
   }
-  ws.at(S.SFA, km + 1) += ws.at(S.SEA, km + 1);
-  // ---- bottom edge value
+  // ---- bottom edge value, then the reverse of the forward elimination k = km..2 with qf_ad, gam_ad and the pending
+  //      contributions to q1_ad / dp1_ad of the level above carried in registers
+  double sfa, sga, sda, qpk, qpkm1, dpend = 0.;
   {
     const double d = ws.at(S.SD, km), gamk = ws.at(S.SG, km), qfk = ws.at(S.SF, km);
     const double a_bot = 1. + d * (d + 1.5), den = d * (d + 0.5) - a_bot * gamk;
-    const double fa = ws.at(S.SFA, km + 1);
-    const double numb_ad = fa / den, den_ad = -ws.at(S.SF, km + 1) * fa / den;
+    const double numb_ad = fa_bot / den, den_ad = -ws.at(S.SF, km + 1) * fa_bot / den;
     double d_ad = 2. * (2. * d + 1.) * q1(km) * numb_ad + (2. * d + 0.5) * den_ad;
-    ws.at(S.SQ1, km) += 2. * d * (d + 1.) * numb_ad; ws.at(S.SQ1, km - 1) += numb_ad;
-    double abot_ad = -qfk * numb_ad - gamk * den_ad;
-    ws.at(S.SFA, km) -= a_bot * numb_ad;
-    ws.at(S.SGA, km) -= a_bot * den_ad;
+    qpk = 2. * d * (d + 1.) * numb_ad; qpkm1 = numb_ad;
+    const double abot_ad = -qfk * numb_ad - gamk * den_ad;
+    sfa = ws.at(S.SFA, km) - a_bot * numb_ad;
+    sga = ws.at(S.SGA, km) - a_bot * den_ad;
     d_ad += (2. * d + 1.5) * abot_ad;
-    ws.at(S.SDA, km) += d_ad;
+    sda = d_ad;
   }
-  // ---- reverse of the forward elimination, k = km..2
   for (int k = km; k >= 2; --k) {
     const double bet = ws.at(S.SB, k), gam = ws.at(S.SG, k), qf = ws.at(S.SF, k), d4 = ws.at(S.SD, k);
-    const double ga = ws.at(S.SGA, k);
-    double d4_ad = ws.at(S.SDA, k) + ga / bet;
-    double bet_ad = -gam * ga / bet;
-    const double t = ws.at(S.SFA, k) / bet;
-    ws.at(S.SQ1, k - 1) += 3. * t; ws.at(S.SQ1, k) += 3. * d4 * t;
+    double d4_ad = sda + sga / bet;
+    double bet_ad = -gam * sga / bet;
+    const double t = sfa / bet;
+    ws.at(S.SQ1, k) += qpk + 3. * d4 * t;
+    qpk = qpkm1 + 3. * t; qpkm1 = 0.;
     d4_ad += 3. * q1(k) * t;
-    ws.at(S.SFA, k - 1) -= t;
     bet_ad -= qf * t;
-    d4_ad += 2. * bet_ad; ws.at(S.SGA, k - 1) -= bet_ad;
+    d4_ad += 2. * bet_ad;
+    sfa = ws.at(S.SFA, k - 1) - t;
+    sga = ws.at(S.SGA, k - 1) - bet_ad;
+    sda = 0.;
     const double dpk = pe1(k + 1) - pe1(k);
-    ws.at(S.SDP, k - 1) += d4_ad / dpk; ws.at(S.SDP, k) -= d4 * d4_ad / dpk;
+    ws.at(S.SDP, k) += dpend - d4 * d4_ad / dpk;
+    dpend = d4_ad / dpk;
   }
   {
     const double gam1 = ws.at(S.SG, 1), qf1 = ws.at(S.SF, 1);
-    const double ga = ws.at(S.SGA, 1);
-    double grat_ad = (2. * grat + 1.5) / bet1 * ga;
-    double bet_ad = -gam1 * ga / bet1;
-    const double t = ws.at(S.SFA, 1) / bet1;
+    double grat_ad = (2. * grat + 1.5) / bet1 * sga;
+    double bet_ad = -gam1 * sga / bet1;
+    const double t = sfa / bet1;
     bet_ad -= qf1 * t;
     grat_ad += 2. * (2. * grat + 1.) * q1(1) * t;
-    ws.at(S.SQ1, 1) += 2. * grat * (grat + 1.) * t; ws.at(S.SQ1, 2) += t;
+    ws.at(S.SQ1, 1) += qpk + 2. * grat * (grat + 1.) * t; ws.at(S.SQ1, 2) += t;
     grat_ad += (2. * grat + 0.5) * bet_ad;
-    ws.at(S.SDP, 2) += grat_ad / dp1_1; ws.at(S.SDP, 1) -= grat * grat_ad / dp1_1;
+    ws.at(S.SDP, 2) += grat_ad / dp1_1; ws.at(S.SDP, 1) += dpend - grat * grat_ad / dp1_1;
   }
   for (int k = 1; k <= km; ++k) { const double a = ws.at(S.SDP, k); ws.at(S.SP1, k + 1) += a; ws.at(S.SP1, k) -= a; }
 }
