@@ -114,7 +114,7 @@ HD void map_col_ad(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const 
   const double grat = dp1_2 / dp1_1, bet1 = grat * (grat + 0.5);
   {
     double qf = ((grat + grat) * (grat + 1.) * q1(1) + q1(2)) / bet1, gam = (1. + grat * (grat + 1.5)) / bet1;
-    ws.at(S.SF, 1) = qf; ws.at(S.SG, 1) = gam; ws.at(S.SB, 1) = bet1; ws.at(S.SD, 1) = grat;
+    ws.at(S.SF, 1) = qf; ws.at(S.SG, 1) = gam; ws.at(S.SD, 1) = grat;
     double d4 = grat, a_prev = q1(1), dp_prev = dp1_1;
     for (int k = 2; k <= km; ++k) {
       const double dpk = pe1(k + 1) - pe1(k), ak_ = q1(k);
@@ -122,7 +122,7 @@ HD void map_col_ad(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const 
       const double bet = 2. + d4 + d4 - gam;
       qf = (3. * (a_prev + d4 * ak_) - qf) / bet;
       gam = d4 / bet;
-      ws.at(S.SF, k) = qf; ws.at(S.SG, k) = gam; ws.at(S.SB, k) = bet; ws.at(S.SD, k) = d4;
+      ws.at(S.SF, k) = qf; ws.at(S.SG, k) = gam; ws.at(S.SD, k) = d4;      // bet is recomputed on the way back
       a_prev = ak_; dp_prev = dpk;
     }
     const double a_bot = 1. + d4 * (d4 + 1.5), den = d4 * (d4 + 0.5) - a_bot * gam;
@@ -139,7 +139,10 @@ HD void map_col_ad(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const 
     ws.at(S.SEA, l + 1) += a3_ad - 3. * a4_ad;
   };
   int k0 = 1;
+  double p2k = 0., p2k1 = 0.;      // pending pe2_ad(k), pe2_ad(k+1): targets are visited in order, one update per level
   for (int k = 1; k <= km; ++k) {
+    if (k > 1) ws.at(S.SP2, k - 1) += p2k;             // level k-1 is complete
+    p2k = p2k1; p2k1 = 0.;
     const double g = q2_ad(k);
     const double p2t = pe2(k), p2b = pe2(k + 1);
     int l; bool found = false;
@@ -155,7 +158,7 @@ HD void map_col_ad(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const 
       addq(l, 0., (1. - 0.5 * s) * g, 0.5 * s * g, (0.5 * s - R3 * w) * g);
       const double pr_ad = (0.5 * Sm - a4 * R3 * (2. * pr + pl)) * g;
       pl_ad = (0.5 * Sm - a4 * R3 * (pr + 2. * pl)) * g;
-      ws.at(S.SP2, k + 1) += pr_ad / dpl; ws.at(S.SP1, l) -= pr_ad / dpl; ws.at(S.SDP, l) -= pr * pr_ad / dpl;
+      p2k1 += pr_ad / dpl; ws.at(S.SP1, l) -= pr_ad / dpl; ws.at(S.SDP, l) -= pr * pr_ad / dpl;
       k0 = l;
     } else {
       const double D = p2b - p2t;
@@ -176,9 +179,9 @@ HD void map_col_ad(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const 
         qsum += dp * Fm;
       }
       const double q2v = qsum / D, qs_ad = g / D, D_ad = -q2v * g / D;
-      ws.at(S.SP2, k + 1) += D_ad; ws.at(S.SP2, k) -= D_ad;
+      p2k1 += D_ad; p2k -= D_ad;
       const double W_ad = E * qs_ad, E_ad = (p1r - p2t) * qs_ad;
-      ws.at(S.SP1, l + 1) += W_ad; ws.at(S.SP2, k) -= W_ad;
+      ws.at(S.SP1, l + 1) += W_ad; p2k -= W_ad;
       addq(l, 0., (1. - 0.5 * (1. + pl)) * E_ad, 0.5 * (1. + pl) * E_ad, (0.5 * (1. + pl) - R3 * (1. + pl * (1. + pl))) * E_ad);
       pl_ad = (0.5 * Sm - a4 * R3 * (1. + 2. * pl)) * E_ad;
       for (int mm = l + 1; mm < mend; ++mm) { ws.at(S.SDP, mm) += q1(mm) * qs_ad; ws.at(S.SQ1, mm) += (pe1(mm + 1) - pe1(mm)) * qs_ad; }
@@ -188,12 +191,13 @@ HD void map_col_ad(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const 
         addq(m, 0., (1. - 0.5 * esl) * F_ad, 0.5 * esl * F_ad, 0.5 * esl * (1. - R23 * esl) * F_ad);
         const double esl_ad = (0.5 * (b3 - b2 + b4 * (1. - R23 * esl)) - 0.5 * esl * b4 * R23) * F_ad;
         dp_ad += esl_ad / dpm; ws.at(S.SDP, m) -= esl * esl_ad / dpm;
-        ws.at(S.SP2, k + 1) += dp_ad; ws.at(S.SP1, m) -= dp_ad;
+        p2k1 += dp_ad; ws.at(S.SP1, m) -= dp_ad;
         k0 = m;
       }
     }
-    ws.at(S.SP2, k) += pl_ad / dpl; ws.at(S.SP1, l) -= pl_ad / dpl; ws.at(S.SDP, l) -= pl * pl_ad / dpl;
+    p2k += pl_ad / dpl; ws.at(S.SP1, l) -= pl_ad / dpl; ws.at(S.SDP, l) -= pl * pl_ad / dpl;
   }
+  ws.at(S.SP2, km) += p2k; ws.at(S.SP2, km + 1) += p2k1;
   // ---- reverse of the back substitution  qe(k) = qf(k) - gam(k) qe(k+1), k = km..1
   double fa_bot;
   {
@@ -221,8 +225,11 @@ HD void map_col_ad(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const 
     d_ad += (2. * d + 1.5) * abot_ad;
     sda = d_ad;
   }
+  double gam_k = ws.at(S.SG, km);
   for (int k = km; k >= 2; --k) {
-    const double bet = ws.at(S.SB, k), gam = ws.at(S.SG, k), qf = ws.at(S.SF, k), d4 = ws.at(S.SD, k);
+    const double gam = gam_k, gam_km1 = ws.at(S.SG, k - 1), qf = ws.at(S.SF, k), d4 = ws.at(S.SD, k);
+    const double bet = 2. + d4 + d4 - gam_km1;
+    gam_k = gam_km1;
     double d4_ad = sda + sga / bet;
     double bet_ad = -gam * sga / bet;
     const double t = sfa / bet;
