@@ -480,7 +480,8 @@ inline void Dycore::add_col(Program& P, const char* group, int kind, const NhCol
   Dycore* self = this;
   static const char* tags[][3] = {{"riem_c.nl", "riem_c.tl", "riem_c.ad"}, {"riem3.nl", "riem3.tl", "riem3.ad"}, {"edge_profile.nl", "edge_profile.tl", "edge_profile.ad"},
                                   {"zh_init.nl", "zh_init.tl", "zh_init.ad"}, {"p_ring.nl", "p_ring.tl", "p_ring.ad"},
-                                  {"remap_field_nh.nl", "remap_field_nh.tl", "remap_field_nh.ad"}, {"remap_press_nh.nl", "remap_press_nh.tl", "remap_press_nh.ad"}};
+                                  {"remap_field_nh.nl", "remap_field_nh.tl", "remap_field_nh.ad"}, {"remap_press_nh.nl", "remap_press_nh.tl", "remap_press_nh.ad"},
+                                  {"remap_w_nh.nl", "remap_w_nh.tl", "remap_w_nh.ad"}};
   P.push_back(Op{group, [self, kind, a, r, skip, when](Exec& e, int mode) {
     if (when == 2 && !self->last_acoustic) return;
     NhColArgs b = a; b.last_call = (when == 3 ? self->remap_last : self->last_acoustic) ? 1 : 0;

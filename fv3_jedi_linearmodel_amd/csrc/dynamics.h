@@ -191,7 +191,7 @@ inline void Dynamics::build_remap_nh() {
   auto args = [&](int what) { NhColArgs a = nh_args(0.); a.ak = ak_dev; a.bk = bk_dev; a.what = what; return a; };
   { NhColArgs a = args(0); a.f[0] = f("pe"); a.f[1] = f("peln"); a.f[2] = f("pt"); a.f[3] = f("delp"); a.f[4] = f("delz"); a.f[5] = t_m;
     add_col(remap_nh, "remap", NHC_RM_FIELD, a, A, Rect{1, 0, 1, 0}, 3); }
-  { NhColArgs a = args(1); a.f[0] = f("pe"); a.f[1] = f("w"); a.f[2] = f("ws"); a.f[3] = w_m; add_col(remap_nh, "remap", NHC_RM_FIELD, a, A, Rect{1, 0, 1, 0}, 3); }
+  { NhColArgs a = args(1); a.f[0] = f("pe"); a.f[1] = f("w"); a.f[2] = f("ws"); a.f[3] = w_m; add_col(remap_nh, "remap", NHC_RM_W, a, A, Rect{1, 0, 1, 0}, 3); }
   { NhColArgs a = args(2); a.f[0] = f("pe"); a.f[1] = f("delz"); a.f[2] = f("delp"); a.f[3] = dz_m; add_col(remap_nh, "remap", NHC_RM_FIELD, a, A, Rect{1, 0, 1, 0}, 3); }
   for (int n = 0; n < nq; ++n) { NhColArgs a = args(3); a.f[0] = f("pe"); a.f[1] = q[n]; a.f[2] = q_m[n]; add_col(remap_nh, "remap", NHC_RM_FIELD, a, A, Rect{1, 0, 1, 0}, 3); }
   { NhColArgs a = args(nq > 0 ? 1 : 0); a.f[0] = f("pe"); a.f[1] = f("peln"); a.f[2] = f("pk"); a.f[3] = t_m; a.f[4] = dz_m; a.f[5] = nq > 0 ? q_m[0] : Fld{};

@@ -440,6 +440,71 @@ HD void remap_field_col_nh(const IO& io, const NhColArgs& a, const ColWs& ws) {
     map_col_io(io, km, ws, 1, io.cst(0.), [&](int k, const T& x) { io.st(2, k, x); });
   }
 }
+// Adjoint of remap_field_col_nh for what = 0, 2, 3 without the tape: the column map itself is the hydrostatic path's
+// hand-written map_col_ad (remap.h), the pre- and post-transforms are differentiated here.  (The w map, iv = -2, stays
+// on the tape: NHC_RM_W.)  Raw workspace slots: 0..12 map_col_ad, 13..15 staged trajectories.
+HD void remap_field_col_nh_ad(const NhColArgs& a, const ColWs& ws, int tile, int i, int j) {
+  const Geom& g = a.g; const int km = g.npz;
+  const MapAdSlots S{0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12};
+  auto F = [&](int sl, int k) -> size_t { return fidx(g, a.f[sl], tile, i, j, k); };
+  auto pe1 = [&](int k) { return a.f[0].t[F(0, k)]; };
+  const double ps = pe1(km + 1);
+  auto pe2 = [&](int k) -> double { return k == 1 ? a.ptop : (k == km + 1 ? ps : a.ak[k - 1] + a.bk[k - 1] * ps); };
+  for (int k = 0; k <= km + 1; ++k) { ws.at(S.SP1, k) = 0.; ws.at(S.SQ1, k) = 0.; ws.at(S.SP2, k) = 0.; }
+  double ps_ad = 0.;
+  if (a.what == 0) {
+    const double rrg = -a.rdgas / a.grav, k1k = a.rdgas / (a.cp_air - a.rdgas);
+    auto pn1 = [&](int k) { return a.f[1].t[F(1, k)]; };
+    for (int k = 1; k <= km; ++k) {
+      const double pt = a.f[2].t[F(2, k)];
+      ws.at(13, k) = pt * exp(k1k * log(rrg * a.f[3].t[F(3, k)] / a.f[4].t[F(4, k)] * pt));
+    }
+    for (int k = 1; k <= km + 1; ++k) ws.at(14, k) = (k == 1 || k == km + 1) ? pn1(k) : log(pe2(k));
+    auto tv = [&](int k) { return ws.at(13, k); };
+    auto pn2 = [&](int k) { return ws.at(14, k); };
+    auto q2ad = [&](int k) { return a.f[5].p[F(5, k)]; };
+    map_col_ad(km, pn1, tv, pn2, q2ad, ws, S);
+    for (int k = 1; k <= km; ++k) {
+      const double ta = ws.at(S.SQ1, k), t = ws.at(13, k), pt = a.f[2].t[F(2, k)];
+      a.f[2].p[F(2, k)] += ta * (t / pt) * (1. + k1k);
+      a.f[3].p[F(3, k)] += ta * t * k1k / a.f[3].t[F(3, k)];
+      a.f[4].p[F(4, k)] -= ta * t * k1k / a.f[4].t[F(4, k)];
+      a.f[5].p[F(5, k)] = 0.;
+    }
+    for (int k = 1; k <= km + 1; ++k) a.f[1].p[F(1, k)] += ws.at(S.SP1, k);
+    a.f[1].p[F(1, 1)] += ws.at(S.SP2, 1); a.f[1].p[F(1, km + 1)] += ws.at(S.SP2, km + 1);
+    for (int k = 2; k <= km; ++k) ps_ad += a.bk[k - 1] * ws.at(S.SP2, k) / pe2(k);
+    a.f[0].p[F(0, km + 1)] += ps_ad;
+    return;
+  }
+  if (a.what == 2) {
+    auto q1 = [&](int k) { return -(a.f[1].t[F(1, k)] / a.f[2].t[F(2, k)]); };
+    auto outq = [&](int k, double x) { ws.at(15, k) = x; };
+    map_col<double>(km, pe1, q1, pe2, outq, ws, 13, 14);          // mapped -delz/delp: needed by the product rule below
+    for (int k = 1; k <= km; ++k) {
+      const double oa = a.f[3].p[F(3, k)], dpa = -ws.at(15, k) * oa;
+      ws.at(S.SP2, k + 1) += dpa; ws.at(S.SP2, k) -= dpa;
+    }
+    auto q2ad = [&](int k) { return -(pe2(k + 1) - pe2(k)) * a.f[3].p[F(3, k)]; };
+    map_col_ad(km, pe1, q1, pe2, q2ad, ws, S);
+    for (int k = 1; k <= km; ++k) {
+      const double qa = ws.at(S.SQ1, k), dp = a.f[2].t[F(2, k)];
+      a.f[1].p[F(1, k)] -= qa / dp;
+      a.f[2].p[F(2, k)] += qa * a.f[1].t[F(1, k)] / (dp * dp);
+      a.f[3].p[F(3, k)] = 0.;
+    }
+  } else {
+    auto q1 = [&](int k) { return a.f[1].t[F(1, k)]; };
+    auto q2ad = [&](int k) { return a.f[2].p[F(2, k)]; };
+    map_col_ad(km, pe1, q1, pe2, q2ad, ws, S);
+    for (int k = 1; k <= km; ++k) { a.f[1].p[F(1, k)] += ws.at(S.SQ1, k); a.f[2].p[F(2, k)] = 0.; }
+  }
+  for (int k = 1; k <= km + 1; ++k) a.f[0].p[F(0, k)] += ws.at(S.SP1, k);
+  ps_ad = ws.at(S.SP2, km + 1);
+  for (int k = 2; k <= km; ++k) ps_ad += a.bk[k - 1] * ws.at(S.SP2, k);
+  a.f[0].p[F(0, km + 1)] += ps_ad;
+}
+
 // New pressures, pkz from the equation of state, and the temperature hand-over (:1644-1661, :1798-1812, :1852-1857, :2203-2250).
 // f: 0 pe  1 peln  2 pk (end interfaces read, interior interfaces written)  3 T_v  4 delz  5 q_v (what = 1)  ->  6 delp  7 pkz  8 pt  9 pe2
 template <class IO>
@@ -465,7 +530,7 @@ HD void remap_press_col_nh(const IO& io, const NhColArgs& a) {
   }
 }
 
-enum NhColKind { NHC_RIEM_C = 0, NHC_RIEM3, NHC_EDGE, NHC_ZH_INIT, NHC_RING, NHC_RM_FIELD, NHC_RM_PRESS };
+enum NhColKind { NHC_RIEM_C = 0, NHC_RIEM3, NHC_EDGE, NHC_ZH_INIT, NHC_RING, NHC_RM_FIELD, NHC_RM_PRESS, NHC_RM_W };
 // One kernel per (operator, mode): each gets its own register allocation (the taped remap needs ~250 VGPRs, the nonlinear
 // solvers a fraction of that).
 template <int KIND, int MODE>
@@ -479,7 +544,7 @@ struct NhColFn {
     else if (KIND == NHC_EDGE) edge_col(io, a, ws);
     else if (KIND == NHC_ZH_INIT) zh_init_col(io, a, hs);
     else if (KIND == NHC_RING) ring_col(io, a);
-    else if (KIND == NHC_RM_FIELD) remap_field_col_nh(io, a, ws);
+    else if (KIND == NHC_RM_FIELD || KIND == NHC_RM_W) remap_field_col_nh(io, a, ws);
     else remap_press_col_nh(io, a);
   }
   HD void operator()(int i, int j, int zz) const {
@@ -491,6 +556,7 @@ struct NhColFn {
     const ColWs ws{a.ws + col, a.ws_stride, a.g.npz + 2};
     const double hs = a.hs ? a.hs[col] : 0.;
     if (KIND == NHC_EDGE && MODE == MODE_AD) { edge_col_ad(a, ws, z, i, j); return; }
+    if (KIND == NHC_RM_FIELD && MODE == MODE_AD) { remap_field_col_nh_ad(a, ws, z, i, j); return; }
     if (MODE == MODE_NL) { ColNL io{a.g, a.f, z, i, j, nullptr}; body(io, ws, hs); }
     else if (MODE == MODE_TL) { ColTL io{a.g, a.f, z, i, j, nullptr}; body(io, ws, hs); }
     else {
@@ -523,6 +589,7 @@ inline void run_nh_col(Exec& ex, int mode, const NhColArgs& a0, int kind, const 
     case NHC_ZH_INIT: run_nh_col_k<NHC_ZH_INIT>(ex, mode, a, R, skip, tag); break;
     case NHC_RING: run_nh_col_k<NHC_RING>(ex, mode, a, R, skip, tag); break;
     case NHC_RM_FIELD: run_nh_col_k<NHC_RM_FIELD>(ex, mode, a, R, skip, tag); break;
+    case NHC_RM_W: run_nh_col_k<NHC_RM_W>(ex, mode, a, R, skip, tag); break;
     default: run_nh_col_k<NHC_RM_PRESS>(ex, mode, a, R, skip, tag); break;
   }
 }
