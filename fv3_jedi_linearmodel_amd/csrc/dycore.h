@@ -13,6 +13,7 @@
 #include "column.h"
 #include "exchange.h"
 #include "nh.h"
+#include "nh_ad.h"
 #include <functional>
 #include <map>
 #include <string>
@@ -360,7 +361,7 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
   state.init(n3 * (16 + 3 * (size_t)nq + (nh ? 6 + (size_t)nq : 0)) + n3p * (8 + (nh ? 1 : 0)) + np);
   work.init(n3 * ((g.face ? 120 : 114) + (nh ? 28 : 0)) + n3p * (14 + (nh ? 44 : 0)));
   if (nh) {
-    nh_ws = (double*)dev_alloc((size_t)2 * NS_COUNT * (npz + 2) * np * 8);
+    nh_ws = (double*)dev_alloc((size_t)NH_WS_SLOTS * (npz + 2) * np * 8);
     nh_tape.cap = 104 * (npz + 2);
     int tape_tiles = ntile;                   // as many tiles per adjoint launch as a third of the free HBM holds (32 B per entry)
 #ifndef FV3LM_HOST_EMUL
@@ -472,6 +473,7 @@ inline NhColArgs Dycore::nh_args(double dt_) const {
   NhColArgs a{};
   a.g = g; a.ws = nh_ws; a.ws_stride = (size_t)g.ntile * g.plane; a.tape = nh_tape; a.hs = hs_dev; a.lev = lev_dev;
   a.zvir = opt.zvir; a.cp_air = opt.cp_air;
+  { const char* e = std::getenv("FV3LM_NH_TAPE"); a.use_tape = (e && e[0] == '1') ? 1 : 0; }
   a.dt = dt_; a.akap = opt.akap; a.ptop = opt.ptop; a.rdgas = opt.rdgas; a.grav = opt.grav; a.a_imp = opt.a_imp; a.p_fac = opt.p_fac; a.scale_z = opt.scale_z;
   return a;
 }

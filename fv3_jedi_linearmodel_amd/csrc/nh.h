@@ -14,6 +14,7 @@ namespace fv3 {
 
 constexpr double NH_DZ_MIN = 2.0;      // nh_utils: dz_min
 constexpr int NH_NF = 13;
+constexpr int NH_WS_SLOTS = 32;        // raw (double) workspace slots per column: 2 per generic-scalar slot, 31 for the hand-written adjoints (nh_ad.h)
 
 struct NhColArgs {
   Geom g; Fld f[NH_NF];
@@ -24,7 +25,10 @@ struct NhColArgs {
   const double *ak, *bk;               // hybrid coefficients, device [npz+1] (vertical remap)
   double zvir, cp_air;
   int last_call, what;
+  int use_tape;                        // adjoint of the implicit solvers: 1 = taped run of the generic code (FV3LM_NH_TAPE=1), 0 = nh_ad.h
 };
+HD void riem_c_col_ad(const NhColArgs& a, const ColWs& ws, int tile, int i, int j, double hs);
+HD void riem3_col_ad(const NhColArgs& a, const ColWs& ws, int tile, int i, int j, double hs);
 
 // common tail of SIM1 / SIM: new layer thickness from the perturbation pressure (nh_utils_tlm.F90:2862-2883, :3241-3265)
 template <class IO>
@@ -557,6 +561,8 @@ struct NhColFn {
     const double hs = a.hs ? a.hs[col] : 0.;
     if (KIND == NHC_EDGE && MODE == MODE_AD) { edge_col_ad(a, ws, z, i, j); return; }
     if (KIND == NHC_RM_FIELD && MODE == MODE_AD) { remap_field_col_nh_ad(a, ws, z, i, j); return; }
+    if (KIND == NHC_RIEM_C && MODE == MODE_AD && !a.use_tape) { riem_c_col_ad(a, ws, z, i, j, hs); return; }
+    if (KIND == NHC_RIEM3 && MODE == MODE_AD && !a.use_tape) { riem3_col_ad(a, ws, z, i, j, hs); return; }
     if (MODE == MODE_NL) { ColNL io{a.g, a.f, z, i, j, nullptr}; body(io, ws, hs); }
     else if (MODE == MODE_TL) { ColTL io{a.g, a.f, z, i, j, nullptr}; body(io, ws, hs); }
     else {

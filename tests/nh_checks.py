@@ -211,3 +211,21 @@ def cube_check_nh_dot_product(c, tol=1e-11):
     c.dy.fv_dynamics(AD)
     rhs = sum(float(np.sum(c.dy.get(n, 1) * p)) for n, p in zip(fv_names(c), dx))
     assert abs(lhs - rhs) <= tol * abs(lhs), (lhs, rhs)
+
+
+def nh_adjoint_fields(c):
+    """input adjoints of two acoustic steps for a fixed random output adjoint (used to compare the hand-written adjoints of
+    the implicit solvers with the taped run of the generic code, FV3LM_NH_TAPE=1)"""
+    T, _ = nh_state(c)
+    rng = np.random.default_rng(23)
+    A = c.rect(1, c.nx, 1, c.ny)
+    put(c, T)
+    c.dy.dyn_core(NL)
+    for n in OUTS:
+        s = np.zeros((c.dy.levels(n), c.ny + 7, c.nx + 7))
+        if n != "zh":
+            s[A] = rng.standard_normal(s[A].shape)
+        c.dy.put(n, s[None], 1)
+    c.dy.put("ws", rng.standard_normal((1, 1, c.ny + 7, c.nx + 7)), 1)     # exercises the surface-w output of the last step too
+    c.dy.dyn_core(AD)
+    return {n: c.dy.get(n, 1)[0].copy() for n in INS}

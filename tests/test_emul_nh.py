@@ -57,3 +57,17 @@ def test_nh_cube_adjoint_matches_oracle(nhcube):
 
 def test_nh_cube_dot_product(nhcube):
     N.cube_check_nh_dot_product(nhcube)
+
+
+def test_nh_hand_written_adjoints_match_the_taped_run(monkeypatch):
+    """riem_solver_c / riem_solver3: the hand-written reverse sweeps (csrc/nh_ad.h, the default) against the taped run of the
+    generic column code (FV3LM_NH_TAPE=1, csrc/coltape.h)"""
+    kw = dict(nx=10, ny=8, npz=9, n_split=2, dt=600.0, backend="emul", oracle=False, hord_ks_traj=0, hord_ks_pert=0, hydrostatic=0)
+    monkeypatch.delenv("FV3LM_NH_TAPE", raising=False)
+    hand = N.nh_adjoint_fields(Case(**kw))
+    monkeypatch.setenv("FV3LM_NH_TAPE", "1")
+    tape = N.nh_adjoint_fields(Case(**kw))
+    from common import relerr
+    for n in hand:
+        assert relerr(hand[n], tape[n]) < 1e-11, n
+        assert abs(hand[n]).max() > 0

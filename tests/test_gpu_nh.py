@@ -90,3 +90,15 @@ def test_nh_cube_dot_product_c96l127():
     from common import CubeCase
     c = CubeCase(n=96, npz=127, n_split=6, k_split=1, dt=225.0, nq=0, backend="hip", hord_ks_traj=0, hord_ks_pert=0, hydrostatic=0)
     N.cube_check_nh_dot_product(c)
+
+
+def test_nh_hand_written_adjoints_match_the_taped_run(monkeypatch):
+    """csrc/nh_ad.h (default) against the taped run of the generic column code (FV3LM_NH_TAPE=1) on the device"""
+    from common import Case, relerr
+    kw = dict(nx=16, ny=12, npz=24, n_split=2, dt=600.0, backend="hip", oracle=False, hord_ks_traj=0, hord_ks_pert=0, hydrostatic=0)
+    monkeypatch.delenv("FV3LM_NH_TAPE", raising=False)
+    hand = N.nh_adjoint_fields(Case(**kw))
+    monkeypatch.setenv("FV3LM_NH_TAPE", "1")
+    tape = N.nh_adjoint_fields(Case(**kw))
+    for n in hand:
+        assert relerr(hand[n], tape[n]) < 1e-10, n
