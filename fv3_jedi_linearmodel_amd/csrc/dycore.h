@@ -172,6 +172,7 @@ struct Dycore {
     if (!g.face) { add(P, grp, Edged<D, false>(s)); return; }
     const int lo = 1 + W, hi = g.nx - W, BIG = 1 << 20;
     const Rect regs[5] = {{lo, hi, lo, hi}, {-BIG, BIG, -BIG, lo - 1}, {-BIG, BIG, hi + 1, BIG}, {-BIG, lo - 1, lo, hi}, {hi + 1, BIG, lo, hi}};
+    std::vector<Edged<D, true>> strips;
     for (int r = 0; r < 5; ++r) {
       D t = s; Rect anchor{1, 0, 1, 0}; bool any = false;
       for (int n = 0; n < D::NOUT; ++n) {
@@ -183,14 +184,23 @@ struct Dycore {
       if (r == 0) {
         for (int m = 0; m < D::NIN; ++m) if ((edge_only_inputs((const D*)nullptr) >> m) & 1u) { const int nk = t.in[m].nk; t.in[m] = Fld{}; t.in[m].nk = nk; }
         add(P, grp, Edged<D, false>(t));
-      } else add(P, grp, Edged<D, true>(t));
+      } else strips.push_back(Edged<D, true>(t));
     }
+    add_multi(P, grp, strips);
   }
 
   template <class St>
   void add(Program& P, const char* group, const St& s) {
     Ctx* cp = &ctx;
     P.push_back(Op{group, [s, cp](Exec& e, int mode) { run(e, mode, s, *cp); }});
+  }
+  // several instances of one stage type (the edge strips of a face) as one launch (exec.h run_multi)
+  template <class St>
+  void add_multi(Program& P, const char* group, const std::vector<St>& v) {
+    if (v.empty()) return;
+    if (v.size() == 1) { add(P, group, v[0]); return; }
+    Ctx* cp = &ctx;
+    P.push_back(Op{group, [v, cp](Exec& e, int mode) { run_multi(e, mode, v.data(), (int)v.size(), *cp); }});
   }
   // Halo update of one field or of a staggered vector pair.  Single tile: doubly-periodic wrap; cube faces:
   // table-driven exchange (exchange.h).
@@ -233,8 +243,10 @@ struct Dycore {
       const int npy = g.ny + 1;
       a.orect[0] = R(r.i0, r.i1, 4, npy - 3); add(P, grp, a);
       TpPpmY_<true> e; e.in[0] = qq; e.in[1] = cry; e.out[0] = out; e.k1 = npz; e.hsel = hsel; e.cdir = cdir;
-      e.orect[0] = R(r.i0, r.i1, r.j0, 3); add(P, grp, e);
-      e.orect[0] = R(r.i0, r.i1, npy - 2, r.j1); add(P, grp, e);
+      std::vector<TpPpmY_<true>> ev;
+      e.orect[0] = R(r.i0, r.i1, r.j0, 3); ev.push_back(e);
+      e.orect[0] = R(r.i0, r.i1, npy - 2, r.j1); ev.push_back(e);
+      add_multi(P, grp, ev);
     };
     auto ppm_x = [&](Fld qq, Fld out, Rect r, int cdir) {
       TpPpmX_<false> a; a.in[0] = qq; a.in[1] = crx; a.out[0] = out; a.k1 = npz; a.hsel = hsel;
@@ -242,8 +254,10 @@ struct Dycore {
       const int npx = g.nx + 1;
       a.orect[0] = R(4, npx - 3, r.j0, r.j1); add(P, grp, a);
       TpPpmX_<true> e; e.in[0] = qq; e.in[1] = crx; e.out[0] = out; e.k1 = npz; e.hsel = hsel; e.cdir = cdir;
-      e.orect[0] = R(r.i0, 3, r.j0, r.j1); add(P, grp, e);
-      e.orect[0] = R(npx - 2, r.i1, r.j0, r.j1); add(P, grp, e);
+      std::vector<TpPpmX_<true>> ev;
+      e.orect[0] = R(r.i0, 3, r.j0, r.j1); ev.push_back(e);
+      e.orect[0] = R(npx - 2, r.i1, r.j0, r.j1); ev.push_back(e);
+      add_multi(P, grp, ev);
     };
     ppm_y(q, fy2, R(isd, ied, js, je + 1), 2);
     TpQi b; b.in[0] = q; b.in[1] = fy2; b.in[2] = yfx; b.in[3] = ray; b.out[0] = q_i; b.orect[0] = R(isd, ied, js, je); b.k1 = npz;
@@ -282,16 +296,20 @@ struct Dycore {
     // with the wave along j, exec.h strip_tr)
     a.orect[0] = R(3, npx - 2, 1, npy - 1); a.orect[1] = R(1, npx - 1, 3, npy - 2); add(P, grp, a);
     A2bA_<true> ae; ae.in[0] = q; ae.out[0] = qx; ae.out[1] = qy; ae.k1 = nk;
+    std::vector<A2bA_<true>> av;
     for (int e = 0; e < 4; ++e) {
       const Rect r = e == 0 ? R(1, 2, 1, npy - 1) : e == 1 ? R(npx - 1, npx, 1, npy - 1) : e == 2 ? R(1, npx - 1, 1, 2) : R(1, npx - 1, npy - 1, npy);
-      ae.orect[e < 2 ? 0 : 1] = r; ae.orect[e < 2 ? 1 : 0] = empty_in(r); add(P, grp, ae);
+      ae.orect[e < 2 ? 0 : 1] = r; ae.orect[e < 2 ? 1 : 0] = empty_in(r); av.push_back(ae);
     }
+    add_multi(P, grp, av);
     b.orect[0] = R(3, npx - 2, 3, npy - 2); add(P, grp, b);
     A2bB_<true> be; be.in[0] = qx; be.in[1] = qy; be.in[2] = q; be.out[0] = qb; be.k1 = nk;
+    std::vector<A2bB_<true>> bv;
     for (int e = 0; e < 4; ++e) {
       be.orect[0] = e == 0 ? R(1, npx, 1, 2) : e == 1 ? R(1, npx, npy - 1, npy) : e == 2 ? R(1, 2, 3, npy - 2) : R(npx - 1, npx, 3, npy - 2);
-      add(P, grp, be);
+      bv.push_back(be);
     }
+    add_multi(P, grp, bv);
   }
 
   void build_acoustic();
@@ -533,10 +551,12 @@ inline void Dycore::build_acoustic() {
       s.orect[0] = s.orect[1] = R(3, npx - 2, js - 1, je + 1); s.orect[2] = s.orect[3] = R(is - 1, ie + 1, 3, npy - 2); add(P, "c_sw", s);
       CswInterpC_<true> e; for (int n = 0; n < 4; ++n) { e.in[n] = s.in[n]; e.out[n] = s.out[n]; }
       e.in[4] = ua; e.in[5] = va; e.dt2 = dt2; e.k1 = npz;
+      std::vector<CswInterpC_<true>> ev;
       for (int m = 0; m < 4; ++m) {
         const Rect r = m == 0 ? R(0, 2, js - 1, je + 1) : m == 1 ? R(npx - 1, npx + 1, js - 1, je + 1) : m == 2 ? R(is - 1, ie + 1, 0, 2) : R(is - 1, ie + 1, npy - 1, npy + 1);
-        e.orect[0] = e.orect[1] = m < 2 ? r : empty_in(r); e.orect[2] = e.orect[3] = m < 2 ? empty_in(r) : r; add(P, "c_sw", e);
+        e.orect[0] = e.orect[1] = m < 2 ? r : empty_in(r); e.orect[2] = e.orect[3] = m < 2 ? empty_in(r) : r; ev.push_back(e);
       }
+      add_multi(P, "c_sw", ev);
     } }
   Fld divgd = W("divgd", npz);
   if (opt.nord > 0) {
@@ -592,10 +612,12 @@ inline void Dycore::build_acoustic() {
     Fld ut_e = W("ut_e", npz), vt_e = W("vt_e", npz);
     const int npx = g.nx + 1, npy = g.ny + 1;
     DswWindsE se; se.in[0] = ut_a; se.in[1] = vt_a; se.in[2] = uc; se.in[3] = vc; se.out[0] = ut_e; se.out[1] = vt_e; se.k1 = npz;
+    std::vector<DswWindsE> sv;
     for (int e = 0; e < 4; ++e) {
       const Rect r = e == 0 ? R(is - 1, ie + 2, 0, 1) : e == 1 ? R(is - 1, ie + 2, npy - 1, npy) : e == 2 ? R(0, 1, js - 1, je + 2) : R(npx - 1, npx, js - 1, je + 2);
-      se.orect[e < 2 ? 0 : 1] = r; se.orect[e < 2 ? 1 : 0] = empty_in(r); add(P, "d_sw", se);
+      se.orect[e < 2 ? 0 : 1] = r; se.orect[e < 2 ? 1 : 0] = empty_in(r); sv.push_back(se);
     }
+    add_multi(P, "d_sw", sv);
     DswWindsCD s; s.in[0] = ut_a; s.in[1] = vt_a; s.in[2] = ut_e; s.in[3] = vt_e; s.out[0] = ut; s.out[1] = crx; s.out[2] = xfx; s.out[3] = vt; s.out[4] = cry; s.out[5] = yfx;
     s.orect[0] = R(is - 1, ie + 2, jsd, jed); s.orect[1] = s.orect[2] = R(is, ie + 1, jsd, jed);
     s.orect[3] = R(isd, ied, js - 1, je + 2); s.orect[4] = s.orect[5] = R(isd, ied, js, je + 1); s.dt = dt; s.k1 = npz; add_face(P, "d_sw", s, 1);

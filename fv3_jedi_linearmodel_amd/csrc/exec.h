@@ -607,6 +607,73 @@ void run_ad(Exec& ex, const S& s, const Ctx& c) {
     ex.launches++;
   }
 }
+// ---- several instances of one stage in one launch (the edge strips of a face: same stage type, different output rectangles) ----
+// A strip launch covers ~1 % of a face and is launch-latency-bound; the four strips of a stage go out together.  Adjoint: the
+// input regions of the strips overlap at the face corners, so each input point is owned by the first strip whose region
+// contains it and that thread runs the gather of every strip that reaches the point, in strip order (no race, fixed order).
+constexpr int MAXSTRIP = 4;
+template <class S>
+struct Multi { S s[MAXSTRIP]; Rect R[MAXSTRIP]; int n, boff[MAXSTRIP + 1], gx[MAXSTRIP], tr[MAXSTRIP]; };
+template <class S, bool TL>
+__global__ void __launch_bounds__(BX* BY) k_stage_multi_fw(Multi<S> m, Ctx c) {
+  int b = blockIdx.x, r = 0;
+  while (r + 1 < m.n && b >= m.boff[r + 1]) ++r;
+  b -= m.boff[r];
+  int i, j; thread_point(m.R[r], m.tr[r], b % m.gx[r], b / m.gx[r], threadIdx.x, threadIdx.y, i, j);
+  if (i > m.R[r].i1 || j > m.R[r].j1) return;
+  if (TL) body_tl(m.s[r], c, i, j, blockIdx.z); else body_nl(m.s[r], c, i, j, blockIdx.z);
+}
+template <class S>
+__global__ void __launch_bounds__(BX* BY) k_stage_multi_ad(Multi<S> m, Rect Q0, Rect Q1, Rect Q2, Rect Q3, Ctx c, int nkmax) {
+  const Rect Q[MAXSTRIP] = {Q0, Q1, Q2, Q3};
+  int b = blockIdx.x, r = 0;
+  while (r + 1 < m.n && b >= m.boff[r + 1]) ++r;
+  b -= m.boff[r];
+  int i, j; thread_point(Q[r], m.tr[r], b % m.gx[r], b / m.gx[r], threadIdx.x, threadIdx.y, i, j);
+  if (i > Q[r].i1 || j > Q[r].j1) return;
+  for (int r2 = 0; r2 < r; ++r2) if (Q[r2].has(i, j)) return;          // owned by an earlier strip
+  // static indices (unrolled): a dynamically indexed stage struct would be copied to scratch
+  if (0 >= r && 0 < m.n && Q0.has(i, j)) ad_point(m.s[0], c, m.R[0], i, j, blockIdx.z, nkmax);
+  if (1 >= r && 1 < m.n && Q1.has(i, j)) ad_point(m.s[1], c, m.R[1], i, j, blockIdx.z, nkmax);
+  if (2 >= r && 2 < m.n && Q2.has(i, j)) ad_point(m.s[2], c, m.R[2], i, j, blockIdx.z, nkmax);
+  if (3 >= r && 3 < m.n && Q3.has(i, j)) ad_point(m.s[3], c, m.R[3], i, j, blockIdx.z, nkmax);
+}
+template <class S>
+void run_multi(Exec& ex, int mode, const S* s0, int n, const Ctx& c) {
+  if (n > MAXSTRIP) { for (int r = 0; r < n; ++r) run(ex, mode, s0[r], c); return; }
+  Multi<S> m; m.n = n;
+  Rect Q[MAXSTRIP]; int nkmax = 0; double bytes = 0.;
+  for (int r = 0; r < MAXSTRIP; ++r) {
+    const int q = r < n ? r : n - 1;
+    S t = s0[q];
+    if (ex.tshift) { for (int k = 0; k < S::NIN; ++k) t.in[k] = ex.sh(t.in[k]); for (int k = 0; k < S::NOUT; ++k) t.out[k] = ex.sh(t.out[k]); }
+    m.s[r] = t; m.R[r] = rect_union(t.orect, S::NOUT); Q[r] = ad_input_rect(t, c, m.R[r]);
+    if (r < n) bytes += stage_bytes(t, c, m.R[r], mode);
+  }
+  for (int k = 0; k < S::NIN; ++k) if (m.s[0].in[k].nk > nkmax) nkmax = m.s[0].in[k].nk;
+  const int nz = mode == MODE_AD ? c.g.ntile * nkmax : c.g.ntile * (m.s[0].k1 - m.s[0].k0 + 1);
+  m.boff[0] = 0;
+  for (int r = 0; r < n; ++r) {
+    const Rect& X = mode == MODE_AD ? Q[r] : m.R[r];
+    m.tr[r] = strip_tr(X);
+    const dim3 gd = grid_for(X, 1, m.tr[r]);
+    m.gx[r] = gd.x; m.boff[r + 1] = m.boff[r] + gd.x * gd.y;
+  }
+  ex.mark_begin(S::name(), mode == MODE_NL ? ".nl" : mode == MODE_TL ? ".tl" : ".ad", bytes);
+  const dim3 grid(m.boff[n], 1, nz);
+  if (mode == MODE_NL) hipLaunchKernelGGL((k_stage_multi_fw<S, false>), grid, dim3(BX, BY), 0, ex.stream, m, c);
+  else if (mode == MODE_TL) hipLaunchKernelGGL((k_stage_multi_fw<S, true>), grid, dim3(BX, BY), 0, ex.stream, m, c);
+  else hipLaunchKernelGGL(k_stage_multi_ad<S>, grid, dim3(BX, BY), 0, ex.stream, m, Q[0], Q[1], Q[2], Q[3], c, nkmax);
+  ex.mark_end();
+  ex.launches++;
+  if constexpr (S::NALIAS > 0) if (mode == MODE_AD && c.g.face)
+    for (int r = 0; r < n; ++r) {
+      ex.mark_begin(S::name(), ".ad_corner", 0.);
+      hipLaunchKernelGGL(k_stage_ad_alias<S>, dim3(4, c.g.ntile * nkmax), dim3(64), 0, ex.stream, m.s[r], c, m.R[r]);
+      ex.mark_end();
+      ex.launches++;
+    }
+}
 // generic per-point functor launch: f(i, j, z)
 template <class F>
 __global__ void __launch_bounds__(BX* BY) k_points(F f, Rect R) {
@@ -675,6 +742,12 @@ void for_points(Exec& ex, const Rect& R, int nz, const F& f, const char* tag = "
 }
 #endif
 
+template <class S>
+void run(Exec& ex, int mode, const S& s0, const Ctx& c);
+#ifdef FV3LM_HOST_EMUL
+template <class S>
+void run_multi(Exec& ex, int mode, const S* s0, int n, const Ctx& c) { for (int r = 0; r < n; ++r) run(ex, mode, s0[r], c); }
+#endif
 template <class S>
 void run(Exec& ex, int mode, const S& s0, const Ctx& c) {
   S s = s0;

@@ -20,6 +20,10 @@ def short(name):
     m = re.search(r"k_stage_fw_lds<fv3::(?:Edged<fv3::)?([A-Za-z0-9_]+?)D?(?:_?<|,)[^>]*?(true|false)\s*>*\s*,\s*(true|false)>", name)
     if m:       # LDS-staged forward launch of a bulk stage: last template argument true = tangent, false = nonlinear
         return "%s.%s(lds)" % (m.group(1).rstrip("_"), "tl" if m.group(3) == "true" else "nl")
+    m = re.search(r"k_stage_multi_(fw|ad)<fv3::(Edged<fv3::)?([A-Za-z0-9]+?)(D, true>|_<true>|_)?\s*(?:,\s*(true|false))?\s*>\(", name)
+    if m:       # the edge strips of a face in one launch
+        mode = "ad" if m.group(1) == "ad" else ("tl" if m.group(5) == "true" else "nl")
+        return "%s.%s(strips)" % (m.group(3) + ("" if m.group(3).endswith("E") else "e"), mode)
     m = re.search(r"k_stage_ad_lds<fv3::(?:Edged<fv3::)?([A-Za-z0-9_]+?)D?(?:_?<|,)", name)
     if m:
         return "%s.ad(lds)" % m.group(1).rstrip("_")
