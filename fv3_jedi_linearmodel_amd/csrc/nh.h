@@ -534,6 +534,24 @@ HD void remap_press_col_nh(const IO& io, const NhColArgs& a) {
   }
 }
 
+// adjoint of ring_col written out (a cumulative sum and, for pk3, one power per level): consumes f[1].p, accumulates into f[0].p
+HD void ring_col_ad(const NhColArgs& a, int tile, int i, int j) {
+  const Geom& g = a.g; const int km = g.npz;
+  double p = a.ptop;
+  for (int k = 1; k <= km; ++k) p += a.f[0].t[fidx(g, a.f[0], tile, i, j, k)];
+  if (a.what == 1) a.f[1].p[fidx(g, a.f[1], tile, i, j, 1)] = 0.;
+  double sum = 0.;
+  for (int k = km; k >= 1; --k) {
+    const size_t n = fidx(g, a.f[1], tile, i, j, k + 1);
+    const double oa = a.f[1].p[n];
+    a.f[1].p[n] = 0.;
+    sum += (a.what == 1) ? oa : a.akap * exp(a.akap * log(p)) / p * oa;
+    const size_t m = fidx(g, a.f[0], tile, i, j, k);
+    a.f[0].p[m] += sum;
+    p -= a.f[0].t[m];
+  }
+}
+
 enum NhColKind { NHC_RIEM_C = 0, NHC_RIEM3, NHC_EDGE, NHC_ZH_INIT, NHC_RING, NHC_RM_FIELD, NHC_RM_PRESS, NHC_RM_W };
 // One kernel per (operator, mode): each gets its own register allocation (the taped remap needs ~250 VGPRs, the nonlinear
 // solvers a fraction of that).
@@ -560,6 +578,7 @@ struct NhColFn {
     const ColWs ws{a.ws + col, a.ws_stride, a.g.npz + 2};
     const double hs = a.hs ? a.hs[col] : 0.;
     if (KIND == NHC_EDGE && MODE == MODE_AD) { edge_col_ad(a, ws, z, i, j); return; }
+    if (KIND == NHC_RING && MODE == MODE_AD) { ring_col_ad(a, z, i, j); return; }
     if (KIND == NHC_RM_FIELD && MODE == MODE_AD) { remap_field_col_nh_ad(a, ws, z, i, j); return; }
     if (KIND == NHC_RIEM_C && MODE == MODE_AD && !a.use_tape) { riem_c_col_ad(a, ws, z, i, j, hs); return; }
     if (KIND == NHC_RIEM3 && MODE == MODE_AD && !a.use_tape) { riem3_col_ad(a, ws, z, i, j, hs); return; }
