@@ -444,9 +444,10 @@ HD void remap_field_col_nh(const IO& io, const NhColArgs& a, const ColWs& ws) {
     map_col_io(io, km, ws, 1, io.cst(0.), [&](int k, const T& x) { io.st(2, k, x); });
   }
 }
-// Adjoint of remap_field_col_nh for what = 0, 2, 3 without the tape: the column map itself is the hydrostatic path's
-// hand-written map_col_ad (remap.h), the pre- and post-transforms are differentiated here.  (The w map, iv = -2, stays
-// on the tape: NHC_RM_W.)  Raw workspace slots: 0..12 map_col_ad, 13..15 staged trajectories.
+// Adjoint of remap_field_col_nh without the tape: the column map itself is the hydrostatic path's hand-written
+// map_col_ad (remap.h; map_col_ad_iv<-2> for the vertical velocity), the pre- and post-transforms are differentiated
+// here.  FV3LM_NH_TAPE=1 keeps the w map on the tape (NHC_RM_W), which is what the tests compare against.
+// Raw workspace slots: 0..12 map_col_ad, 13..15 staged trajectories.
 HD void remap_field_col_nh_ad(const NhColArgs& a, const ColWs& ws, int tile, int i, int j) {
   const Geom& g = a.g; const int km = g.npz;
   const MapAdSlots S{0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12};
@@ -497,6 +498,13 @@ HD void remap_field_col_nh_ad(const NhColArgs& a, const ColWs& ws, int tile, int
       a.f[2].p[F(2, k)] += qa * a.f[1].t[F(1, k)] / (dp * dp);
       a.f[3].p[F(3, k)] = 0.;
     }
+  } else if (a.what == 1) {       // vertical velocity: profile with the surface value ws as lower boundary (iv = -2)
+    auto q1 = [&](int k) { return a.f[1].t[F(1, k)]; };
+    auto q2ad = [&](int k) { return a.f[3].p[F(3, k)]; };
+    double a_qs = 0.;
+    map_col_ad_iv<-2>(km, pe1, q1, pe2, q2ad, ws, S, a.f[2].t[F(2, 1)], &a_qs);
+    for (int k = 1; k <= km; ++k) { a.f[1].p[F(1, k)] += ws.at(S.SQ1, k); a.f[3].p[F(3, k)] = 0.; }
+    a.f[2].p[F(2, 1)] += a_qs;
   } else {
     auto q1 = [&](int k) { return a.f[1].t[F(1, k)]; };
     auto q2ad = [&](int k) { return a.f[2].p[F(2, k)]; };
@@ -579,7 +587,7 @@ struct NhColFn {
     const double hs = a.hs ? a.hs[col] : 0.;
     if (KIND == NHC_EDGE && MODE == MODE_AD) { edge_col_ad(a, ws, z, i, j); return; }
     if (KIND == NHC_RING && MODE == MODE_AD) { ring_col_ad(a, z, i, j); return; }
-    if (KIND == NHC_RM_FIELD && MODE == MODE_AD) { remap_field_col_nh_ad(a, ws, z, i, j); return; }
+    if ((KIND == NHC_RM_FIELD || KIND == NHC_RM_W) && MODE == MODE_AD && !(KIND == NHC_RM_W && a.use_tape)) { remap_field_col_nh_ad(a, ws, z, i, j); return; }
     if (KIND == NHC_RIEM_C && MODE == MODE_AD && !a.use_tape) { riem_c_col_ad(a, ws, z, i, j, hs); return; }
     if (KIND == NHC_RIEM3 && MODE == MODE_AD && !a.use_tape) { riem3_col_ad(a, ws, z, i, j, hs); return; }
     if (MODE == MODE_NL) { ColNL io{a.g, a.f, z, i, j, nullptr}; body(io, ws, hs); }

@@ -106,13 +106,29 @@ HD void map_col(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const FOu
 // slots: SG gam, SB bet, SF qf (pre back-substitution), SE qe, SD d4, SDP dp1_ad, SGA gam_ad,
 // SFA qf_ad, SEA qe_ad, SDA d4_ad.
 struct MapAdSlots { int SP1, SQ1, SP2, SG, SB, SF, SE, SD, SDP, SGA, SFA, SEA, SDA; };
-template <class FP1, class FQ1, class FP2, class FAd>
-HD void map_col_ad(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const FAd& q2_ad, const ColWs& ws,
-                   const MapAdSlots& S) {
+// IV = -2: the profile of the vertical velocity (lower boundary value qs given, fv_mapz_tlm.F90:8549-8590); qs_ad receives its adjoint.
+template <int IV, class FP1, class FQ1, class FP2, class FAd>
+HD void map_col_ad_iv(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const FAd& q2_ad, const ColWs& ws,
+                      const MapAdSlots& S, double qs, double* qs_ad) {
   // ---- forward replay with storage
   const double dp1_1 = pe1(2) - pe1(1), dp1_2 = pe1(3) - pe1(2);
   const double grat = dp1_2 / dp1_1, bet1 = grat * (grat + 0.5);
-  {
+  if (IV == -2) {
+    double qf = 1.5 * q1(1), dp_prev = dp1_1;
+    ws.at(S.SF, 1) = qf; ws.at(S.SG, 2) = 0.5;
+    for (int k = 2; k <= km - 1; ++k) {
+      const double dpk = pe1(k + 1) - pe1(k), gr = dp_prev / dpk, bet = 2. + gr + gr - ws.at(S.SG, k);
+      qf = (3. * (q1(k - 1) + q1(k)) - qf) / bet;
+      ws.at(S.SF, k) = qf; ws.at(S.SD, k) = gr; ws.at(S.SG, k + 1) = gr / bet;
+      dp_prev = dpk;
+    }
+    const double gr = dp_prev / (pe1(km + 1) - pe1(km)), den = 2. + gr + gr - ws.at(S.SG, km);
+    qf = (3. * (q1(km - 1) + q1(km)) - gr * qs - qf) / den;
+    ws.at(S.SF, km) = qf; ws.at(S.SD, km) = gr; ws.at(S.SF, km + 1) = qs;
+    double qe = qf;
+    ws.at(S.SE, km + 1) = qs; ws.at(S.SE, km) = qe;
+    for (int k = km - 1; k >= 1; --k) { qe = ws.at(S.SF, k) - ws.at(S.SG, k + 1) * qe; ws.at(S.SE, k) = qe; }
+  } else {
     double qf = ((grat + grat) * (grat + 1.) * q1(1) + q1(2)) / bet1, gam = (1. + grat * (grat + 1.5)) / bet1;
     ws.at(S.SF, 1) = qf; ws.at(S.SG, 1) = gam; ws.at(S.SD, 1) = grat;
     double d4 = grat, a_prev = q1(1), dp_prev = dp1_1;
@@ -198,6 +214,36 @@ HD void map_col_ad(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const 
     p2k += pl_ad / dpl; ws.at(S.SP1, l) -= pl_ad / dpl; ws.at(S.SDP, l) -= pl * pl_ad / dpl;
   }
   ws.at(S.SP2, km) += p2k; ws.at(S.SP2, km + 1) += p2k1;
+  if (IV == -2) {
+    // reverse of  q(k) = qf(k) - gam(k+1) q(k+1), k = km-1..1 ;  q(km) = qf(km) ;  q(km+1) = qs
+    double carry = 0.;
+    for (int k = 1; k <= km - 1; ++k) {
+      const double e = ws.at(S.SEA, k) + carry;
+      ws.at(S.SFA, k) = e;
+      ws.at(S.SGA, k + 1) = -ws.at(S.SE, k + 1) * e;
+      carry = -ws.at(S.SG, k + 1) * e;
+    }
+    double a_qs = ws.at(S.SEA, km + 1), sfa, sga;
+    {   // q(km) = (3 (a(km-1) + a(km)) - gr qs - qf(km-1)) / den,  den = 2 + 2 gr - gam(km)
+      const double gr = ws.at(S.SD, km), den = 2. + gr + gr - ws.at(S.SG, km), t = (ws.at(S.SEA, km) + carry) / den;
+      ws.at(S.SQ1, km - 1) += 3. * t; ws.at(S.SQ1, km) += 3. * t;
+      a_qs -= gr * t;
+      const double a_den = -ws.at(S.SF, km) * t, a_gr = -qs * t + 2. * a_den, dpk = pe1(km + 1) - pe1(km);
+      sfa = ws.at(S.SFA, km - 1) - t;
+      sga = ws.at(S.SGA, km) - a_den;
+      ws.at(S.SDP, km - 1) += a_gr / dpk; ws.at(S.SDP, km) -= gr * a_gr / dpk;
+    }
+    for (int k = km - 1; k >= 2; --k) {   // qf(k) = (3 (a(k-1) + a(k)) - qf(k-1)) / bet, bet = 2 + 2 gr - gam(k), gam(k+1) = gr / bet
+      const double gr = ws.at(S.SD, k), bet = 2. + gr + gr - ws.at(S.SG, k), t = sfa / bet;
+      ws.at(S.SQ1, k - 1) += 3. * t; ws.at(S.SQ1, k) += 3. * t;
+      const double a_bet = -ws.at(S.SF, k) * t - ws.at(S.SG, k + 1) * sga / bet, a_gr = sga / bet + 2. * a_bet, dpk = pe1(k + 1) - pe1(k);
+      sfa = ws.at(S.SFA, k - 1) - t;
+      sga = (k > 2 ? ws.at(S.SGA, k) : 0.) - a_bet;      // gam(2) = 0.5 is a constant
+      ws.at(S.SDP, k - 1) += a_gr / dpk; ws.at(S.SDP, k) -= gr * a_gr / dpk;
+    }
+    ws.at(S.SQ1, 1) += 1.5 * sfa;
+    if (qs_ad) *qs_ad += a_qs;
+  } else {
   // ---- reverse of the back substitution  qe(k) = qf(k) - gam(k) qe(k+1), k = km..1
   double fa_bot;
   {
@@ -256,7 +302,12 @@ HD void map_col_ad(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const 
     grat_ad += (2. * grat + 0.5) * bet_ad;
     ws.at(S.SDP, 2) += grat_ad / dp1_1; ws.at(S.SDP, 1) += dpend - grat * grat_ad / dp1_1;
   }
+  }
   for (int k = 1; k <= km; ++k) { const double a = ws.at(S.SDP, k); ws.at(S.SP1, k + 1) += a; ws.at(S.SP1, k) -= a; }
+}
+template <class FP1, class FQ1, class FP2, class FAd>
+HD void map_col_ad(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const FAd& q2_ad, const ColWs& ws, const MapAdSlots& S) {
+  map_col_ad_iv<1>(km, pe1, q1, pe2, q2_ad, ws, S, 0., nullptr);
 }
 
 // ---------------------------------------------------------------- kernels
