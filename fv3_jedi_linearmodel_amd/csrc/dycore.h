@@ -380,14 +380,18 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
   work.init(n3 * ((g.face ? 120 : 114) + (nh ? 28 : 0)) + n3p * (14 + (nh ? 44 : 0)));
   if (nh) {
     nh_ws = (double*)dev_alloc((size_t)NH_WS_SLOTS * (npz + 2) * np * 8);
-    nh_tape.cap = 104 * (npz + 2);
-    int tape_tiles = ntile;                   // as many tiles per adjoint launch as a third of the free HBM holds (32 B per entry)
+    const char* tape_env = std::getenv("FV3LM_NH_TAPE");
+    const bool tape_on = tape_env && tape_env[0] == '1';      // the taped adjoints are the reference path of the tests (nh_ad.h is the default)
+    nh_tape.cap = tape_on ? 104 * (npz + 2) : 1;
+    int tape_tiles = tape_on ? ntile : 1;
+    if (tape_on) {                   // as many tiles per adjoint launch as a third of the free HBM holds (32 B per entry)
 #ifndef FV3LM_HOST_EMUL
     { size_t fr = 0, tot = 0;
       if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = 0;
       const size_t per_tile = (size_t)nh_tape.cap * g.plane * 32;
       tape_tiles = (int)std::max<size_t>(1, std::min<size_t>((size_t)ntile, fr / 3 / per_tile)); }
 #endif
+    }
     nh_tape.stride = (size_t)tape_tiles * g.plane;
     nh_tape.part = (TapePart*)dev_alloc((size_t)nh_tape.cap * nh_tape.stride * sizeof(TapePart));
     nh_tape.idx = (TapeIdx*)dev_alloc((size_t)nh_tape.cap * nh_tape.stride * sizeof(TapeIdx));

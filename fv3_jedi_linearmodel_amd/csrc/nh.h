@@ -542,6 +542,56 @@ HD void remap_press_col_nh(const IO& io, const NhColArgs& a) {
   }
 }
 
+// adjoint of zh_init_col: zh(k) = zs - sum_{l >= k} delz(l)
+HD void zh_init_col_ad(const NhColArgs& a, int tile, int i, int j) {
+  const Geom& g = a.g; const int km = g.npz;
+  double G = 0.;
+  for (int k = 1; k <= km; ++k) {
+    const size_t n = fidx(g, a.f[1], tile, i, j, k);
+    G += a.f[1].p[n]; a.f[1].p[n] = 0.;
+    a.f[0].p[fidx(g, a.f[0], tile, i, j, k)] -= G;
+  }
+  a.f[1].p[fidx(g, a.f[1], tile, i, j, km + 1)] = 0.;
+}
+// adjoint of remap_press_col_nh.  f: 0 pe  1 peln  2 pk  3 T_v  4 delz  5 q_v (what = 1)  ->  6 delp  7 pkz  8 pt  9 pe2
+HD void remap_press_col_nh_ad(const NhColArgs& a, int tile, int i, int j) {
+  const Geom& g = a.g; const int km = g.npz;
+  const double rrg = -a.rdgas / a.grav;
+  auto F = [&](int sl, int k) -> size_t { return fidx(g, a.f[sl], tile, i, j, k); };
+  const double ps = a.f[0].t[F(0, km + 1)];
+  double ps_ad = 0., pe_hi = a.ptop;
+  double a_hi = 0.;        // adjoint of the upper interface pressure of layer k, from dp(k) = pe_lo - pe_hi (pe_hi of layer 1 is the constant ptop)
+  a.f[9].p[F(9, 1)] = 0.;
+  for (int k = 1; k <= km; ++k) {
+    const double pe_lo = (k == km) ? ps : a.ak[k] + a.bk[k] * ps;
+    const double dp = pe_lo - pe_hi, t = a.f[3].t[F(3, k)], dz = a.f[4].t[F(4, k)];
+    const double pkz = exp(a.akap * log(rrg * dp / dz * t));
+    const double po = a.f[8].p[F(8, k)];
+    double a_t, a_pkz = a.f[7].p[F(7, k)];
+    if (a.last_call) {
+      if (a.what) { const double q = a.f[5].t[F(5, k)], f1 = 1. + a.zvir * q; a_t = po / f1; a.f[5].p[F(5, k)] -= po * t * a.zvir / (f1 * f1); }
+      else a_t = po;
+    } else { a_t = po / pkz; a_pkz -= po * t / (pkz * pkz); }
+    const double c = a_pkz * a.akap * pkz;
+    a_t += c / t;
+    a.f[3].p[F(3, k)] += a_t;
+    a.f[4].p[F(4, k)] -= c / dz;
+    const double a_dp = a.f[6].p[F(6, k)] + c / dp;
+    a.f[6].p[F(6, k)] = 0.; a.f[7].p[F(7, k)] = 0.; a.f[8].p[F(8, k)] = 0.;
+    // interface k (upper, pe_hi) is complete now: dp(k-1) gave +, dp(k) gives -, plus the peln / pk / pe2 outputs at level k
+    if (k > 1) {
+      const double pn = log(pe_hi), pkh = exp(a.akap * pn);
+      const double a_pe = a_hi - a_dp + a.f[1].p[F(1, k)] / pe_hi + a.akap * pkh / pe_hi * a.f[2].p[F(2, k)] + a.f[9].p[F(9, k)];
+      a.f[1].p[F(1, k)] = 0.; a.f[2].p[F(2, k)] = 0.; a.f[9].p[F(9, k)] = 0.;
+      ps_ad += a.bk[k - 1] * a_pe;
+    }
+    a_hi = a_dp;
+    pe_hi = pe_lo;
+  }
+  ps_ad += a_hi + a.f[9].p[F(9, km + 1)];
+  a.f[9].p[F(9, km + 1)] = 0.;
+  a.f[0].p[F(0, km + 1)] += ps_ad;
+}
 // adjoint of ring_col written out (a cumulative sum and, for pk3, one power per level): consumes f[1].p, accumulates into f[0].p
 HD void ring_col_ad(const NhColArgs& a, int tile, int i, int j) {
   const Geom& g = a.g; const int km = g.npz;
@@ -587,6 +637,8 @@ struct NhColFn {
     const double hs = a.hs ? a.hs[col] : 0.;
     if (KIND == NHC_EDGE && MODE == MODE_AD) { edge_col_ad(a, ws, z, i, j); return; }
     if (KIND == NHC_RING && MODE == MODE_AD) { ring_col_ad(a, z, i, j); return; }
+    if (KIND == NHC_ZH_INIT && MODE == MODE_AD && !a.use_tape) { zh_init_col_ad(a, z, i, j); return; }
+    if (KIND == NHC_RM_PRESS && MODE == MODE_AD && !a.use_tape) { remap_press_col_nh_ad(a, z, i, j); return; }
     if ((KIND == NHC_RM_FIELD || KIND == NHC_RM_W) && MODE == MODE_AD && !(KIND == NHC_RM_W && a.use_tape)) { remap_field_col_nh_ad(a, ws, z, i, j); return; }
     if (KIND == NHC_RIEM_C && MODE == MODE_AD && !a.use_tape) { riem_c_col_ad(a, ws, z, i, j, hs); return; }
     if (KIND == NHC_RIEM3 && MODE == MODE_AD && !a.use_tape) { riem3_col_ad(a, ws, z, i, j, hs); return; }
@@ -602,7 +654,7 @@ struct NhColFn {
 };
 template <int KIND, int MODE>
 inline void run_nh_col_km(Exec& ex, const NhColArgs& a, const Rect& R, const Rect& skip, const char* tag) {
-  if (MODE != MODE_AD) { for_points(ex, R, a.g.ntile, NhColFn<KIND, MODE>{a, skip, 0}, tag); return; }
+  if (MODE != MODE_AD || !a.use_tape) { for_points(ex, R, a.g.ntile, NhColFn<KIND, MODE>{a, skip, 0}, tag); return; }   // hand-written adjoints need no tape
   const int chunk = (int)(a.tape.stride / a.g.plane);       // tiles the tape holds at once (dycore.h sizes it from the free HBM)
   for (int z = 0; z < a.g.ntile; z += chunk) for_points(ex, R, std::min(chunk, a.g.ntile - z), NhColFn<KIND, MODE>{a, skip, z}, tag);
 }
