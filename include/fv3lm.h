@@ -122,7 +122,8 @@ int fv3lm_run_group(fv3lm_handle* h, const char* group, int mode);  /* one kerne
      "c_sw" (C_SW_TLM sw_core_tlm.F90:87), "geopk_c"/"geopk_d" (GEOPK_TLM dyn_core_tlm.F90:4578),
      "p_grad_c" (:3194), "d_sw" (D_SW_TLM sw_core_tlm.F90:1047), "one_grad_p" (:3867), "halo_*" */
 int fv3lm_dyn_core(fv3lm_handle* h, int mode);   /* DYN_CORE_TLM dyn_core_tlm.F90:93 / DYN_CORE_FWD+BWD dyn_core_adm.F90:115,1686 */
-/* The operator itself.  State fields u v pt(=temperature) delp q1..qn are device-resident (fv3lm_field_put /
+/* The operator itself.  State fields u v pt(=temperature) delp q1..qn — and w, delz when hydrostatic = 0 (nh_core_tlm.F90 /
+ * nh_utils_tlm.F90 path: RIEM_SOLVER_C, RIEM_SOLVER3 with a_imp in (0.5, 0.999], UPDATE_DZ_C/D) — are device-resident (fv3lm_field_put /
  * _get; compute domain is..ie x js..je, D-grid winds incl. the far edge row/column).
  *  fv3lm_step_tl : replaces compute_fv3_pressures_tlm + FV_DYNAMICS_TLM in %step_tl
  *                  (DYN/fv3jedi_lm_dynamics_mod.F90:404-438).  In: trajectory (which=0) and perturbation
