@@ -377,7 +377,7 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
   ctx.g = g; ctx.lev = lev_dev; ctx.nlev = npz;
   n3 = np * npz; n3p = np * (npz + 1);
   state.init(n3 * (16 + 3 * (size_t)nq + (nh ? 6 + (size_t)nq : 0)) + n3p * (8 + (nh ? 1 : 0)) + np);
-  work.init(n3 * ((g.face ? 120 : 114) + (nh ? 28 : 0)) + n3p * (14 + (nh ? 44 : 0)));
+  work.init(n3 * ((g.face ? 120 : 114) + (nh ? 28 : 0)) + n3p * (14 + (nh ? 46 : 0)));
   if (nh) {
     nh_ws = (double*)dev_alloc((size_t)NH_WS_SLOTS * (npz + 2) * np * 8);
     const char* tape_env = std::getenv("FV3LM_NH_TAPE");
@@ -589,7 +589,10 @@ inline void Dycore::build_acoustic() {
   if (nh) {
     // interface heights advected with the C-grid fluxes, the vertically implicit solver, pressure gradient (dyn_core_tlm.F90:1860-1960)
     Fld gz_a = W("gz_a", npz + 1);
-    { UpdateDzCD s; s.in[0] = zh; s.in[1] = utf; s.in[2] = vtf; s.out[0] = gz_a; s.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); s.k1 = npz + 1;
+    Fld xfz = W("xfz", npz + 1), yfz = W("yfz", npz + 1);
+    { DzFluxC s; s.in[0] = utf; s.in[1] = vtf; s.out[0] = xfz; s.out[1] = yfz; s.orect[0] = R(is - 1, ie + 2, js - 1, je + 1);
+      s.orect[1] = R(is - 1, ie + 1, js - 1, je + 2); s.k1 = npz + 1; add(P, "update_dz_c", s); }
+    { UpdateDzCD s; s.in[0] = zh; s.in[1] = xfz; s.in[2] = yfz; s.out[0] = gz_a; s.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); s.k1 = npz + 1;
       add_face(P, "update_dz_c", s, 1); }
     { NhColArgs a = nh_args(dt2); a.f[0] = gz_a; a.f[1] = wc; a.f[2] = ptc; a.f[3] = delpc; a.f[4] = gz; a.f[5] = pkc;
       add_col(P, "riem_c", NHC_RIEM_C, a, R(is - 1, ie + 1, js - 1, je + 1)); }

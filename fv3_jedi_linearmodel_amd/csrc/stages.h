@@ -1087,16 +1087,14 @@ struct CswTransportWD {
   }
 };
 typedef Edged<CswTransportWD, false> CswTransportW;
-// UPDATE_DZ_C, advection part (nh_utils_tlm.F90:247-366): interface heights with the C-grid area fluxes interpolated to
-// the interfaces.  Launched over the npz+1 interfaces; the fluxes have npz levels.
-struct UpdateDzCD {
-  STAGE_BASE("UpdateDzC", 3, 1)   // in: gz (npz+1) utf vtf (npz)   out: gz_a (npz+1)
-  HD static constexpr bool uses(int M, int di, int dj, int) { return M > 0 || di == 0 || dj == 0; }
-  HD static constexpr unsigned wants(int) { return 0x1u; }
-  HD static constexpr Box box(int M) { return M == 0 ? Box{-1, 1, -1, 1, 0, 0} : M == 1 ? Box{0, 1, 0, 0, -2, 1} : Box{0, 0, 0, 1, -2, 1}; }
-  static constexpr int NALIAS = 2;
-  HD static constexpr int alias_box(int M) { return M; }
-  HD bool alias(const Ctx& c, int M, int i, int j, int n, int& ai, int& aj) const { return M == 0 && fill2_alias(c.g, n + 1, i, j, ai, aj); }
+// UPDATE_DZ_C, advection part (nh_utils_tlm.F90:247-366), in two stages: the C-grid area fluxes interpolated to the npz+1
+// interfaces (vertical stencil only), then the upwind update of the interface heights (horizontal stencil only).
+struct DzFluxC {
+  STAGE_BASE("DzFluxC", 2, 2)   // in: utf vtf (npz)   out: xfz yfz (npz+1)
+  STAGE_NO_ALIAS
+  HD static constexpr bool uses(int, int, int, int) { return true; }
+  HD static constexpr Box box(int) { return Box{0, 0, 0, 0, -2, 1}; }
+  HD static constexpr unsigned wants(int M) { return M == 0 ? 0x1u : 0x2u; }
   template <int M, class T, class A>
   HD T flux(const A& a, const Ctx& c, int i, int j, int k) const {   // area flux at interface k
     const int km = c.g.npz;
@@ -1105,15 +1103,30 @@ struct UpdateDzCD {
     if (k == km + 1) return IN(M, i, j, -1) + (IN(M, i, j, -1) - IN(M, i, j, -2)) * (dp0(km) / (dp0(km - 1) + dp0(km)));
     return (dp0(k) * IN(M, i, j, -1) + dp0(k - 1) * IN(M, i, j, 0)) * (1. / (dp0(k - 1) + dp0(k)));
   }
+  template <class T, class A>
+  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+    o[0] = o[1] = T(0.);
+    if ((a.want & 0x1u) && orect[0].has(i, j)) o[0] = flux<0, T>(a, c, i, j, k);
+    if ((a.want & 0x2u) && orect[1].has(i, j)) o[1] = flux<1, T>(a, c, i, j, k);
+  }
+};
+struct UpdateDzCD {
+  STAGE_BASE("UpdateDzC", 3, 1)   // in: gz xfz yfz (npz+1)   out: gz_a (npz+1)
+  HD static constexpr bool uses(int M, int di, int dj, int) { return M > 0 || di == 0 || dj == 0; }
+  HD static constexpr unsigned wants(int) { return 0x1u; }
+  HD static constexpr Box box(int M) { return M == 0 ? Box{-1, 1, -1, 1, 0, 0} : M == 1 ? Box{0, 1, 0, 0, 0, 0} : Box{0, 0, 0, 1, 0, 0}; }
+  static constexpr int NALIAS = 2;
+  HD static constexpr int alias_box(int M) { return M; }
+  HD bool alias(const Ctx& c, int M, int i, int j, int n, int& ai, int& aj) const { return M == 0 && fill2_alias(c.g, n + 1, i, j, ai, aj); }
   template <bool EDGE, class T, class A>
   HD void eval_e(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     auto gx = [&](int ii, int jj) -> T { if (EDGE) fill2_map(c.g, 1, ii, jj); return IN(0, ii, jj); };
     auto gy = [&](int ii, int jj) -> T { if (EDGE) fill2_map(c.g, 2, ii, jj); return IN(0, ii, jj); };
     T xf[2], yf[2], fx[2], fy[2];
     for (int d = 0; d < 2; ++d) {
-      xf[d] = flux<1, T>(a, c, i + d, j, k);
+      xf[d] = IN(1, i + d, j);
       fx[d] = xf[d] * ((val(xf[d]) > 0.) ? gx(i + d - 1, j) : gx(i + d, j));
-      yf[d] = flux<2, T>(a, c, i, j + d, k);
+      yf[d] = IN(2, i, j + d);
       fy[d] = yf[d] * ((val(yf[d]) > 0.) ? gy(i, j + d - 1) : gy(i, j + d));
     }
     const double ar = MET(area, i, j);
@@ -1230,7 +1243,6 @@ constexpr int kclass_of(const PGradC*, int M) { return M < 2 ? 1 : 0; }
 constexpr int kclass_of(const OneGradP*, int M) { return M < 2 ? 0 : 1; }
 constexpr int kclass_of(const PGradCNh*, int M) { return M < 2 ? 1 : 0; }
 constexpr int kclass_of(const NhPGrad*, int M) { return M < 3 ? 0 : 1; }
-template <bool E> constexpr int kclass_of(const Edged<UpdateDzCD, E>*, int M) { return M == 0 ? 1 : 0; }
 
 // inputs that only the face-edge formulas of a stage read (bit m = input m): not given to the bulk launch
 template <class D> constexpr unsigned edge_only_inputs(const D*) { return 0u; }
