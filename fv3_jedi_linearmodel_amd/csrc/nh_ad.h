@@ -10,7 +10,8 @@
 
 namespace fv3 {
 
-// raw workspace slots (km+2 doubles each; NH_WS_SLOTS of them per column, nh.h)
+// raw workspace slots (km+2 doubles each; NH_WS_SLOTS of them per column, nh.h).  HS_*: forward values; HA_*: adjoints.  Some HS_
+// slots are reused for adjoints once their forward value is dead (noted where it happens).
 enum { HS_DZ = 0, HS_PEM, HS_PM, HS_DM, HS_PT, HS_W1, HS_P, HS_GR, HS_GAM, HS_BET, HS_PP, HS_AA, HS_GM2, HS_BET2, HS_W2F, HS_W2, HS_PE, HS_P1,
        HS_DZN, HS_WK, HS_CL, HA_DZ, HA_PEM, HA_PM, HA_DM, HA_PT, HA_PP, HA_PE, HA_W1, HA_GR, HA_PQ, HS_COUNT };
 static_assert(HS_COUNT <= NH_WS_SLOTS, "column workspace too small for the hand-written adjoints");
@@ -39,7 +40,7 @@ HD void nhad_pp_edges_fwd(const NhAdCol& W, double rgas, double gama) {
     ppk = (dd(k) - ppk) / bet;
     W(HS_PP, k + 1) = ppk;          // pre back-substitution value; overwritten below except k = km+1
   }
-  // keep the forward-sweep values of pp in HS_W2F's place?  No: the reverse sweep needs only the final pp and gam, bet.
+  // the reverse sweep recovers the pre back-substitution values from the final ones: ppf(k) = pp(k) + gam(k) pp(k+1)
   for (int k = km; k >= 2; --k) { ppk = W(HS_PP, k) - W(HS_GAM, k) * ppk; W(HS_PP, k) = ppk; }
 }
 // adjoint: consumes HA_PP(1..km+1); accumulates HA_PQ(k) (adjoint of pe = P - pm, handed on by the caller), HA_GR, and through
