@@ -99,6 +99,17 @@ def test_dot_product_step(case_q):
     assert abs(lhs - rhs) <= 1e-12 * abs(lhs), (lhs, rhs)
 
 
+def test_step_c12l64_tl_and_dot_product():
+    """BASELINE config 1 (C12 L64 hydrostatic, one tile, one TL step) on the host emulation of the stage code"""
+    from common import Case
+    from groups import dot_product_step, check_fv_dynamics
+    from oracle import TL
+    c = Case(nx=12, ny=12, npz=64, n_split=4, k_split=1, dt=900.0, backend="emul", nq=1)
+    check_fv_dynamics(c, TL, 1e-10)
+    lhs, rhs = dot_product_step(c)
+    assert abs(lhs - rhs) <= 1e-12 * abs(lhs), (lhs, rhs)
+
+
 def test_repeated_adjoint_on_one_forward_sweep(case_q):
     from groups import repeated_adjoint
     assert repeated_adjoint(case_q) < 1e-13

@@ -95,6 +95,17 @@ def test_dot_product_step(case_q):
     assert abs(lhs - rhs) <= 1e-12 * abs(lhs), (lhs, rhs)
 
 
+def test_step_c12l64_tl_and_dot_product():
+    """BASELINE config 1 (C12 L64 hydrostatic, one tile, one TL step): tangent-linear step against the oracle's whole
+    step, and the TL/AD dot-product identity"""
+    from common import Case
+    from groups import dot_product_step, check_fv_dynamics
+    c = Case(nx=12, ny=12, npz=64, n_split=4, k_split=1, dt=900.0, backend="hip", nq=1)
+    check_fv_dynamics(c, TL, 1e-10)
+    lhs, rhs = dot_product_step(c)
+    assert abs(lhs - rhs) <= 1e-12 * abs(lhs), (lhs, rhs)
+
+
 def test_dot_product_step_c48l72():
     """BASELINE config 2 (C48 L72 hydrostatic, 4 tracers, k_split 1, n_split 6, dt 900 s): the TL/AD
     dot-product identity of the whole step at full size — a size-independent invariant."""
