@@ -1,0 +1,22 @@
+"""Options the path does not build are refused at create with a message, never approximated: checked on the
+host-emulation build of the same create() code."""
+import pytest
+from common import Case
+
+
+@pytest.mark.parametrize("kw, needle", [
+    (dict(nord=2), "nord"),
+    (dict(hord_dp=10), "hord"),
+    (dict(hord_mt=2, hord_mt_pert=1), "split_hord"),
+    (dict(hydrostatic=0, a_imp=0.4, hord_ks_traj=0, hord_ks_pert=0), "a_imp"),
+])
+def test_unsupported_options_are_refused(kw, needle):
+    with pytest.raises(Exception) as e:
+        Case(nx=10, ny=8, npz=12, backend="emul", oracle=False, **kw)      # 12 levels: some lie below the perturbation sponge
+    assert needle in str(e.value), str(e.value)
+
+
+def test_nonhydrostatic_needs_three_levels():
+    with pytest.raises(Exception) as e:
+        Case(nx=10, ny=8, npz=2, backend="emul", oracle=False, hydrostatic=0, hord_ks_traj=0, hord_ks_pert=0)
+    assert "npz" in str(e.value)
