@@ -638,9 +638,13 @@ __global__ void __launch_bounds__(BX* BY) k_stage_multi_ad(Multi<S> m, Rect Q0, 
   if (2 >= r && 2 < m.n && Q2.has(i, j)) ad_point(m.s[2], c, m.R[2], i, j, blockIdx.z, nkmax);
   if (3 >= r && 3 < m.n && Q3.has(i, j)) ad_point(m.s[3], c, m.R[3], i, j, blockIdx.z, nkmax);
 }
+// The merged adjoint (four inlined gathers) measured faster for some stages and much slower for others (register
+// pressure): opt-in per stage with `static constexpr bool MERGE_AD_STRIPS = true`; the forward modes always merge.
+template <class S, class = void> struct merge_ad_strips { static constexpr bool value = false; };
+template <class S> struct merge_ad_strips<S, typename std::enable_if<S::MERGE_AD_STRIPS>::type> { static constexpr bool value = true; };
 template <class S>
 void run_multi(Exec& ex, int mode, const S* s0, int n, const Ctx& c) {
-  if (n > MAXSTRIP) { for (int r = 0; r < n; ++r) run(ex, mode, s0[r], c); return; }
+  if (n > MAXSTRIP || (mode == MODE_AD && !merge_ad_strips<S>::value)) { for (int r = 0; r < n; ++r) run(ex, mode, s0[r], c); return; }
   Multi<S> m; m.n = n;
   Rect Q[MAXSTRIP]; int nkmax = 0; double bytes = 0.;
   for (int r = 0; r < MAXSTRIP; ++r) {
@@ -663,7 +667,7 @@ void run_multi(Exec& ex, int mode, const S* s0, int n, const Ctx& c) {
   const dim3 grid(m.boff[n], 1, nz);
   if (mode == MODE_NL) hipLaunchKernelGGL((k_stage_multi_fw<S, false>), grid, dim3(BX, BY), 0, ex.stream, m, c);
   else if (mode == MODE_TL) hipLaunchKernelGGL((k_stage_multi_fw<S, true>), grid, dim3(BX, BY), 0, ex.stream, m, c);
-  else hipLaunchKernelGGL(k_stage_multi_ad<S>, grid, dim3(BX, BY), 0, ex.stream, m, Q[0], Q[1], Q[2], Q[3], c, nkmax);
+  else if constexpr (merge_ad_strips<S>::value) hipLaunchKernelGGL(k_stage_multi_ad<S>, grid, dim3(BX, BY), 0, ex.stream, m, Q[0], Q[1], Q[2], Q[3], c, nkmax);
   ex.mark_end();
   ex.launches++;
   if constexpr (S::NALIAS > 0) if (mode == MODE_AD && c.g.face)

@@ -42,12 +42,15 @@ namespace fv3 {
 // strips next to the face edges (dycore.h add_face).
 template <class D, class = void> struct d_lds_fw { static constexpr bool v = false; };
 template <class D> struct d_lds_fw<D, typename std::enable_if<D::LDS_FW_OK>::type> { static constexpr bool v = true; };
+template <class D, class = void> struct d_merge_ad { static constexpr bool v = false; };
+template <class D> struct d_merge_ad<D, typename std::enable_if<D::MERGE_AD_OK>::type> { static constexpr bool v = true; };
 template <class D, class = void> struct d_lds_ad { static constexpr bool v = false; };
 template <class D> struct d_lds_ad<D, typename std::enable_if<D::LDS_AD_OK>::type> { static constexpr bool v = true; };
 template <class D, bool EDGE>
 struct Edged : D {
   // bulk launch: tiles + halos staged through LDS for the stages and modes where that measured faster (exec.h)
   static constexpr bool LDS_FW = !EDGE && d_lds_fw<D>::v, LDS_AD = !EDGE && d_lds_ad<D>::v;
+  static constexpr bool MERGE_AD_STRIPS = EDGE && d_merge_ad<D>::v;     // adjoint of the four strips in one launch (exec.h run_multi)
   static constexpr int LDS_BY = 8;
   Edged() = default;
   Edged(const D& d) : D(d) {}
@@ -693,6 +696,7 @@ typedef Edged<DswKeWindsD, false> DswKeWinds;
 typedef Edged<DswKeWindsD, true> DswKeWindsE;
 // KE = 0.5*(vb*ytp_v + ub*xtp_u), face corners from the edge-normal winds (sw_core_tlm.F90:3197-3273)
 struct DswKeD {
+  static constexpr bool MERGE_AD_OK = true;
   static constexpr bool LDS_FW_OK = true;
   STAGE_COMMON("DswKe", 6, 1)   // in: vb ub u v ut vt   out: ke
   double dt;
