@@ -172,7 +172,7 @@ def main():
                 set_allreduce_callback(lib, allmax)
         active = len(cube.faces_of(rank, world)) > 0
         if active:
-            nhkw = dict(hydrostatic=0, hord_ks_traj=0, hord_ks_pert=0) if args.nonhydrostatic else {}
+            nhkw = dict(hydrostatic=0) if args.nonhydrostatic else {}
             c = CubeCase(n=args.nx, npz=args.npz, n_split=args.n_split, k_split=args.k_split, dt=args.dt, backend="hip", nq=args.nq,
                          rank=rank, world=world, **nhkw)
             T, P = cube_step_state(c)

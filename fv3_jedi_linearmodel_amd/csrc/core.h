@@ -138,6 +138,7 @@ constexpr int NMETRIC = 32 + 18;
 // Per-level resolved options (dyn_core_tlm.F90:741-921), device array of npz entries.
 struct LevelParams {
   int hord_mt, hord_vt, hord_tm, hord_dp, hord_tr;
+  int hord_tm_g;            // flagstruct%hord_tm as passed to UPDATE_DZ_D for all npz+1 interfaces (dyn_core_tlm.F90:1091): no sponge override
   int nord, nord_v, nord_w, nord_t, nord_v_pert;
   double d2_divg, damp_vt, damp_w, damp_t, d_con, damp_vt_pert;
   // tracer_2d sub-cycling of the current call (fv_tracer2d_tlm.F90:1306-1345): sub-steps this level takes and 1/that

@@ -31,8 +31,16 @@ inline void h2d(Exec&, void* d, const void* s, size_t n) { std::memcpy(d, s, n);
 inline void d2h(Exec&, void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
 inline void dev_sync(Exec&) {}
 #else
-#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); std::abort(); } } while (0)
-inline void* dev_alloc(size_t n) { void* p = nullptr; HIPCHK(hipMalloc(&p, n ? n : 8)); HIPCHK(hipMemset(p, 0, n ? n : 8)); return p; }
+// no abort(): the failure is recorded (exec.h sticky_error) and surfaces as the status of the C-ABI call
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { char b_[320]; std::snprintf(b_, sizeof b_, "HIP error '%s' at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #x); set_sticky(b_); } } while (0)
+inline void* dev_alloc(size_t n) {
+  void* p = nullptr;
+  if (!sticky_error().empty()) return nullptr;                // after a failure (e.g. out of memory at C384) nothing more is allocated
+  const hipError_t e = hipMalloc(&p, n ? n : 8);
+  if (e != hipSuccess) { char b_[200]; std::snprintf(b_, sizeof b_, "hipMalloc of %zu bytes failed: %s", n, hipGetErrorString(e)); set_sticky(b_); (void)hipGetLastError(); return nullptr; }
+  HIPCHK(hipMemset(p, 0, n ? n : 8));
+  return p;
+}
 inline void dev_free(void* p) { if (p) (void)hipFree(p); }
 inline void dev_zero(Exec& ex, void* p, size_t n) { HIPCHK(hipMemsetAsync(p, 0, n, ex.stream)); }
 inline void dev_copy(Exec& ex, void* d, const void* s, size_t n) { HIPCHK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, ex.stream)); }
@@ -48,7 +56,7 @@ struct Arena {
   void init(size_t ndoubles) { cap = ndoubles; t = (double*)dev_alloc(cap * 8); p = (double*)dev_alloc(cap * 8); used = 0; }
   void destroy() { dev_free(t); dev_free(p); t = p = nullptr; }
   Fld take(size_t n, int nk) {
-    if (used + n > cap) { std::fprintf(stderr, "fv3lm: arena overflow\n"); std::abort(); }
+    if (used + n > cap) { set_sticky("internal sizing error: field arena overflow"); Fld f; f.t = t; f.p = p; f.nk = nk; return f; }   // create() fails; nothing runs on it
     Fld f; f.t = t + used; f.p = p + used; f.nk = nk; used += n; return f;
   }
 };
@@ -105,6 +113,7 @@ inline bool resolve_level(const Options& o, int k, int npz, LevelParams& lp) {
     if (o.do_vort_damp_pert) { nord_v_pert = 0; damp_vt_pert = 0.5 * d2p; }
   }
   lp.hord_mt = hord_m; lp.hord_vt = hord_v; lp.hord_tm = hord_t; lp.hord_dp = hord_p; lp.hord_tr = o.hord_tr;
+  lp.hord_tm_g = o.hord_tm;
   lp.nord = nord_k; lp.nord_v = nord_v; lp.nord_w = nord_w; lp.nord_t = nord_t; lp.nord_v_pert = nord_v_pert;
   lp.d2_divg = d2_divg; lp.damp_vt = damp_vt; lp.damp_w = damp_w; lp.damp_t = damp_t; lp.d_con = d_con_k;
   lp.damp_vt_pert = damp_vt_pert;
@@ -154,7 +163,7 @@ struct Dycore {
 
   Fld& f(const char* n) {
     auto it = F.find(n);
-    if (it == F.end()) { std::fprintf(stderr, "fv3lm: unknown field %s\n", n); std::abort(); }
+    if (it == F.end()) { set_sticky(std::string("internal error: unknown field ") + n); static Fld none; none = Fld{}; return none; }
     return it->second;
   }
   Fld S(const char* n, int nk) { Fld x = state.take((size_t)g.ntile * nk * g.plane, nk); F[n] = x; return x; }
@@ -345,6 +354,15 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
   nh = !o.hydrostatic;
   if (nh && npz < 3) { err = "non-hydrostatic solver needs npz >= 3"; return false; }
   if (nh && !(o.a_imp > 0.5)) { err = "non-hydrostatic: a_imp must be > 0.5 (semi-implicit solver; the reference's a_imp <= 0.5 Riemann-invariant solver is not built)"; return false; }
+  // options whose other values are not built are refused, never silently replaced by what is built:
+  //   remap profiles: only the linear one, |kord| > 16 (fv_mapz_tlm.F90:8653-8666; the limited profiles are the split_kord work of DESIGN.md §8)
+  for (int kd : {o.kord_tm, o.kord_mt, o.kord_wz, o.kord_tr})
+    if ((kd < 0 ? -kd : kd) <= 16) { err = "kord_tm/kord_mt/kord_wz/kord_tr: only |kord| > 16 (the linear profile of the TL/AD reference) is built"; return false; }
+  //   tracer advection: the perturbation runs with the trajectory scheme (no split_hord recompute); hord_tr_ks_* are read by the
+  //   reference's namelist but used nowhere on the path (fv_control_tlmadm.F90:166-172), so they are accepted and ignored here too
+  if (nq_ > 0 && o.hord_tr != o.hord_tr_pert) { err = "trajectory/perturbation hord split (split_hord) not supported: hord_tr != hord_tr_pert"; return false; }
+  if (nh && o.hord_tm != o.hord_tm_pert) { err = "trajectory/perturbation hord split (split_hord) not supported: hord_tm != hord_tm_pert (update_dz_d)"; return false; }
+  if (nh && o.hord_tm != 1 && o.hord_tm != 2 && o.hord_tm != 333) { err = "hord must be 1, 2 or 333 (the schemes the TL/AD reference implements)"; return false; }
   lev_host.resize(npz + 1);
   for (int k = 1; k <= npz; ++k) {
     if (!resolve_level(o, k, npz, lev_host[k - 1])) { err = "trajectory/perturbation hord split (split_hord) not supported"; return false; }
@@ -680,7 +698,7 @@ inline void Dycore::build_acoustic() {
     { DswRa s; s.in[0] = xfx_e; s.in[1] = yfx_e; s.out[0] = rax_e; s.out[1] = ray_e; s.orect[0] = R(is, ie, jsd, jed); s.orect[1] = R(isd, ied, js, je);
       s.k1 = npz + 1; add(P, "update_dz_d", s); }
     Fld fxz = W("fxz", npz + 1), fyz = W("fyz", npz + 1), d6z = W("del6_z", npz + 1), zh_a = W("zh_a", npz + 1);
-    build_tp(P, "update_dz_d", "tpz", zh, crx_e, cry_e, xfx_e, yfx_e, rax_e, ray_e, xfx_e, yfx_e, Fld{}, HORD_TM, DAMP_NONE, false, fxz, fyz, npz + 1);
+    build_tp(P, "update_dz_d", "tpz", zh, crx_e, cry_e, xfx_e, yfx_e, rax_e, ray_e, xfx_e, yfx_e, Fld{}, HORD_TM_G, DAMP_NONE, false, fxz, fyz, npz + 1);   // the global hord_tm for every interface (dyn_core_tlm.F90:1091, nh_utils_tlm.F90:496-514)
     { Del6AD s; s.in[0] = zh; s.out[0] = d6z; s.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); s.k1 = npz + 1; add_face(P, "update_dz_d", s, 1); }
     { UpdateDzD s; s.in[0] = zh; s.in[1] = d6z; s.in[2] = fxz; s.in[3] = fyz; s.in[4] = rax_e; s.in[5] = ray_e; s.out[0] = zh_a;
       s.orect[0] = R(is, ie, js, je); s.k1 = npz + 1; add(P, "update_dz_d", s); }

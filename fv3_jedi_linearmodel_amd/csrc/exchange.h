@@ -172,12 +172,17 @@ inline bool run_transport(Exec& ex, const ExRemote& x, bool reverse, size_t per_
   }
 #ifndef FV3LM_HOST_EMUL
   if (!T.comm) { err = "halo exchange with another rank needed before fv3lm_comm_init"; return false; }
-  T.pGroupStart();
+  // every RCCL result is checked: a failed send or receive must not leave the halo silently stale
+  ncclResult_t rc_ = T.pGroupStart();
+  if (rc_ != ncclSuccess) { err = "ncclGroupStart failed (code " + std::to_string((int)rc_) + ")"; return false; }
+  bool ok = true; int bad = 0;
   for (int p = 0; p < np; ++p) {
-    if (sc[p]) T.pSend(sb[p], (size_t)sc[p], ncclDouble, x.peer[p], T.comm, ex.stream);
-    if (rc[p]) T.pRecv(rb[p], (size_t)rc[p], ncclDouble, x.peer[p], T.comm, ex.stream);
+    if (sc[p]) { const ncclResult_t r = T.pSend(sb[p], (size_t)sc[p], ncclDouble, x.peer[p], T.comm, ex.stream); if (r != ncclSuccess) { ok = false; bad = (int)r; } }
+    if (rc[p]) { const ncclResult_t r = T.pRecv(rb[p], (size_t)rc[p], ncclDouble, x.peer[p], T.comm, ex.stream); if (r != ncclSuccess) { ok = false; bad = (int)r; } }
   }
-  if (T.pGroupEnd() != ncclSuccess) { err = "RCCL send/recv group failed"; return false; }
+  rc_ = T.pGroupEnd();        // always closed, also after a failed call inside the group
+  if (!ok) { err = "ncclSend/ncclRecv failed (code " + std::to_string(bad) + ")"; return false; }
+  if (rc_ != ncclSuccess) { err = "ncclGroupEnd failed (code " + std::to_string((int)rc_) + ")"; return false; }
   return true;
 #else
   err = "halo exchange with another rank needed but no transport callback is set";

@@ -14,6 +14,13 @@
 
 namespace fv3 {
 
+// A library a Fortran host links must not abort (include/fv3lm.h: every entry point returns a status).  The first failure of
+// a HIP call, allocation or internal sizing check is recorded here and the work goes on as no-ops where it can; every C-ABI
+// entry point reports it through its status and fv3lm_last_error() (fv3lm_capi.cpp status()).  One process drives one GPU
+// (like one MPI rank of the reference), so the record is per process.
+inline std::string& sticky_error() { static std::string e; return e; }
+inline void set_sticky(const std::string& m) { if (sticky_error().empty()) sticky_error() = m; }
+
 // Per-kernel measurement: HIP events recorded on the library's own stream around every launch while
 // profiling is on (bench.py's roofline leg), aggregated by kernel name together with the algorithmic
 // bytes of each launch (compulsory reads+writes of the launch's fields).
@@ -39,7 +46,7 @@ struct Exec {
     if (!profiling) return;
     ProfRec r; r.name = std::string(name) + suffix; r.bytes = bytes;
 #ifndef FV3LM_HOST_EMUL
-    (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1); (void)hipEventRecord(r.e0, stream);
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess || hipEventRecord(r.e0, stream) != hipSuccess) { set_sticky("profiling: hipEventCreate/Record failed"); profiling = false; return; }
 #endif
     recs.push_back(r);
   }

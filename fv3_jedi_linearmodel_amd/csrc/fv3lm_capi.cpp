@@ -31,12 +31,15 @@ int fv3lm_create(fv3lm_handle** out, const fv3lm_dims* dm, const fv3lm_options* 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail("fv3lm_create: no HIP device visible (this library has no CPU fallback)");
 #endif
+  sticky_error().clear();
   fv3lm_handle* h = new fv3lm_handle;
+  // every failure path releases what was allocated so far (destroy2 / destroy accept a partly built object)
+  auto bail = [&](std::string e) { h->d.destroy2(); h->d.destroy(); delete h; return fail("fv3lm_create: " + e); };   // e by value: it may live in *h
   if (!h->d.init(dm->nx, dm->ny, dm->npz, dm->ntile, dm->face, dm->nq, dm->dt, dm->n_split, dm->k_split, *opt, metrics, da_min,
-                 da_min_c, phis)) {
-    std::string e = h->d.err; delete h; return fail("fv3lm_create: " + e);
-  }
-  if (!h->d.init2(ak, bk)) { std::string e = h->d.err; delete h; return fail("fv3lm_create: " + e); }
+                 da_min_c, phis)) return bail(h->d.err);
+  if (!sticky_error().empty()) return bail(sticky_error());
+  if (!h->d.init2(ak, bk)) return bail(h->d.err);
+  if (!sticky_error().empty()) return bail(sticky_error());
   *out = h;
   return 0;
 }
@@ -55,15 +58,25 @@ int fv3lm_field_levels(fv3lm_handle* h, const char* name) { Fld f; return find(h
 int fv3lm_field_put(fv3lm_handle* h, const char* name, int which, const double* host) {
   Fld f; if (!find(h, name, f)) return 1;
   h2d(h->d.ex, which ? f.p : f.t, host, (size_t)h->d.g.ntile * f.nk * h->d.g.plane * 8);
-  return 0;
+  return sticky_error().empty() ? 0 : fail(sticky_error());
 }
 int fv3lm_field_get(fv3lm_handle* h, const char* name, int which, double* host) {
   Fld f; if (!find(h, name, f)) return 1;
   d2h(h->d.ex, host, which ? f.p : f.t, (size_t)h->d.g.ntile * f.nk * h->d.g.plane * 8);
-  return 0;
+  return sticky_error().empty() ? 0 : fail(sticky_error());
 }
 // sticky conditions a sweep may have run into
 static int status(fv3lm_handle* h) {
+#ifndef FV3LM_HOST_EMUL
+  { const hipError_t e = hipGetLastError();      // launch-time failures (bad configuration, out of resources) of the kernels queued so far
+    if (e != hipSuccess) set_sticky(std::string("HIP kernel launch failed: ") + hipGetErrorString(e)); }
+  if (const char* dbg = std::getenv("FV3LM_DEBUG_SYNC")) if (dbg[0] == '1') {   // debug runs: execution-time faults surface at the call that caused them
+    const hipError_t e = hipStreamSynchronize(h->d.ex.stream);
+    if (e != hipSuccess) set_sticky(std::string("HIP stream failed: ") + hipGetErrorString(e));
+  }
+#endif
+  if (!sticky_error().empty()) return fail(sticky_error());
+  if (!h->d.err.empty() && h->d.halo_missing) return fail(h->d.err);
   if (h->d.halo_missing) return fail("halo exchange needed before fv3lm_set_exchange provided its table (face mode)");
   if (h->d.tracer_subcycle_error) return fail("tracer_2d: accumulated Courant number > 60: trajectory is not usable");
   if (h->d.nh_overflow()) return fail("non-hydrostatic column solver: reverse-mode tape overflow (internal sizing error)");
@@ -137,20 +150,20 @@ int fv3lm_dyn_core(fv3lm_handle* h, int mode) {
   h->d.dyn_core(mode);
   return status(h);
 }
-int fv3lm_pressures(fv3lm_handle* h, int mode) { h->d.pressures(mode); return 0; }
+int fv3lm_pressures(fv3lm_handle* h, int mode) { h->d.pressures(mode); return status(h); }
 int fv3lm_tracer_2d(fv3lm_handle* h, int mode) {
   if (mode == MODE_AD) h->d.tracer_ad(); else h->d.tracer_fwd(mode);
   return status(h);
 }
 int fv3lm_traj_slots(fv3lm_handle* h) { return (int)h->d.traj_slot.size(); }   /* acoustic steps whose intermediates stay resident */
 int fv3lm_tracer_nsplt(fv3lm_handle* h) { return h->d.nsplt_max; }   /* largest sub-step count tracer_2d has used so far */
-int fv3lm_remap(fv3lm_handle* h, int mode, int last_step) { run_remap(h->d.ex, mode, h->d.remap_args(last_step != 0)); return 0; }
+int fv3lm_remap(fv3lm_handle* h, int mode, int last_step) { run_remap(h->d.ex, mode, h->d.remap_args(last_step != 0)); return status(h); }
 int fv3lm_fv_dynamics(fv3lm_handle* h, int mode) { h->d.fv_dynamics(mode); return status(h); }
 int fv3lm_step_tl(fv3lm_handle* h) { h->d.step_tl(); return status(h); }
 int fv3lm_step_nl(fv3lm_handle* h) { h->d.step_nl(); return status(h); }
 int fv3lm_step_ad(fv3lm_handle* h) { h->d.step_ad(); return status(h); }
 int fv3lm_zero_work_adjoint(fv3lm_handle* h) { h->d.zero_work_adjoint(); return 0; }
-int fv3lm_sync(fv3lm_handle* h) { dev_sync(h->d.ex); return 0; }
+int fv3lm_sync(fv3lm_handle* h) { dev_sync(h->d.ex); return status(h); }
 long fv3lm_launch_count(fv3lm_handle* h) { return h->d.ex.launches; }
 int fv3lm_level_params(fv3lm_handle* h, int k, int* ip, double* rp) {
   if (k < 1 || k > h->d.g.npz) return fail("level out of range");

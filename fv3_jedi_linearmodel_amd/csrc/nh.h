@@ -216,7 +216,10 @@ HD void riem3_col(const IO& io, const NhColArgs& a, const ColWs& ws, double hs) 
     w2.set(k, io.ld(1, k)); pt2.set(k, io.ld(2, k));
     p_ = p; l_ = l;
   }
-  nh_sim(io, ws, km, a.dt, a.rdgas, gama, a.akap, wsfc, a.a_imp, a.p_fac, a.scale_z);
+  // solver dispatch of RIEM_SOLVER3 (nh_core_tlm.F90:155-189): a_imp > 0.999 -> SIM1_SOLVER (fully implicit, no scale_m), else SIM_SOLVER;
+  // a_imp <= 0.5 (RIM_2D, SIM3) is refused at create
+  if (a.a_imp > 0.999) nh_sim1(io, ws, km, a.dt, a.rdgas, gama, a.akap, wsfc, a.p_fac);
+  else nh_sim(io, ws, km, a.dt, a.rdgas, gama, a.akap, wsfc, a.a_imp, a.p_fac, a.scale_z);
   for (int k = 1; k <= km; ++k) { io.st(4, k, w2(k)); io.st(5, k, dz2(k)); }
   for (int k = 1; k <= km + 1; ++k) io.st(7, k, pe(k));
   T z = io.cst(zs);

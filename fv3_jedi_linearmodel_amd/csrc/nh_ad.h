@@ -280,7 +280,9 @@ HD void riem3_col_ad(const NhColArgs& a, const ColWs& ws, int tile, int i, int j
   const Geom& g = a.g; const int km = g.npz;
   const NhAdCol W{ws, km};
   const double gama = 1. / (1. - a.akap), rgrav = 1. / a.grav, zs = hs * rgrav, dt = a.dt, rdt = 1. / dt, rgas = a.rdgas;
-  const double alpha = a.a_imp, beta = 1. - alpha, ra = 1. / alpha, t2 = beta / alpha, t1g = 2. * gama * (alpha * dt) * (alpha * dt), scale_m = a.scale_z;
+  // a_imp > 0.999: the reference runs SIM1_SOLVER (nh_core_tlm.F90:176-181) = this sweep with alpha = 1 and no scale_m term
+  const bool sim1 = a.a_imp > 0.999;
+  const double alpha = sim1 ? 1. : a.a_imp, beta = 1. - alpha, ra = 1. / alpha, t2 = beta / alpha, t1g = 2. * gama * (alpha * dt) * (alpha * dt), scale_m = sim1 ? 0. : a.scale_z;
   auto F = [&](int sl, int k) -> size_t { return fidx(g, a.f[sl], tile, i, j, k); };
   // ---------------- forward replay with storage
   nhad_dz_fwd(W, a, tile, i, j);

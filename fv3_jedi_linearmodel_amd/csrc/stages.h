@@ -504,9 +504,9 @@ struct DswRa {   // sw_core_tlm.F90:2969-2978
 };
 
 // ---- fv_tp_2d building blocks (tp_core_tlm.F90:83-236) ----
-enum HordSel { HORD_MT = 0, HORD_VT, HORD_TM, HORD_DP, HORD_TR };
+enum HordSel { HORD_MT = 0, HORD_VT, HORD_TM, HORD_DP, HORD_TR, HORD_TM_G };
 HD int hord_of(const LevelParams& l, int sel) {
-  return sel == HORD_MT ? l.hord_mt : sel == HORD_VT ? l.hord_vt : sel == HORD_TM ? l.hord_tm : sel == HORD_DP ? l.hord_dp : l.hord_tr;
+  return sel == HORD_MT ? l.hord_mt : sel == HORD_VT ? l.hord_vt : sel == HORD_TM ? l.hord_tm : sel == HORD_DP ? l.hord_dp : sel == HORD_TM_G ? l.hord_tm_g : l.hord_tr;
 }
 // Line accessors by absolute cell index along x / y; corner-halo points are read through the
 // copy_corners view of the sweep direction (cdir = 1 for x sweeps, 2 for y sweeps, 0: as stored).

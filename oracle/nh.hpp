@@ -146,7 +146,7 @@ void riem_solver_c(double dt, int km, double akap, double ptop, const Arr2<doubl
     }
 }
 
-// RIEM_SOLVER3, nh_core_tlm.F90:245-389 (a_imp in (0.5, 0.999]: SIM_SOLVER; use_logp = fp_out = .false.) on is..ie, js..je.
+// RIEM_SOLVER3, nh_core_tlm.F90:245-389 (a_imp in (0.5, 0.999]: SIM_SOLVER, a_imp > 0.999: SIM1_SOLVER; use_logp = fp_out = .false.) on is..ie, js..je.
 template <class T>
 void riem_solver3(double dt, int km, double akap, double ptop, const Arr2<double>& zs, Arr3<T>& w, Arr3<T>& delz, const Arr3<T>& pt,
                   const Arr3<T>& delp, Arr3<T>& zh, Arr3<T>& pe, Arr3<T>& ppe, Arr3<T>& pk3, Arr3<T>& pk, Arr3<T>& peln, const Arr2<T>& ws,
@@ -165,7 +165,9 @@ void riem_solver3(double dt, int km, double akap, double ptop, const Arr2<double
         w2[k] = w(i, j, k);
         pt2[k] = pt(i, j, k);
       }
-      sim_solver(dt, km, c.rdgas, gama, akap, pe2, dm, pm2, pem, w2, dz2, pt2, ws(i, j), nh.a_imp, nh.p_fac, nh.scale_z);
+      // nh_core_tlm.F90:155-189: a_imp > 0.999 -> SIM1_SOLVER, (0.5, 0.999] -> SIM_SOLVER (RIM_2D / SIM3 not restated)
+      if (nh.a_imp > 0.999) sim1_solver(dt, km, c.rdgas, gama, akap, pe2, dm, pm2, pem, w2, dz2, pt2, ws(i, j), nh.p_fac);
+      else sim_solver(dt, km, c.rdgas, gama, akap, pe2, dm, pm2, pem, w2, dz2, pt2, ws(i, j), nh.a_imp, nh.p_fac, nh.scale_z);
       for (int k = 1; k <= km; ++k) { w(i, j, k) = w2[k]; delz(i, j, k) = dz2[k]; }
       if (last_call) for (int k = 1; k <= km + 1; ++k) { peln(i, j, k) = peln2[k]; pk(i, j, k) = pk3(i, j, k); pe(i, j, k) = pem[k]; }
       for (int k = 1; k <= km + 1; ++k) ppe(i, j, k) = pe2[k];

@@ -20,7 +20,7 @@ def main():
     nh = os.environ.get("FV3LM_DIST_NH", "0") == "1"      # non-hydrostatic: w, delz prognostic; w / heights / pressures join the exchanges
     kw = dict(n=8, npz=6, n_split=2, k_split=2, backend="emul", nq=2)
     if nh:
-        kw.update(hydrostatic=0, hord_ks_traj=0, hord_ks_pert=0, dt=1200.0)
+        kw.update(hydrostatic=0, dt=1200.0)
     ref = CubeCase(**kw)                       # whole cube in this process
     c = CubeCase(rank=rank, world=world, **kw)   # this rank's faces
 

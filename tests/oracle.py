@@ -21,6 +21,11 @@ def _ptr(a):
     return a.ctypes.data_as(_dp)
 
 
+def _nh_opts(opt, a_imp, p_fac, scale_z):
+    """solver options default to the case's fv3lm_options (the same struct the product was created with)"""
+    return (opt.a_imp if a_imp is None else a_imp, opt.p_fac if p_fac is None else p_fac, opt.scale_z if scale_z is None else scale_z)
+
+
 class Oracle:
     def __init__(self, nx, ny, npz, nq, metrics, opt, da_min, da_min_c, phis, ak, bk):
         L = self.L = C.CDLL(build_oracle())
@@ -29,6 +34,7 @@ class Oracle:
         names = L.orc_metric_names().decode().split(",")
         self.nx, self.ny, self.npz = nx, ny, npz
         self.pj, self.pi = ny + 7, nx + 7
+        self.opt = opt
         arrs = [np.ascontiguousarray(metrics[n][0], dtype=np.float64) for n in names]
         mp = (_dp * len(arrs))(*[_ptr(a) for a in arrs])
         il = opt.int_list()
@@ -106,8 +112,9 @@ class Oracle:
         return self._call("orc_dyn_core", mode, [C.c_double(bdt), C.c_int(n_split)], ins, ins_p,
                           [n] * 8 + [n + 1, n + 1, n + 1, n], outs_p)
 
-    def dyn_core_nh(self, mode, bdt, n_split, ins, ins_p=None, outs_p=None, a_imp=0.75, p_fac=0.05, scale_z=0.0):
+    def dyn_core_nh(self, mode, bdt, n_split, ins, ins_p=None, outs_p=None, a_imp=None, p_fac=None, scale_z=None):
         n = self.npz
+        a_imp, p_fac, scale_z = _nh_opts(self.opt, a_imp, p_fac, scale_z)
         return self._call("orc_dyn_core_nh", mode, [C.c_double(bdt), C.c_int(n_split), C.c_double(a_imp), C.c_double(p_fac), C.c_double(scale_z)],
                           ins, ins_p, [n] * 6 + [n + 1] * 4, outs_p)
 
@@ -127,7 +134,8 @@ class Oracle:
         return self._call("orc_fv_dynamics", mode, [C.c_int(nq), C.c_double(bdt), C.c_int(n_split), C.c_int(k_split)],
                           ins, ins_p, [self.npz] * (4 + nq), outs_p)
 
-    def fv_dynamics_nh(self, mode, nq, bdt, n_split, k_split, ins, ins_p=None, outs_p=None, a_imp=0.75, p_fac=0.05, scale_z=0.0):
+    def fv_dynamics_nh(self, mode, nq, bdt, n_split, k_split, ins, ins_p=None, outs_p=None, a_imp=None, p_fac=None, scale_z=None):
+        a_imp, p_fac, scale_z = _nh_opts(self.opt, a_imp, p_fac, scale_z)
         return self._call("orc_fv_dynamics_nh", mode, [C.c_int(nq), C.c_double(bdt), C.c_int(n_split), C.c_int(k_split), C.c_double(a_imp),
                                                        C.c_double(p_fac), C.c_double(scale_z)], ins, ins_p, [self.npz] * (6 + nq), outs_p)
 
@@ -138,6 +146,7 @@ class CubeOracle:
 
     def __init__(self, n, npz, nq, metrics, opt, da_min, da_min_c, phis, ak, bk, edge, ecorner, tables):
         self.n, self.npz, self.nq = n, npz, nq
+        self.opt = opt
         self.pj = self.pi = n + 7
         self.faces = []
         for t in range(6):
@@ -181,6 +190,7 @@ class CubeOracle:
         return self._call("orc_cube_fv_dynamics", mode, [C.c_int(nq), C.c_double(bdt), C.c_int(n_split), C.c_int(k_split)], ins, ins_p,
                           [self.npz] * (4 + nq), outs_p)
 
-    def fv_dynamics_nh(self, mode, nq, bdt, n_split, k_split, ins, ins_p=None, outs_p=None, a_imp=0.75, p_fac=0.05, scale_z=0.0):
+    def fv_dynamics_nh(self, mode, nq, bdt, n_split, k_split, ins, ins_p=None, outs_p=None, a_imp=None, p_fac=None, scale_z=None):
+        a_imp, p_fac, scale_z = _nh_opts(self.opt, a_imp, p_fac, scale_z)
         return self._call("orc_cube_fv_dynamics_nh", mode, [C.c_int(nq), C.c_double(bdt), C.c_int(n_split), C.c_int(k_split), C.c_double(a_imp),
                                                             C.c_double(p_fac), C.c_double(scale_z)], ins, ins_p, [self.npz] * (6 + nq), outs_p)

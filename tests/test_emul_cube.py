@@ -10,7 +10,7 @@ from groups import cube_check_dyn_core, cube_dot_product, cube_check_fv_dynamics
 
 @pytest.fixture(scope="module")
 def ccase():
-    return CubeCase(n=8, npz=5, n_split=2, backend="emul", oracle=True, hord_ks_traj=0, hord_ks_pert=0)
+    return CubeCase(n=8, npz=5, n_split=2, backend="emul", oracle=True)
 
 
 def test_cube_dyn_core_tl(ccase):

@@ -32,7 +32,7 @@ from groups import check_tracer
 
 @pytest.fixture(scope="module")
 def fcase_q():
-    return Case(nx=12, ny=12, npz=6, n_split=2, dt=1800.0, backend="emul", face=4, nq=2, hord_ks_traj=0, hord_ks_pert=0)
+    return Case(nx=12, ny=12, npz=6, n_split=2, dt=1800.0, backend="emul", face=4, nq=2)
 
 
 def test_face_tracer_tl(fcase_q):

@@ -8,7 +8,11 @@ from common import Case
     (dict(nord=2), "nord"),
     (dict(hord_dp=10), "hord"),
     (dict(hord_mt=2, hord_mt_pert=1), "split_hord"),
-    (dict(hydrostatic=0, a_imp=0.4, hord_ks_traj=0, hord_ks_pert=0), "a_imp"),
+    (dict(hydrostatic=0, a_imp=0.4), "a_imp"),
+    (dict(kord_tm=-9), "kord"),
+    (dict(kord_tr=8), "kord"),
+    (dict(nq=2, hord_tr=2, hord_tr_pert=1), "hord_tr"),
+    (dict(hydrostatic=0, hord_tm=2, hord_tm_pert=1, hord_tm_ks_traj=1, hord_tm_ks_pert=1), "hord_tm"),
 ])
 def test_unsupported_options_are_refused(kw, needle):
     with pytest.raises(Exception) as e:
@@ -18,5 +22,5 @@ def test_unsupported_options_are_refused(kw, needle):
 
 def test_nonhydrostatic_needs_three_levels():
     with pytest.raises(Exception) as e:
-        Case(nx=10, ny=8, npz=2, backend="emul", oracle=False, hydrostatic=0, hord_ks_traj=0, hord_ks_pert=0)
+        Case(nx=10, ny=8, npz=2, backend="emul", oracle=False, hydrostatic=0)
     assert "npz" in str(e.value)

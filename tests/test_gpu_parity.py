@@ -143,7 +143,7 @@ def test_face_group_ad(fcase, group):
 def test_face_tracer():
     from common import Case
     from groups import check_tracer
-    c = Case(nx=12, ny=12, npz=6, n_split=2, dt=1800.0, backend="hip", face=4, nq=2, hord_ks_traj=0, hord_ks_pert=0)
+    c = Case(nx=12, ny=12, npz=6, n_split=2, dt=1800.0, backend="hip", face=4, nq=2)
     check_tracer(c, TL, 1e-11)
     check_tracer(c, AD, 1e-10)
 
@@ -151,7 +151,7 @@ def test_face_tracer():
 @pytest.fixture(scope="module")
 def cube_case():
     from common import CubeCase
-    return CubeCase(n=8, npz=5, n_split=2, backend="hip", oracle=True, hord_ks_traj=0, hord_ks_pert=0)
+    return CubeCase(n=8, npz=5, n_split=2, backend="hip", oracle=True)
 
 
 KINDS = [("cell", "delp", ""), ("dvec", "u", "v"), ("cvec", "uc", "vc"), ("corner", "divgd", ""), ("dedge", "u_o", "v_o")]

@@ -42,14 +42,14 @@ def nh_state_fv(c, seed=5):
 
 @pytest.fixture(scope="module")
 def nhcase():
-    return Case(nx=10, ny=8, npz=8, n_split=2, dt=600.0, backend="none", hord_ks_traj=0, hord_ks_pert=0)
+    return Case(nx=10, ny=8, npz=8, n_split=2, dt=600.0, backend="none")
 
 
 @pytest.fixture(scope="module")
 def nhcase_fd():
     """The reference damps the vorticity of the perturbation with its own coefficients (sw_core_tlm.F90:2436-2452), so its
     tangent is the derivative of the nonlinear code only where both sets coincide: vorticity damping off on both sides here."""
-    return Case(nx=10, ny=8, npz=8, n_split=2, dt=600.0, backend="none", hord_ks_traj=0, hord_ks_pert=0, do_vort_damp=0,
+    return Case(nx=10, ny=8, npz=8, n_split=2, dt=600.0, backend="none", do_vort_damp=0,
                 do_vort_damp_pert=0)
 
 
@@ -98,7 +98,7 @@ def test_nh_adjoint_dot_product(nhcase):
 
 @pytest.fixture(scope="module")
 def nhcase_fv():
-    return Case(nx=10, ny=8, npz=8, n_split=2, k_split=2, dt=1200.0, nq=2, backend="none", hord_ks_traj=0, hord_ks_pert=0, do_vort_damp=0,
+    return Case(nx=10, ny=8, npz=8, n_split=2, k_split=2, dt=1200.0, nq=2, backend="none", do_vort_damp=0,
                 do_vort_damp_pert=0)
 
 
@@ -135,3 +135,15 @@ def test_nh_fv_dynamics_adjoint_dot_product(nhcase_fv):
     lhs = sum(float(np.sum(y * s)) for y, s in zip(tl, seeds))
     rhs = sum(float(np.sum(x * p)) for x, p in zip(ad, P))
     assert abs(lhs - rhs) <= 1e-10 * abs(lhs), (lhs, rhs)
+
+
+def test_nh_sim1_dispatch_tangent_matches_finite_differences():
+    """a_imp > 0.999: RIEM_SOLVER3 runs SIM1_SOLVER (nh_core_tlm.F90:176-181); the restated dispatch against finite differences"""
+    c = Case(nx=10, ny=8, npz=8, n_split=2, dt=600.0, backend="none", do_vort_damp=0, do_vort_damp_pert=0, a_imp=1.0, scale_z=0.3)
+    test_nh_tangent_matches_finite_differences(c)
+    c075 = Case(nx=10, ny=8, npz=8, n_split=2, dt=600.0, backend="none", do_vort_damp=0, do_vort_damp_pert=0, a_imp=0.75, scale_z=0.3)
+    T, P = nh_state(c)
+    a, _ = c.oracle.dyn_core_nh(NL, c.dims.dt, c.dims.n_split, T)
+    b, _ = c075.oracle.dyn_core_nh(NL, c.dims.dt, c.dims.n_split, T)
+    A = c.rect(1, c.nx, 1, c.ny)
+    assert np.max(np.abs(a[4][A] - b[4][A])) > 1e-6         # the two solvers do differ
