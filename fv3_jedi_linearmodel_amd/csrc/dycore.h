@@ -16,6 +16,8 @@
 #include "nh_ad.h"
 #include <functional>
 #include <map>
+#include <memory>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -124,6 +126,14 @@ struct Op {
   std::string group;
   std::function<void(Exec&, int)> fn;   // mode-aware
   bool accum = false;                   // flux-capacitor update: skipped in the adjoint's trajectory recompute
+  // adjoint bookkeeping for Dycore::plan_adjoint: the adjoint buffers (.p) the op's adjoint accumulates into (its forward
+  // inputs) and the ones it reads (its forward outputs); stage ops can be switched to store-instead-of-accumulate per input
+  std::vector<double*> ad_in, ad_out;
+  std::vector<int> ad_in_slot;                 // stage input index of each ad_in entry
+  std::function<void(unsigned)> set_wmask;     // stage ops only
+  std::string name;                            // stage name (diagnostics)
+  Op() = default;
+  Op(std::string g_, std::function<void(Exec&, int)> f_, bool acc_ = false) : group(std::move(g_)), fn(std::move(f_)), accum(acc_) {}
 };
 typedef std::vector<Op> Program;
 
@@ -181,7 +191,9 @@ struct Dycore {
     if (!g.face) { add(P, grp, Edged<D, false>(s)); return; }
     const int lo = 1 + W, hi = g.nx - W, BIG = 1 << 20;
     const Rect regs[5] = {{lo, hi, lo, hi}, {-BIG, BIG, -BIG, lo - 1}, {-BIG, BIG, hi + 1, BIG}, {-BIG, lo - 1, lo, hi}, {hi + 1, BIG, lo, hi}};
-    std::vector<Edged<D, true>> strips;
+    // program order: strips first, bulk last -- the backward sweep then runs the bulk launch first, which is the one that can
+    // store the input adjoints instead of accumulating them (plan_adjoint); the five launches are independent of each other
+    std::vector<Edged<D, true>> strips; bool have_bulk = false; Edged<D, false> bulk;
     for (int r = 0; r < 5; ++r) {
       D t = s; Rect anchor{1, 0, 1, 0}; bool any = false;
       for (int n = 0; n < D::NOUT; ++n) {
@@ -192,16 +204,27 @@ struct Dycore {
       for (int n = 0; n < D::NOUT; ++n) if (is_empty(t.orect[n])) t.orect[n] = empty_in(anchor);
       if (r == 0) {
         for (int m = 0; m < D::NIN; ++m) if ((edge_only_inputs((const D*)nullptr) >> m) & 1u) { const int nk = t.in[m].nk; t.in[m] = Fld{}; t.in[m].nk = nk; }
-        add(P, grp, Edged<D, false>(t));
+        bulk = Edged<D, false>(t); have_bulk = true;
       } else strips.push_back(Edged<D, true>(t));
     }
     add_multi(P, grp, strips);
+    if (have_bulk) add(P, grp, bulk);
   }
 
   template <class St>
+  static void declare(Op& op, const St& s) {
+    for (int m = 0; m < St::NIN; ++m) if (St::wants(m) && s.in[m].p) { op.ad_in.push_back(s.in[m].p); op.ad_in_slot.push_back(m); }
+    for (int n = 0; n < St::NOUT; ++n) op.ad_out.push_back(s.out[n].p);
+  }
+  template <class St>
   void add(Program& P, const char* group, const St& s) {
     Ctx* cp = &ctx;
-    P.push_back(Op{group, [s, cp](Exec& e, int mode) { run(e, mode, s, *cp); }});
+    auto sp = std::make_shared<St>(s);
+    Op op{group, [sp, cp](Exec& e, int mode) { run(e, mode, *sp, *cp); }};
+    declare(op, s);
+    op.set_wmask = [sp](unsigned w) { sp->wmask = w; };
+    op.name = St::name();
+    P.push_back(op);
   }
   // several instances of one stage type (the edge strips of a face) as one launch (exec.h run_multi)
   template <class St>
@@ -209,7 +232,10 @@ struct Dycore {
     if (v.empty()) return;
     if (v.size() == 1) { add(P, group, v[0]); return; }
     Ctx* cp = &ctx;
-    P.push_back(Op{group, [v, cp](Exec& e, int mode) { run_multi(e, mode, v.data(), (int)v.size(), *cp); }});
+    Op op{group, [v, cp](Exec& e, int mode) { run_multi(e, mode, v.data(), (int)v.size(), *cp); }};
+    for (const St& s : v) declare(op, s);
+    op.ad_in_slot.clear();            // strips only ever accumulate
+    P.push_back(op);
   }
   // Halo update of one field or of a staggered vector pair.  Single tile: doubly-periodic wrap; cube faces:
   // table-driven exchange (exchange.h).
@@ -224,19 +250,60 @@ struct Dycore {
   // both jobs at once and ignores it)
   void add_halo(Program& P, const char* group, int kind, Fld f0, Fld f1 = Fld{}, int when = 0) {
     Dycore* self = this;
-    P.push_back(Op{group, [self, kind, f0, f1, when](Exec&, int mode) {
+    Op op{group, [self, kind, f0, f1, when](Exec&, int mode) {
       if (self->g.face && ((when == 1 && self->last_acoustic) || (when == 2 && !self->last_acoustic))) return;
       if (!self->g.face && when == 2) return;
       self->halo(mode, kind, f0, f1);
-    }});
+    }};
+    op.ad_in = {f0.p, f1.p};          // the adjoint exchange moves halo adjoints onto their source elements: both must hold defined values
+    P.push_back(op);
   }
   bool set_face_data(const double* edge, const double* ecorner);
   bool set_exchange(int kind, const int* rows, int n);
   bool set_exchange_remote(int kind, int npeers, const int* peers, const int* nsend, const int* send_rows, const int* nrecv, const int* recv_rows);
   void add_accum(Program& P, const char* group, Fld acc, Fld x, Rect r) {
     Geom gg = g;
-    P.push_back(Op{group, [acc, x, r, gg](Exec& e, int mode) { run_accum(e, mode, gg, acc, x, r); }, true});
+    Op op{group, [acc, x, r, gg](Exec& e, int mode) { run_accum(e, mode, gg, acc, x, r); }, true};
+    op.ad_in = {x.p}; op.ad_out = {acc.p};
+    P.push_back(op);
   }
+  // Backward sweep without clearing the work adjoints.  Walking the program in reverse (= the order of the backward sweep), the
+  // first op that touches the adjoint of a work array decides: a stage launch stores it (bit in its wmask; exec.h writes the whole
+  // padded plane, zeros outside the stage's reach), anything else (column operators, exchanges, strips) needs it cleared first.  Work
+  // arrays whose adjoint is read by their producer but written by nobody (outputs without a consumer) are cleared as well.
+  // Returns the ranges of A.p to clear before every backward pass over P.
+  // preset: work arrays whose adjoint the driver sets before the backward pass (the step outputs u_o .. receive the incoming adjoint).
+  std::vector<std::pair<double*, size_t>> plan_adjoint(Program& P, const Arena& A, const std::vector<double*>& preset = {}) {
+    std::map<double*, size_t> size;
+    for (auto& kv : F) if (kv.second.p >= A.p && kv.second.p < A.p + A.cap) size[kv.second.p] = (size_t)g.ntile * kv.second.nk * g.plane;
+    auto inA = [&](double* q_) { return q_ && q_ >= A.p && q_ < A.p + A.cap; };
+    std::set<double*> written(preset.begin(), preset.end()), zero;
+    const bool off = std::getenv("FV3LM_NO_AD_WRITE_MODE") != nullptr;     // debugging aid: every work adjoint cleared, every launch accumulates
+    for (auto it = P.rbegin(); it != P.rend(); ++it) {
+      unsigned w = 0;
+      for (double* q_ : it->ad_out) if (inA(q_) && !written.count(q_)) zero.insert(q_);
+      for (size_t n = 0; n < it->ad_in.size(); ++n) {
+        double* q_ = it->ad_in[n];
+        if (!inA(q_) || written.count(q_)) continue;
+        const char* skip = std::getenv("FV3LM_AD_WRITE_SKIP");        // debugging aid: stage names (comma separated) kept in accumulate mode
+        const bool skipped = skip && ("," + std::string(skip) + ",").find("," + it->name + ",") != std::string::npos;
+        if (std::getenv("FV3LM_AD_WRITE_LIST") && it->set_wmask && !skipped && !zero.count(q_)) std::fprintf(stderr, "write-mode %s input %d\n", it->name.c_str(), it->ad_in_slot[n]);
+        if (!off && !skipped && it->set_wmask && n < it->ad_in_slot.size() && !zero.count(q_)) w |= 1u << it->ad_in_slot[n];
+        else zero.insert(q_);
+        written.insert(q_);
+      }
+      if (it->set_wmask) it->set_wmask(w);
+    }
+    std::vector<std::pair<double*, size_t>> out;
+    for (double* q_ : zero) {      // std::set iterates in address order: merge neighbours
+      const size_t n = size.count(q_) ? size[q_] : 0;
+      if (!n) { set_sticky("internal error: adjoint plan met an unregistered work array"); continue; }
+      if (!out.empty() && out.back().first + out.back().second == q_) out.back().second += n; else out.push_back({q_, n});
+    }
+    if (std::getenv("FV3LM_AD_WRITE_LIST")) { size_t tot = 0; for (auto& z_ : out) tot += z_.second; std::fprintf(stderr, "plan_adjoint: %zu work adjoints cleared per pass (%zu ranges, %.1f field-equivalents of %zu in the arena)\n", zero.size(), out.size(), double(tot) / double(n3 ? n3 : 1), size.size()); }
+    return out;
+  }
+  std::vector<std::pair<double*, size_t>> acoustic_zero;     // plan_adjoint(acoustic, work)
 
   // fv_tp_2d as a stage sequence (tp_core_tlm.F90:83-236): q -> fx, fy.  mx/my = xfx/yfx or mass fluxes.
   void build_tp(Program& P, const char* grp, const std::string& pre, Fld q, Fld crx, Fld cry, Fld xfx, Fld yfx, Fld rax,
@@ -250,23 +317,25 @@ struct Dycore {
       TpPpmY_<false> a; a.in[0] = qq; a.in[1] = cry; a.out[0] = out; a.k1 = npz; a.hsel = hsel;
       if (!g.face) { a.orect[0] = r; add(P, grp, a); return; }
       const int npy = g.ny + 1;
-      a.orect[0] = R(r.i0, r.i1, 4, npy - 3); add(P, grp, a);
+      a.orect[0] = R(r.i0, r.i1, 4, npy - 3);
       TpPpmY_<true> e; e.in[0] = qq; e.in[1] = cry; e.out[0] = out; e.k1 = npz; e.hsel = hsel; e.cdir = cdir;
       std::vector<TpPpmY_<true>> ev;
       e.orect[0] = R(r.i0, r.i1, r.j0, 3); ev.push_back(e);
       e.orect[0] = R(r.i0, r.i1, npy - 2, r.j1); ev.push_back(e);
       add_multi(P, grp, ev);
+      add(P, grp, a);          // bulk last: first in the backward sweep (plan_adjoint)
     };
     auto ppm_x = [&](Fld qq, Fld out, Rect r, int cdir) {
       TpPpmX_<false> a; a.in[0] = qq; a.in[1] = crx; a.out[0] = out; a.k1 = npz; a.hsel = hsel;
       if (!g.face) { a.orect[0] = r; add(P, grp, a); return; }
       const int npx = g.nx + 1;
-      a.orect[0] = R(4, npx - 3, r.j0, r.j1); add(P, grp, a);
+      a.orect[0] = R(4, npx - 3, r.j0, r.j1);
       TpPpmX_<true> e; e.in[0] = qq; e.in[1] = crx; e.out[0] = out; e.k1 = npz; e.hsel = hsel; e.cdir = cdir;
       std::vector<TpPpmX_<true>> ev;
       e.orect[0] = R(r.i0, 3, r.j0, r.j1); ev.push_back(e);
       e.orect[0] = R(npx - 2, r.i1, r.j0, r.j1); ev.push_back(e);
       add_multi(P, grp, ev);
+      add(P, grp, a);
     };
     ppm_y(q, fy2, R(isd, ied, js, je + 1), 2);
     TpQi b; b.in[0] = q; b.in[1] = fy2; b.in[2] = yfx; b.in[3] = ray; b.out[0] = q_i; b.orect[0] = R(isd, ied, js, je); b.k1 = npz;
@@ -303,7 +372,7 @@ struct Dycore {
     }
     // face: the 4-point formulas away from the edges, the edge formulas on strips two points wide (column strips run
     // with the wave along j, exec.h strip_tr)
-    a.orect[0] = R(3, npx - 2, 1, npy - 1); a.orect[1] = R(1, npx - 1, 3, npy - 2); add(P, grp, a);
+    a.orect[0] = R(3, npx - 2, 1, npy - 1); a.orect[1] = R(1, npx - 1, 3, npy - 2);
     A2bA_<true> ae; ae.in[0] = q; ae.out[0] = qx; ae.out[1] = qy; ae.k1 = nk;
     std::vector<A2bA_<true>> av;
     for (int e = 0; e < 4; ++e) {
@@ -311,7 +380,8 @@ struct Dycore {
       ae.orect[e < 2 ? 0 : 1] = r; ae.orect[e < 2 ? 1 : 0] = empty_in(r); av.push_back(ae);
     }
     add_multi(P, grp, av);
-    b.orect[0] = R(3, npx - 2, 3, npy - 2); add(P, grp, b);
+    add(P, grp, a);            // bulk last: first in the backward sweep (plan_adjoint)
+    b.orect[0] = R(3, npx - 2, 3, npy - 2);
     A2bB_<true> be; be.in[0] = qx; be.in[1] = qy; be.in[2] = q; be.out[0] = qb; be.k1 = nk;
     std::vector<A2bB_<true>> bv;
     for (int e = 0; e < 4; ++e) {
@@ -319,6 +389,7 @@ struct Dycore {
       bv.push_back(be);
     }
     add_multi(P, grp, bv);
+    add(P, grp, b);
   }
 
   void build_acoustic();
@@ -417,6 +488,8 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
     nh_tape.overflow = (int*)dev_alloc(8);
   }
   build_acoustic();
+  { std::vector<double*> pre; for (const char* n_ : st_out) pre.push_back(f(n_).p);
+    acoustic_zero = plan_adjoint(acoustic, work, pre); }
   ck_stride = 0;
   for (const char* n_ : st_in) ck_stride += (size_t)f(n_).nk * np;
   ckpt = (double*)dev_alloc((size_t)n_split * k_split * ck_stride * 8);
@@ -524,11 +597,17 @@ inline void Dycore::add_col(Program& P, const char* group, int kind, const NhCol
                                   {"zh_init.nl", "zh_init.tl", "zh_init.ad"}, {"p_ring.nl", "p_ring.tl", "p_ring.ad"},
                                   {"remap_field_nh.nl", "remap_field_nh.tl", "remap_field_nh.ad"}, {"remap_press_nh.nl", "remap_press_nh.tl", "remap_press_nh.ad"},
                                   {"remap_w_nh.nl", "remap_w_nh.tl", "remap_w_nh.ad"}};
-  P.push_back(Op{group, [self, kind, a, r, skip, when](Exec& e, int mode) {
+  Op op{group, [self, kind, a, r, skip, when](Exec& e, int mode) {
     if (when == 2 && !self->last_acoustic) return;
     NhColArgs b = a; b.last_call = (when == 3 ? self->remap_last : self->last_acoustic) ? 1 : 0;
     run_nh_col(e, mode, b, kind, r, skip, tags[kind][mode]);
-  }});
+  }};
+  // forward inputs / outputs of each column operator (nh.h), for plan_adjoint
+  const int nin = kind == NHC_RIEM_C ? 4 : kind == NHC_RIEM3 ? 4 : kind == NHC_EDGE ? 2 : kind == NHC_RING ? 1 : 0;
+  const int nout = kind == NHC_RIEM_C ? 2 : kind == NHC_RIEM3 ? 9 : kind == NHC_EDGE ? 2 : kind == NHC_RING ? 1 : 0;
+  for (int n = 0; n < nin; ++n) op.ad_in.push_back(a.f[n].p);
+  for (int n = 0; n < nout; ++n) op.ad_out.push_back(a.f[nin + n].p);
+  P.push_back(op);
 }
 inline bool Dycore::nh_overflow() {
   if (!nh) return false;
@@ -570,7 +649,7 @@ inline void Dycore::build_acoustic() {
       s.orect[0] = s.orect[1] = R(is - 1, ie + 2, js - 1, je + 1); s.orect[2] = s.orect[3] = R(is - 1, ie + 1, js - 1, je + 2); add(P, "c_sw", s);
     } else {   // 4-point interpolation away from the edges; one-sided / edge formulas and corner views on 3-wide strips
       const int npx = g.nx + 1, npy = g.ny + 1;
-      s.orect[0] = s.orect[1] = R(3, npx - 2, js - 1, je + 1); s.orect[2] = s.orect[3] = R(is - 1, ie + 1, 3, npy - 2); add(P, "c_sw", s);
+      s.orect[0] = s.orect[1] = R(3, npx - 2, js - 1, je + 1); s.orect[2] = s.orect[3] = R(is - 1, ie + 1, 3, npy - 2);
       CswInterpC_<true> e; for (int n = 0; n < 4; ++n) { e.in[n] = s.in[n]; e.out[n] = s.out[n]; }
       e.in[4] = ua; e.in[5] = va; e.dt2 = dt2; e.k1 = npz;
       std::vector<CswInterpC_<true>> ev;
@@ -579,6 +658,7 @@ inline void Dycore::build_acoustic() {
         e.orect[0] = e.orect[1] = m < 2 ? r : empty_in(r); e.orect[2] = e.orect[3] = m < 2 ? empty_in(r) : r; ev.push_back(e);
       }
       add_multi(P, "c_sw", ev);
+      add(P, "c_sw", s);       // bulk last: first in the backward sweep (plan_adjoint)
     } }
   Fld divgd = W("divgd", npz);
   if (opt.nord > 0) {
@@ -619,7 +699,9 @@ inline void Dycore::build_acoustic() {
   } else {
   { GeopkArgs a; a.g = g; a.R = R(is - 1, ie + 1, js - 1, je + 1); a.delp = delpc; a.pt = ptc; a.pe = pe_c; a.peln = peln_c; a.pk = pkc;
     a.gz = gz; a.pkz = Fld{}; a.hs = hs_dev; a.ptop = opt.ptop; a.akap = opt.akap; a.cp_air = opt.cp_air; a.cg = 1;
-    P.push_back(Op{"geopk_c", [a](Exec& e, int mode) { run_geopk(e, mode, a); }}); }
+    Op op{"geopk_c", [a](Exec& e, int mode) { run_geopk(e, mode, a); }};
+    op.ad_in = {a.delp.p, a.pt.p}; op.ad_out = {a.pe.p, a.peln.p, a.pk.p, a.gz.p};
+    P.push_back(op); }
   { PGradC s; s.in[0] = pkc; s.in[1] = gz; s.in[2] = uc1; s.in[3] = vc1; s.out[0] = uc; s.out[1] = vc;
     s.orect[0] = R(is, ie + 1, js, je); s.orect[1] = R(is, ie, js, je + 1); s.dt2 = dt2; s.k1 = npz; add(P, "p_grad_c", s); }
   }
@@ -727,7 +809,9 @@ inline void Dycore::build_acoustic() {
   Fld pkd = pk, gzd = W("gzd", npz + 1);
   { GeopkArgs a; a.g = g; a.R = R(is - 2, ie + 2, js - 2, je + 2); a.delp = delp_o; a.pt = pt_o; a.pe = pe; a.peln = peln; a.pk = pkd;
     a.gz = gzd; a.pkz = pkz; a.hs = hs_dev; a.ptop = opt.ptop; a.akap = opt.akap; a.cp_air = opt.cp_air; a.cg = 0;
-    P.push_back(Op{"geopk_d", [a](Exec& e, int mode) { run_geopk(e, mode, a); }}); }
+    Op op{"geopk_d", [a](Exec& e, int mode) { run_geopk(e, mode, a); }};
+    op.ad_in = {a.delp.p, a.pt.p}; op.ad_out = {a.pe.p, a.peln.p, a.pk.p, a.gz.p, a.pkz.p};
+    P.push_back(op); }
   Fld pkb = W("pk_b", npz + 1), gzb = W("gz_b", npz + 1);
   build_a2b(P, "one_grad_p", "a2bp", pkd, pkb, npz + 1);
   build_a2b(P, "one_grad_p", "a2bg", gzd, gzb, npz + 1);
@@ -796,7 +880,7 @@ inline void Dycore::dyn_core(int mode) {
         ex.tshift = 0;
         run_group(acoustic, nullptr, MODE_NL, true);
       }
-      zero_work_adjoint();
+      for (auto& zr : acoustic_zero) dev_zero(ex, zr.first, zr.second * 8);      // the few work adjoints no stage launch stores first (plan_adjoint)
       for (int n = 0; n < ns; ++n) { dev_copy(ex, f(onames[n]).p, f(names[n]).p, bytes(n)); dev_zero(ex, f(names[n]).p, bytes(n)); }
       run_group(acoustic, nullptr, MODE_AD);
       // pe, peln, pk, pkz of earlier steps are overwritten by later ones: their adjoint is zero there

@@ -111,6 +111,7 @@ struct Dynamics : Dycore {
   size_t ck_k_stride = 0;
   int nsplt_max = 1;
   bool tracer_subcycle_error = false;
+  std::vector<std::pair<double*, size_t>> tracer_zero;     // plan_adjoint(tracer_q, twork)
   std::vector<double*> snap;   // device snapshot of the prognostic state (fv3lm_state_save)
 
   bool init2(const double* ak, const double* bk);
@@ -245,6 +246,7 @@ inline void Dynamics::build_tracer() {
   { TrUpdate s; s.in[0] = qc; s.in[1] = dp1; s.in[2] = dp2; s.in[3] = fx; s.in[4] = fy; s.out[0] = qc_o; s.orect[0] = R(is, ie, js, je); s.k1 = npz;
     add(tracer_q, "tracer", s); }
   twork = work; work = save;
+  tracer_zero = plan_adjoint(tracer_q, twork);
 }
 
 inline void Dynamics::set_tracer_levels(const std::vector<int>& ksplt) {
@@ -329,7 +331,7 @@ inline void Dynamics::tracer_ad() {
     for (int n = nq - 1; n >= 0; --n) {
       dev_copy(ex, qc.t, nsplt > 1 ? subck(km, it, n) : q[n].t, b3);
       run_group(tracer_q, nullptr, MODE_NL);
-      dev_zero(ex, twork.p, twork.used * 8);
+      for (auto& zr : tracer_zero) dev_zero(ex, zr.first, zr.second * 8);       // plan_adjoint: the rest is stored by its first stage launch
       dev_copy(ex, qc_o.p, q[n].p, b3); dev_zero(ex, qc.p, b3);
       run_group(tracer_q, nullptr, MODE_AD);
       dev_copy(ex, q[n].p, qc.p, b3);

@@ -34,6 +34,7 @@ struct Exec {
   hipStream_t stream = nullptr;
 #endif
   bool check_boxes = false;   // host emulation only: verify declared stencil boxes
+  bool no_wmask = false;      // adjoint launches accumulate only (a single kernel group run through fv3lm_run_group: the caller clears and seeds the adjoints)
   // Trajectory slots (dycore.h): while tshift != 0 every trajectory pointer into the work arena [wlo, whi) is redirected
   // to the slot of the acoustic step being run, so that the backward sweep finds that step's intermediates without
   // recomputing them.
@@ -167,10 +168,13 @@ HD void body_ad_joint(const S& s, const Ctx& c, const Rect& R, int i, int j, int
     if (nk == 0 || z >= c.g.ntile * nk) return;
     const int tile = z / nk, kk = 1 + z % nk;
     constexpr Box ub = class_box<S, KC>();
-    if (i < R.i0 + ub.di0 || i > R.i1 + ub.di1 || j < R.j0 + ub.dj0 || j > R.j1 + ub.dj1) return;
+    // outside the reach of every output: nothing to gather, but a write-mode input (s.wmask, below) still stores its zero
+    const bool inreach = !(i < R.i0 + ub.di0 || i > R.i1 + ub.di1 || j < R.j0 + ub.dj0 || j > R.j1 + ub.dj1);
+    if (!inreach && !s.wmask) return;
     double acc[N];
 #pragma unroll
     for (int m = 0; m < N; ++m) acc[m] = 0.0;
+    if (inreach) {
 #pragma unroll
     for (int dk = ub.dk0; dk <= ub.dk1; ++dk) {
       const int k = kk - dk;
@@ -204,12 +208,18 @@ HD void body_ad_joint(const S& s, const Ctx& c, const Rect& R, int i, int j, int
         }
       }
     }
+    }
+    // Store.  Default: accumulate onto what later stages (earlier in this backward sweep) left.  Write mode (bit m of s.wmask,
+    // set by Dycore::plan_adjoint for the first stage of the backward sweep that touches the buffer): store, with zeros outside
+    // the stage's reach, over the whole padded plane -- which is what lets the sweep run without clearing the work adjoints.
 #pragma unroll
     for (int m = 0; m < N; ++m)
       if (kclass_of((const S*)nullptr, m) == KC && S::wants(m) && s.in[m].p) {
         const Box b = S::box(m);
-        if (!(i < R.i0 + b.di0 || i > R.i1 + b.di1 || j < R.j0 + b.dj0 || j > R.j1 + b.dj1))
-          s.in[m].p[(size_t)(tile * nk + kk - 1) * c.g.plane + c.g.idx(i, j)] += acc[m];
+        const bool in_m = !(i < R.i0 + b.di0 || i > R.i1 + b.di1 || j < R.j0 + b.dj0 || j > R.j1 + b.dj1);
+        double* q = &s.in[m].p[(size_t)(tile * nk + kk - 1) * c.g.plane + c.g.idx(i, j)];
+        if ((s.wmask >> m) & 1u) *q = in_m ? acc[m] : 0.0;
+        else if (in_m) *q += acc[m];
       }
   }
 }
@@ -304,6 +314,7 @@ inline Rect ad_input_rect(const S& s, const Ctx& c, const Rect& R) {
     if (R.j0 + b.dj0 < q.j0) q.j0 = R.j0 + b.dj0;
     if (R.j1 + b.dj1 > q.j1) q.j1 = R.j1 + b.dj1;
   }
+  if (s.wmask) return Rect{c.g.isd(), c.g.ied() + 1, c.g.jsd(), c.g.jed() + 1};     // write mode covers the whole padded plane
   if (q.i0 < c.g.isd()) q.i0 = c.g.isd();
   if (q.j0 < c.g.jsd()) q.j0 = c.g.jsd();
   if (q.i1 > c.g.ied() + 1) q.i1 = c.g.ied() + 1;
@@ -524,12 +535,15 @@ __global__ void __launch_bounds__(BX* S::LDS_BY) k_stage_ad_lds(S s, Ctx c, Rect
   const bool lev_ok = (k >= s.k0 && k <= s.k1);
   if (lev_ok) TileLoadAd<S, 0>::run(s, c, tile, kk, bi0, bj0, lds);
   __syncthreads();
-  if (!lev_ok || i > Q.i1 || j > Q.j1) return;
+  if (i > Q.i1 || j > Q.j1) return;
+  if (!lev_ok && !s.wmask) return;
   constexpr Box ub = L::U;
-  if (i < R.i0 + ub.di0 || i > R.i1 + ub.di1 || j < R.j0 + ub.dj0 || j > R.j1 + ub.dj1) return;
+  const bool inreach = lev_ok && !(i < R.i0 + ub.di0 || i > R.i1 + ub.di1 || j < R.j0 + ub.dj0 || j > R.j1 + ub.dj1);
+  if (!inreach && !s.wmask) return;
   double acc[N];
 #pragma unroll
   for (int m = 0; m < N; ++m) acc[m] = 0.0;
+  if (inreach) {
 #pragma unroll
   for (int dj = ub.dj0; dj <= ub.dj1; ++dj) {
     const int oj = j - dj;
@@ -557,12 +571,15 @@ __global__ void __launch_bounds__(BX* S::LDS_BY) k_stage_ad_lds(S s, Ctx c, Rect
         }
     }
   }
+  }
 #pragma unroll
   for (int m = 0; m < N; ++m)
-    if (S::wants(m) && s.in[m].p) {
+    if (S::wants(m) && s.in[m].p) {        // store: see body_ad_joint
       const Box b = S::box(m);
-      if (!(i < R.i0 + b.di0 || i > R.i1 + b.di1 || j < R.j0 + b.dj0 || j > R.j1 + b.dj1))
-        s.in[m].p[(size_t)(tile * nk + kk - 1) * c.g.plane + c.g.idx(i, j)] += acc[m];
+      const bool in_m = lev_ok && !(i < R.i0 + b.di0 || i > R.i1 + b.di1 || j < R.j0 + b.dj0 || j > R.j1 + b.dj1);
+      double* q = &s.in[m].p[(size_t)(tile * nk + kk - 1) * c.g.plane + c.g.idx(i, j)];
+      if ((s.wmask >> m) & 1u) *q = in_m ? acc[m] : 0.0;
+      else if (in_m) *q += acc[m];
     }
 }
 template <class S, bool TL>
@@ -762,6 +779,7 @@ void run_multi(Exec& ex, int mode, const S* s0, int n, const Ctx& c) { for (int 
 template <class S>
 void run(Exec& ex, int mode, const S& s0, const Ctx& c) {
   S s = s0;
+  if (ex.no_wmask) s.wmask = 0;
   if (ex.tshift) {
     for (int m = 0; m < S::NIN; ++m) s.in[m] = ex.sh(s.in[m]);
     for (int n = 0; n < S::NOUT; ++n) s.out[n] = ex.sh(s.out[n]);

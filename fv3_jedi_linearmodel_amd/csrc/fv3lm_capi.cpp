@@ -142,7 +142,10 @@ int fv3lm_halo(fv3lm_handle* h, int kind, const char* name0, const char* name1, 
 }
 int fv3lm_run_group(fv3lm_handle* h, const char* group, int mode) {
   if (mode < 0 || mode > 2) return fail("bad mode");
+  // one group on its own: every adjoint launch accumulates (the stored-first-write plan of Dycore::plan_adjoint belongs to the whole sweep)
+  h->d.ex.no_wmask = group && group[0];
   h->d.run_group(h->d.acoustic, group, mode);
+  h->d.ex.no_wmask = false;
   return status(h);
 }
 int fv3lm_dyn_core(fv3lm_handle* h, int mode) {

@@ -17,6 +17,7 @@ namespace fv3 {
   Fld out[NO];                                                       \
   Rect orect[NO];                                                    \
   int k0 = 1, k1 = 1;                                                \
+  unsigned wmask = 0;   /* adjoint: inputs whose adjoint this instance stores instead of accumulating (exec.h body_ad_joint) */ \
   static const char* name() { return NAME; }                        \
   static const char* ename() { return NAME "e"; }
 // Adjoint refinements a stage may override: uses(M, di, dj, dk) = does any output read input M at that
