@@ -14,6 +14,7 @@
 #include "exchange.h"
 #include "nh.h"
 #include "nh_ad.h"
+#include "tpfused.h"
 #include <functional>
 #include <map>
 #include <memory>
@@ -126,6 +127,7 @@ struct Op {
   std::string group;
   std::function<void(Exec&, int)> fn;   // mode-aware
   bool accum = false;                   // flux-capacitor update: skipped in the adjoint's trajectory recompute
+  unsigned modes = 7u;                  // bit m: the op takes part in mode m (fused forward kernels: nonlinear + tangent; their staged form: adjoint only)
   // adjoint bookkeeping for Dycore::plan_adjoint: the adjoint buffers (.p) the op's adjoint accumulates into (its forward
   // inputs) and the ones it reads (its forward outputs); stage ops can be switched to store-instead-of-accumulate per input
   std::vector<double*> ad_in, ad_out;
@@ -235,6 +237,7 @@ struct Dycore {
     Op op{group, [v, cp](Exec& e, int mode) { run_multi(e, mode, v.data(), (int)v.size(), *cp); }};
     for (const St& s : v) declare(op, s);
     op.ad_in_slot.clear();            // strips only ever accumulate
+    op.name = St::name();
     P.push_back(op);
   }
   // Halo update of one field or of a staggered vector pair.  Single tile: doubly-periodic wrap; cube faces:
@@ -280,6 +283,7 @@ struct Dycore {
     std::set<double*> written(preset.begin(), preset.end()), zero;
     const bool off = std::getenv("FV3LM_NO_AD_WRITE_MODE") != nullptr;     // debugging aid: every work adjoint cleared, every launch accumulates
     for (auto it = P.rbegin(); it != P.rend(); ++it) {
+      if (!((it->modes >> MODE_AD) & 1u)) continue;
       unsigned w = 0;
       for (double* q_ : it->ad_out) if (inA(q_) && !written.count(q_)) zero.insert(q_);
       for (size_t n = 0; n < it->ad_in.size(); ++n) {
@@ -311,6 +315,11 @@ struct Dycore {
     const int is = 1, ie = g.nx, js = 1, je = g.ny, isd = g.isd(), ied = g.ied(), jsd = g.jsd(), jed = g.jed(), npz = nk ? nk : g.npz;
     Fld fy2 = W((pre + "_fy2").c_str(), npz), q_i = W((pre + "_qi").c_str(), npz), fxo = W((pre + "_fxo").c_str(), npz);
     Fld fx2 = W((pre + "_fx2").c_str(), npz), q_j = W((pre + "_qj").c_str(), npz), fyo = W((pre + "_fyo").c_str(), npz);
+    // nonlinear and tangent modes: the whole routine as one LDS-tiled launch (tpfused.h); the staged launches below then serve the
+    // adjoint only (FV3LM_TP_FUSED=0 runs them in every mode -- the two forms agree bit for bit)
+    const char* fenv = std::getenv("FV3LM_TP_FUSED");
+    const bool fused = !(fenv && fenv[0] == '0');
+    const size_t first_op = P.size();
     // the four 1-D PPM sweeps; on a face each is a bulk launch (4-point edge values everywhere) plus two strips three flux
     // points wide next to the face edges (one-sided edge values, corner views of the inner sweeps)
     auto ppm_y = [&](Fld qq, Fld out, Rect r, int cdir) {
@@ -357,6 +366,21 @@ struct Dycore {
     t.out[0] = fx; t.out[1] = fy; t.orect[0] = R(is, ie + 1, js, je); t.orect[1] = R(is, ie, js, je + 1); t.k1 = npz;
     t.dsel = dsel; t.use_mass = use_mass;
     add(P, grp, t);
+    if (fused) {
+      size_t d2_op = P.size();      // the damping Laplacian (TpD2) stays a stage of its own in every mode
+      for (size_t n = first_op; n < P.size(); ++n) if (P[n].name == "TpD2" || P[n].name == "TpD2e") d2_op = n;
+      for (size_t n = first_op; n < P.size(); ++n) if (!(P[n].name == "TpD2" || P[n].name == "TpD2e")) P[n].modes = 1u << MODE_AD;
+      (void)d2_op;
+      TpFusedArgs a; a.q = q; a.crx = crx; a.cry = cry; a.xfx = xfx; a.yfx = yfx; a.rax = rax; a.ray = ray; a.mx = mx; a.my = my;
+      a.mass = use_mass ? mass : Fld{}; a.d2b = d2b; a.fx = fx; a.fy = fy;
+      a.fy2 = fy2; a.q_i = q_i; a.fxo = fxo; a.fx2 = fx2; a.q_j = q_j; a.fyo = fyo;
+      a.hsel = hsel; a.dsel = dsel; a.use_mass = use_mass ? 1 : 0; a.nk = npz;
+      Ctx* cp = &ctx;
+      Op op{grp, [a, cp](Exec& e, int mode) { run_tp_fused(e, mode, a, *cp); }};
+      op.modes = (1u << MODE_NL) | (1u << MODE_TL);
+      op.name = "TpFused";
+      P.push_back(op);
+    }
   }
   // a2b_ord4 (a2b_edge_tlm.F90:48-542): q (nk levels) -> qb on is..ie+1, js..je+1
   void build_a2b(Program& P, const char* grp, const std::string& pre, Fld q, Fld qb, int nk) {
@@ -405,9 +429,9 @@ struct Dycore {
 inline void Dycore::run_group(const Program& P, const char* group, int mode, bool skip_accum) {
   const bool all = (group == nullptr) || (group[0] == 0);
   if (mode != MODE_AD) {
-    for (const Op& op : P) if ((all || op.group == group) && !(skip_accum && op.accum)) op.fn(ex, mode);
+    for (const Op& op : P) if ((all || op.group == group) && !(skip_accum && op.accum) && ((op.modes >> mode) & 1u)) op.fn(ex, mode);
   } else {
-    for (auto it = P.rbegin(); it != P.rend(); ++it) if (all || it->group == group) it->fn(ex, mode);
+    for (auto it = P.rbegin(); it != P.rend(); ++it) if ((all || it->group == group) && ((it->modes >> mode) & 1u)) it->fn(ex, mode);
   }
 }
 

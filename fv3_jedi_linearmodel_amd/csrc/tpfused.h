@@ -1,0 +1,209 @@
+// fv3lm-hip: fv_tp_2d (tp_core_tlm.F90:83-236, _TLM :2123-2324) as ONE LDS-tiled kernel for the nonlinear and tangent-linear modes.
+//
+// The staged form (dycore.h build_tp) runs the routine as seven launches + edge strips -- inner y-sweep, q_i, outer x-sweep, inner
+// x-sweep, q_j, outer y-sweep, flux assembly -- with every intermediate (fy2, q_i, fxo, fx2, q_j, fyo) making a round trip through
+// HBM.  Here one workgroup owns a 64 x 16 block of cells of one level: it loads the block of q plus a 3-cell halo into LDS once
+// (tangent mode: value and tangent planes), runs the four 1-D PPM sweeps and the two intermediate updates against LDS, and writes
+// only the two fluxes.  Cube-face edges are the same four-cell edge values with other weights (edges.h ppm_w), the corner halo of
+// the inner sweeps is read through the copy_corners view of the sweep direction (corner_map) inside the tile -- no strip launches.
+// The arithmetic is the staged stages' own (ppm_flux, the TpQi/TpQj/TpFlux formulas in their order), so both forms agree bit for
+// bit; the adjoint keeps the staged gather launches, and the nonlinear mode stores the six intermediates they read (STORE).
+//
+// Per output point the staged tangent chain moves 64 doubles, this kernel 22 (9 inputs + 2 outputs, value and tangent).
+#pragma once
+#include "stages.h"
+
+namespace fv3 {
+
+struct TpFusedArgs {
+  Fld q, crx, cry, xfx, yfx, rax, ray, mx, my;   // inputs
+  Fld mass, d2b;                                 // damping inputs (t == nullptr when unused)
+  Fld fx, fy;                                    // outputs
+  Fld fy2, q_i, fxo, fx2, q_j, fyo;              // trajectory intermediates (nonlinear mode stores them for the staged adjoint)
+  int hsel, dsel, use_mass, nk;
+};
+constexpr int TPF_W = 64, TPF_H = 16;            // cells per block
+constexpr int TPF_QW = TPF_W + 6, TPF_QH = TPF_H + 6;
+constexpr int TPF_NQ = TPF_QW * TPF_QH, TPF_NFY2 = TPF_QW * (TPF_H + 1), TPF_NQI = TPF_QW * TPF_H, TPF_NFX2 = (TPF_W + 1) * TPF_QH,
+              TPF_NQJ = TPF_W * TPF_QH, TPF_NT = TPF_NQ + TPF_NFY2 + TPF_NQI + TPF_NFX2 + TPF_NQJ;   // doubles per component
+constexpr int TPF_THREADS = 512;
+
+#ifdef FV3LM_HOST_EMUL
+#define TPF_SYNC() ((void)0)
+#else
+#define TPF_SYNC() __syncthreads()
+#endif
+
+template <class T> struct TpfIO;
+template <> struct TpfIO<double> {
+  static constexpr int NC = 1;
+  DEV static double ld(const Fld& f, size_t n) { return f.t[n]; }
+  DEV static void st(const Fld& f, size_t n, double x) { f.t[n] = x; }
+  DEV static double lget(const double* v, int, int e) { return v[e]; }
+  DEV static void lset(double* v, int, int e, double x) { v[e] = x; }
+};
+template <> struct TpfIO<Dual> {
+  static constexpr int NC = 2;
+  DEV static Dual ld(const Fld& f, size_t n) { return Dual(f.t[n], f.p ? f.p[n] : 0.0); }
+  DEV static void st(const Fld& f, size_t n, const Dual& x) { f.t[n] = x.v; f.p[n] = x.d; }
+  DEV static Dual lget(const double* v, int nt, int e) { return Dual(v[e], v[nt + e]); }
+  DEV static void lset(double* v, int nt, int e, const Dual& x) { v[e] = x.v; v[nt + e] = x.d; }
+};
+// an LDS array of T over the rectangle [i0, i0+w) x [j0, ...)
+template <class T>
+struct TpfTile {
+  double* v; int i0, j0, w;
+  DEV T get(int i, int j) const { return TpfIO<T>::lget(v, TPF_NT, (j - j0) * w + (i - i0)); }
+  DEV void set(int i, int j, const T& x) const { TpfIO<T>::lset(v, TPF_NT, (j - j0) * w + (i - i0), x); }
+};
+
+// One block: cells I0..I1 x J0..J1 of level k of one tile.  tid / nth: this thread and the number of threads sharing the block
+// (host emulation: 0 / 1).
+template <class T, bool STORE>
+DEV void tp_fused_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx, int by, double* lds, int tid, int nth) {
+  typedef TpfIO<T> IO;
+  const Geom& g = c.g;
+  const int nx = g.nx, ny = g.ny;
+  const bool face = g.face != 0;
+  const int I0 = 1 + bx * TPF_W, I1 = (I0 + TPF_W - 1 < nx) ? I0 + TPF_W - 1 : nx;
+  const int J0 = 1 + by * TPF_H, J1 = (J0 + TPF_H - 1 < ny) ? J0 + TPF_H - 1 : ny;
+  const bool firstx = bx == 0, lastx = I1 == nx, firsty = by == 0, lasty = J1 == ny;
+  const int W = I1 - I0 + 1, H = J1 - J0 + 1;
+  const size_t base = (size_t)(tile * a.nk + k - 1) * g.plane;
+  auto at = [&](int i, int j) -> size_t { return base + g.idx(i, j); };
+  const TpfTile<T> q{lds, I0 - 3, J0 - 3, W + 6}, fy2{lds + TPF_NQ, I0 - 3, J0, W + 6}, qi{lds + TPF_NQ + TPF_NFY2, I0 - 3, J0, W + 6},
+      fx2{lds + TPF_NQ + TPF_NFY2 + TPF_NQI, I0, J0 - 3, W + 1}, qj{lds + TPF_NQ + TPF_NFY2 + TPF_NQI + TPF_NFX2, I0, J0 - 3, W};
+  const int iord = hord_of(c.lev[k - 1], a.hsel);
+  // ownership of the stored intermediates: every element of their full regions belongs to exactly one block
+  auto own_i = [&](int i) { return (i >= I0 && i <= I1) || (firstx && i < I0) || (lastx && i > I1); };
+  auto own_j = [&](int j) { return (j >= J0 && j <= J1) || (firsty && j < J0) || (lasty && j > J1); };
+
+  // ---- the block of q and its halo
+  { const int w = W + 6, n = w * (H + 6);
+    for (int e = tid; e < n; e += nth) { const int i = I0 - 3 + e % w, j = J0 - 3 + e / w; q.set(i, j, IO::ld(a.q, at(i, j))); } }
+  TPF_SYNC();
+  // ---- inner sweeps: fy2 = yppm(q) on the halo'd columns (copy_corners view 2), fx2 = xppm(q) on the halo'd rows (view 1)
+  { const int w = W + 6, n = w * (H + 1);
+    for (int e = tid; e < n; e += nth) {
+      const int i = I0 - 3 + e % w, j = J0 + e / w;
+      auto line = [&](int jj) -> T { int ii = i, j2 = jj; if (face) corner_map(g, 2, ii, j2); return q.get(ii, j2); };
+      const MetY da{c.m.dya, c, tile, i};
+      const T f = ppm_flux<T>(iord, face, j, ny + 1, line, da, IO::ld(a.cry, at(i, j)));
+      fy2.set(i, j, f);
+      if (STORE && own_i(i) && (j <= J1 || lasty)) a.fy2.t[at(i, j)] = val(f);
+    } }
+  { const int w = W + 1, n = w * (H + 6);
+    for (int e = tid; e < n; e += nth) {
+      const int i = I0 + e % w, j = J0 - 3 + e / w;
+      auto line = [&](int ii) -> T { int i2 = ii, jj = j; if (face) corner_map(g, 1, i2, jj); return q.get(i2, jj); };
+      const MetX da{c.m.dxa, c, tile, j};
+      const T f = ppm_flux<T>(iord, face, i, nx + 1, line, da, IO::ld(a.crx, at(i, j)));
+      fx2.set(i, j, f);
+      if (STORE && own_j(j) && (i <= I1 || lastx)) a.fx2.t[at(i, j)] = val(f);
+    } }
+  TPF_SYNC();
+  // ---- q_i, q_j: the field advanced by the inner fluxes (tp_core_tlm.F90:149-159, :173-181)
+  { const int w = W + 6, n = w * H;
+    for (int e = tid; e < n; e += nth) {
+      const int i = I0 - 3 + e % w, j = J0 + e / w;
+      const T f0 = IO::ld(a.yfx, at(i, j)) * fy2.get(i, j), f1 = IO::ld(a.yfx, at(i, j + 1)) * fy2.get(i, j + 1);
+      const T x = (q.get(i, j) * MET(area, i, j) + f0 - f1) / IO::ld(a.ray, at(i, j));
+      qi.set(i, j, x);
+      if (STORE && own_i(i)) a.q_i.t[at(i, j)] = val(x);
+    } }
+  { const int w = W, n = w * (H + 6);
+    for (int e = tid; e < n; e += nth) {
+      const int i = I0 + e % w, j = J0 - 3 + e / w;
+      const T f0 = IO::ld(a.xfx, at(i, j)) * fx2.get(i, j), f1 = IO::ld(a.xfx, at(i + 1, j)) * fx2.get(i + 1, j);
+      const T x = (q.get(i, j) * MET(area, i, j) + f0 - f1) / IO::ld(a.rax, at(i, j));
+      qj.set(i, j, x);
+      if (STORE && own_j(j)) a.q_j.t[at(i, j)] = val(x);
+    } }
+  TPF_SYNC();
+  // ---- outer sweeps and flux assembly (tp_core_tlm.F90:187-234; deln_flux :1918-2043 as in stages.h TpFlux)
+  int nord; double dc; damp_of(c.lev[k - 1], a.dsel, nord, dc);
+  const bool dmp = (a.dsel != DAMP_NONE) && (dc > 1.e-4);
+  double damp = 0.;
+  if (dmp) { damp = dc * c.m.da_min; if (nord == 1) damp = damp * damp; }
+  { const int w = W + 1, n = w * (H + 1);
+    for (int e = tid; e < n; e += nth) {
+      const int i = I0 + e % w, j = J0 + e / w;
+      if (j <= J1 && (i <= I1 || lastx)) {          // fx(i,j)
+        auto line = [&](int ii) -> T { return qi.get(ii, j); };
+        const MetX da{c.m.dxa, c, tile, j};
+        const T fo = ppm_flux<T>(iord, face, i, nx + 1, line, da, IO::ld(a.crx, at(i, j)));
+        if (STORE) a.fxo.t[at(i, j)] = val(fo);
+        T f = 0.5 * (fo + fx2.get(i, j)) * IO::ld(a.mx, at(i, j));
+        if (dmp) {
+          T f2;
+          if (nord == 0) { f2 = MET(del6_v, i, j) * (q.get(i - 1, j) - q.get(i, j)); if (!a.use_mass) f2 = damp * f2; }
+          else f2 = MET(del6_v, i, j) * (IO::ld(a.d2b, at(i, j)) - IO::ld(a.d2b, at(i - 1, j)));
+          if (a.use_mass) f = f + (0.5 * damp) * (IO::ld(a.mass, at(i - 1, j)) + IO::ld(a.mass, at(i, j))) * f2;
+          else f = f + f2;
+        }
+        IO::st(a.fx, at(i, j), f);
+      }
+      if (i <= I1 && (j <= J1 || lasty)) {          // fy(i,j)
+        auto line = [&](int jj) -> T { return qj.get(i, jj); };
+        const MetY da{c.m.dya, c, tile, i};
+        const T fo = ppm_flux<T>(iord, face, j, ny + 1, line, da, IO::ld(a.cry, at(i, j)));
+        if (STORE) a.fyo.t[at(i, j)] = val(fo);
+        T f = 0.5 * (fo + fy2.get(i, j)) * IO::ld(a.my, at(i, j));
+        if (dmp) {
+          T f2;
+          if (nord == 0) { f2 = MET(del6_u, i, j) * (q.get(i, j - 1) - q.get(i, j)); if (!a.use_mass) f2 = damp * f2; }
+          else f2 = MET(del6_u, i, j) * (IO::ld(a.d2b, at(i, j)) - IO::ld(a.d2b, at(i, j - 1)));
+          if (a.use_mass) f = f + (0.5 * damp) * (IO::ld(a.mass, at(i, j - 1)) + IO::ld(a.mass, at(i, j))) * f2;
+          else f = f + f2;
+        }
+        IO::st(a.fy, at(i, j), f);
+      }
+    } }
+}
+
+inline void tpf_grid(const Geom& g, int& nbx, int& nby) { nbx = (g.nx + TPF_W - 1) / TPF_W; nby = (g.ny + TPF_H - 1) / TPF_H; }
+// algorithmic bytes of one launch: 9 inputs (+ d2b, mass) read and 2 outputs written per cell (x2 in the tangent mode), + the six stored
+// trajectory intermediates of the nonlinear mode
+inline double tpf_bytes(const TpFusedArgs& a, const Geom& g, int mode) {
+  const double cells = double(g.nx) * g.ny * g.ntile * a.nk, nin = 9. + (a.d2b.t ? 1. : 0.) + (a.mass.t ? 1. : 0.);
+  return 8. * cells * (mode == MODE_TL ? 2. * (nin + 2.) : (nin + 2.) + 6.);
+}
+
+#ifndef FV3LM_HOST_EMUL
+template <class T, bool STORE>
+__global__ void __launch_bounds__(TPF_THREADS) k_tp_fused(TpFusedArgs a, Ctx c) {
+  extern __shared__ double tpf_lds[];
+  int bx = blockIdx.x, by = blockIdx.y; xcd_block(gridDim.x, gridDim.y, bx, by);
+  tp_fused_block<T, STORE>(a, c, blockIdx.z / a.nk, 1 + blockIdx.z % a.nk, bx, by, tpf_lds, threadIdx.x, TPF_THREADS);
+}
+#endif
+
+// nonlinear / tangent-linear launch (the adjoint runs the staged launches of build_tp)
+inline void run_tp_fused(Exec& ex, int mode, const TpFusedArgs& a0, const Ctx& c) {
+  TpFusedArgs a = a0;
+  for (Fld* f : {&a.q, &a.crx, &a.cry, &a.xfx, &a.yfx, &a.rax, &a.ray, &a.mx, &a.my, &a.mass, &a.d2b, &a.fx, &a.fy, &a.fy2, &a.q_i, &a.fxo, &a.fx2, &a.q_j, &a.fyo}) *f = ex.sh(*f);
+  int nbx, nby; tpf_grid(c.g, nbx, nby);
+  ex.mark_begin("TpFused", mode == MODE_TL ? ".tl" : ".nl", tpf_bytes(a, c.g, mode));
+#ifdef FV3LM_HOST_EMUL
+  std::vector<double> lds((size_t)TPF_NT * 2);
+  for (int z = 0; z < c.g.ntile * a.nk; ++z)
+    for (int by = 0; by < nby; ++by)
+      for (int bx = 0; bx < nbx; ++bx) {
+        if (mode == MODE_TL) tp_fused_block<Dual, false>(a, c, z / a.nk, 1 + z % a.nk, bx, by, lds.data(), 0, 1);
+        else tp_fused_block<double, true>(a, c, z / a.nk, 1 + z % a.nk, bx, by, lds.data(), 0, 1);
+      }
+#else
+  const dim3 grid(nbx, nby, c.g.ntile * a.nk);
+  if (mode == MODE_TL) {
+    static bool attr = false;      // 2 x 53.5 KB of LDS per block: above the 64 KB default limit of a launch
+    if (!attr) { if (hipFuncSetAttribute((const void*)k_tp_fused<Dual, false>, hipFuncAttributeMaxDynamicSharedMemorySize, TPF_NT * 16) != hipSuccess) set_sticky("hipFuncSetAttribute(k_tp_fused) failed"); attr = true; }
+    hipLaunchKernelGGL((k_tp_fused<Dual, false>), grid, dim3(TPF_THREADS), TPF_NT * 16, ex.stream, a, c);
+  } else {
+    hipLaunchKernelGGL((k_tp_fused<double, true>), grid, dim3(TPF_THREADS), TPF_NT * 8, ex.stream, a, c);
+  }
+#endif
+  ex.mark_end();
+  ex.launches++;
+}
+
+}  // namespace fv3

@@ -228,3 +228,19 @@ def test_tracer_subcycling_gpu():
     cube_check_tracer(cc, TL, 1e-11, scale=80.0)
     cube_check_tracer(cc, AD, 1e-10, scale=80.0)
     assert cc.dy.lib.L.fv3lm_tracer_nsplt(cc.dy.h) >= 2
+
+
+# ---- fv_tp_2d as one LDS-tiled launch (csrc/tpfused.h) against the staged launches, bit for bit (tp_fused_checks.py)
+def test_fused_tp_equals_staged_periodic():
+    from tp_fused_checks import check_fused_equals_staged
+    check_fused_equals_staged(lambda: Case(nx=70, ny=20, npz=3, n_split=2, k_split=1, dt=900.0, backend="hip", oracle=False, nq=2))
+
+
+def test_fused_tp_equals_staged_cube():
+    from tp_fused_checks import check_fused_equals_staged
+    check_fused_equals_staged(lambda: CubeCase(n=66, npz=10, n_split=1, k_split=1, dt=225.0, backend="hip", nq=1))
+
+
+def test_fused_tp_equals_staged_nonhydrostatic():
+    from tp_fused_checks import check_fused_equals_staged
+    check_fused_equals_staged(lambda: Case(nx=66, ny=18, npz=10, n_split=1, k_split=1, dt=300.0, backend="hip", oracle=False, hydrostatic=0))
