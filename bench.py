@@ -13,7 +13,7 @@ the table-driven face exchange (--tiles cube, default).  --tiles periodic runs o
 tile (36,864 columns) per rank instead (the kernel-level workload of round 1's first measurements).
 Extra objects on the JSON line: "roofline" (dominant kernel, HIP events on the library's own stream),
 "contract" (whole step against BASELINE.md §3's algorithmic bytes) and "cpu_baseline" (the oracle
-port timed on one host core on a bounded sample).
+port timed on all host cores, one single-core worker per core, on a bounded sample).
 """
 import argparse
 import json
@@ -28,9 +28,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
 
 
-def algorithmic_bytes(cells, k_split, n_split, nq):
-    """BASELINE.md §3 contract: B_TL = cells*k_split*(n_split*880 + (4nq+10)*8 + ((3+nq)*4+12)*8); B_TL+AD = 2.75 B_TL."""
-    b_tl = cells * k_split * (n_split * 880.0 + (4 * nq + 10) * 8.0 + ((3 + nq) * 4 + 12) * 8.0)
+def algorithmic_bytes(cells, k_split, n_split, nq, nonhydrostatic=False):
+    """BASELINE.md §3 contract: B_TL = cells*k_split*(n_split*B_ac + (4nq+10)*8 + B_map); B_TL+AD = 2.75 B_TL.
+    B_ac = 880 B (hydrostatic) / 1280 B (non-hydrostatic) per cell and acoustic step; B_map = ((3+nq)*4+12)*8 B hydrostatic
+    (320 B at nq = 4), + 64 B non-hydrostatic (w and delz: 384 B at nq = 4)."""
+    b_ac = 1280.0 if nonhydrostatic else 880.0
+    b_map = ((3 + nq) * 4 + 12) * 8.0 + (64.0 if nonhydrostatic else 0.0)
+    b_tl = cells * k_split * (n_split * b_ac + (4 * nq + 10) * 8.0 + b_map)
     return 2.75 * b_tl
 
 
@@ -54,27 +58,46 @@ def pmc_traffic(kernel, args, cube_mode, world):
 
 
 def cpu_baseline(args, opt):
-    """Oracle port (oracle/liboracle.so, one host core) on a bounded sample of the same workload:
-    a 14x14-column tile with the same npz / k_split / n_split / nq (10-20 s of CPU work)."""
-    import numpy as np
-    from common import Case
-    from groups import step_state
-    from oracle import NL, TL, AD
-    nx = 14
-    c = Case(nx=nx, ny=nx, npz=args.npz, n_split=args.n_split, k_split=args.k_split, dt=args.dt, backend="none", nq=args.nq)
-    T, P = step_state(c)
-    ins_n = ["u", "v", "pt", "delp", "pe", "peln", "pk", "pkz"] + ["q%d" % (n + 1) for n in range(c.nq)]
-    i_t = [T[n] for n in ins_n]; i_p = [P[n] for n in ins_n]
+    """Oracle port (oracle/liboracle.so) on ALL host cores: P = os.cpu_count() single-core workers at once (the reference TL/AD have
+    no threading; P independent workers, each with its own slab of columns, are the zero-communication upper bound of its MPI
+    decomposition).  Bounded sample: one 12x12-column tile per worker with the same npz / k_split / n_split / nq,
+    10-30 s of CPU work.  The port's adjoint is a generic operation tape (oracle/scalar.hpp), several times slower than a
+    source-transformed adjoint: the tangent-only rate is reported beside it."""
+    import subprocess
+    P = os.cpu_count() or 1
+    if hasattr(os, "sched_getaffinity"):
+        P = min(P, len(os.sched_getaffinity(0)))
+    nx = 12
+    env = dict(os.environ); env["HIP_VISIBLE_DEVICES"] = ""; env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline_worker.py"), str(nx), str(args.npz), str(args.n_split), str(args.k_split),
+           str(args.nq), str(args.dt), "1" if args.nonhydrostatic else "0"]
     t0 = time.time()
-    c.oracle.fv_dynamics(TL, c.nq, args.dt, args.n_split, args.k_split, i_t, i_p)
-    t_tl = time.time() - t0
-    seeds = [np.ones_like(T["u"]) for _ in range(4 + c.nq)]
-    t0 = time.time()
-    c.oracle.fv_dynamics(AD, c.nq, args.dt, args.n_split, args.k_split, i_t, None, seeds)   # taped forward + reverse
-    t_ad = time.time() - t0
-    return {"value": nx * nx / (t_tl + t_ad), "unit": "column-updates/s", "cores": 1, "kind": "port",
-            "sample": "oracle C++ port, %dx%d-column periodic tile, L%d, k_split=%d n_split=%d nq=%d: TL (dual numbers) %.2f s + "
-                      "AD (taped forward + reverse sweep) %.2f s" % (nx, nx, args.npz, args.k_split, args.n_split, args.nq, t_tl, t_ad)}
+    procs = [subprocess.Popen(cmd + [str(20250114 + w)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True) for w in range(P)]
+    res = []
+    for p in procs:
+        out, err = p.communicate(timeout=900)
+        if p.returncode != 0:
+            raise RuntimeError("cpu baseline worker failed: " + err[-400:])
+        res.append(json.loads(out.strip().splitlines()[-1]))
+    wall = time.time() - t0
+    t_tl = max(r["t_tl"] for r in res); t_ad = max(r["t_ad"] for r in res)
+    cols = sum(r["columns"] for r in res)
+    return {"value": cols / (t_tl + t_ad), "unit": "column-updates/s", "cores": P, "kind": "port",
+            "tangent_only_value": cols / t_tl,
+            "sample": "oracle C++ port, %d single-core workers at once (all host cores), each one %dx%d-column periodic tile, L%d, k_split=%d "
+                      "n_split=%d nq=%d %s: slowest worker TL (dual numbers) %.2f s + AD (taped forward + reverse sweep, %.0fx the tangent) "
+                      "%.2f s; wall %.1f s incl. start-up" % (P, nx, nx, args.npz, args.k_split, args.n_split, args.nq,
+                                                              "non-hydrostatic" if args.nonhydrostatic else "hydrostatic", t_tl,
+                                                              t_ad / max(t_tl, 1e-9), t_ad, wall)}
+
+
+def scheme_string(o, nh):
+    """the scheme flags actually in force (fv3lm_options of the instance that was timed)"""
+    sponge = ("%d/%d/%d/%d below level %d" % (o.hord_mt_ks_pert, o.hord_vt_ks_pert, o.hord_tm_ks_pert, o.hord_dp_ks_pert, o.n_sponge_pert)) if o.hord_ks_pert else "off"
+    s = "hord mt/vt/tm/dp/tr=%d/%d/%d/%d/%d (sponge: %s), kord=%d, nord=%d" % (o.hord_mt, o.hord_vt, o.hord_tm, o.hord_dp, o.hord_tr, sponge, abs(o.kord_tm), o.nord)
+    if nh:
+        s += ", a_imp=%g (%s)" % (o.a_imp, "SIM1" if o.a_imp > 0.999 else "SIM")
+    return s
 
 
 def main():
@@ -237,19 +260,19 @@ def main():
         cnt, ms, by = dom[1]
         achieved = (by / cnt) / (ms / cnt * 1e-3) / 1e9 if ms > 0 and by > 0 else 0.0
         cells = cols_rank * args.npz
-        b_step = algorithmic_bytes(cells, args.k_split, args.n_split, args.nq)
+        b_step = algorithmic_bytes(cells, args.k_split, args.n_split, args.nq, args.nonhydrostatic)
         contract_gbps = b_step / (ms_per_step * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(dom[0], args, cube_mode, world)
         out = {
             "metric": "column-updates/s per TL+AD dyn step", "value": value, "unit": "column-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong" if cube_mode else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C%dL%d %s TL+AD, %s (%d columns per GPU), "
-                                   "k_split=%d n_split=%d dt=%gs nq=%d, hord=2 (1 in the sponge), kord=17, nord=1"
+            "config": {"workload": "C%dL%d %s TL+AD, %s (%d columns per GPU), k_split=%d n_split=%d dt=%gs nq=%d, %s"
                                    % (args.nx, args.npz, "non-hydrostatic" if args.nonhydrostatic else "hydrostatic", ("six cube faces dealt over %d GPU(s) (%s faces per rank), table-driven face exchange%s"
                                                            % (world, "/".join(str(len(cube.faces_of(r, world))) for r in range(world)),
-                                                              ", RCCL point-to-point between ranks" if world > 1 else "")) if cube_mode
-                                      else "1 doubly-periodic tile per GPU", cols_rank, args.k_split, args.n_split, args.dt, args.nq),
+                                                              "" if world == 1 else (", halo messages staged through host memory over gloo (rehearsal on one GPU, NOT RCCL)"
+                                                                                    if args.rehearse_host_transport else ", RCCL point-to-point between ranks"))) if cube_mode
+                                      else "1 doubly-periodic tile per GPU", cols_rank, args.k_split, args.n_split, args.dt, args.nq, scheme_string(c.opt, args.nonhydrostatic)),
                        "columns_per_gpu": cols_rank, "launches_per_step": sum(v[0] for v in prof.values()),
                        "trajectory_slots": "%d of %d acoustic steps keep their intermediates in HBM (no recompute in the backward sweep)"
                                            % (lib.L.fv3lm_traj_slots(c.dy.h), args.n_split * args.k_split)},
@@ -258,7 +281,8 @@ def main():
                          "launches_per_step": cnt, "avg_launch_ms": ms / cnt, "algorithmic_bytes_per_launch": by / cnt,
                          "share_of_step_time": ms / sum(v[1] for v in prof.values())},
             "contract": {"algorithmic_bytes_per_step": b_step, "achieved_GBps": contract_gbps, "frac": contract_gbps / HBM_PEAK_GBPS,
-                         "note": "whole TL+AD step against BASELINE.md §3 (2.75 x B_TL)"},
+                         "note": "whole TL+AD step against BASELINE.md §3 (2.75 x B_TL, %d B per cell and acoustic step); state resident in HBM: the host<->device "
+                                 "copies of a drop-in step_tl/step_ad (DESIGN.md §6) are outside the timed region" % (1280 if args.nonhydrostatic else 880)},
         }
         if args.profile_out:
             with open(args.profile_out, "w") as f:

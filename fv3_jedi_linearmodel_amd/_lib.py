@@ -53,7 +53,8 @@ class Fv3LmLibrary:
 
 
 def load_hip_library():
-    return Fv3LmLibrary(LIB_PATH)
+    # FV3LM_LIB: another build of the same HIP sources (kernel-tuning variants); never a CPU library -- create() needs a HIP device
+    return Fv3LmLibrary(os.environ.get("FV3LM_LIB", LIB_PATH))
 
 
 TRANSPORT_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_dp), C.POINTER(C.c_long), C.POINTER(_dp), C.POINTER(C.c_long))

@@ -311,7 +311,7 @@ struct Dycore {
 
   // fv_tp_2d as a stage sequence (tp_core_tlm.F90:83-236): q -> fx, fy.  mx/my = xfx/yfx or mass fluxes.
   void build_tp(Program& P, const char* grp, const std::string& pre, Fld q, Fld crx, Fld cry, Fld xfx, Fld yfx, Fld rax,
-                Fld ray, Fld mx, Fld my, Fld mass, int hsel, int dsel, bool use_mass, Fld fx, Fld fy, int nk = 0) {
+                Fld ray, Fld mx, Fld my, Fld mass, int hsel, int dsel, bool use_mass, Fld fx, Fld fy, int nk = 0, const Fld* acc4 = nullptr) {
     const int is = 1, ie = g.nx, js = 1, je = g.ny, isd = g.isd(), ied = g.ied(), jsd = g.jsd(), jed = g.jed(), npz = nk ? nk : g.npz;
     Fld fy2 = W((pre + "_fy2").c_str(), npz), q_i = W((pre + "_qi").c_str(), npz), fxo = W((pre + "_fxo").c_str(), npz);
     Fld fx2 = W((pre + "_fx2").c_str(), npz), q_j = W((pre + "_qj").c_str(), npz), fyo = W((pre + "_fyo").c_str(), npz);
@@ -375,6 +375,8 @@ struct Dycore {
       a.mass = use_mass ? mass : Fld{}; a.d2b = d2b; a.fx = fx; a.fy = fy;
       a.fy2 = fy2; a.q_i = q_i; a.fxo = fxo; a.fx2 = fx2; a.q_j = q_j; a.fyo = fyo;
       a.hsel = hsel; a.dsel = dsel; a.use_mass = use_mass ? 1 : 0; a.nk = npz;
+      a.do_acc = 0;
+      if (acc4) { a.acx = acc4[0]; a.acy = acc4[1]; a.amfx = acc4[2]; a.amfy = acc4[3]; }
       Ctx* cp = &ctx;
       Op op{grp, [a, cp](Exec& e, int mode) { run_tp_fused(e, mode, a, *cp); }};
       op.modes = (1u << MODE_NL) | (1u << MODE_TL);
@@ -428,11 +430,13 @@ struct Dycore {
 
 inline void Dycore::run_group(const Program& P, const char* group, int mode, bool skip_accum) {
   const bool all = (group == nullptr) || (group[0] == 0);
+  ex.skip_accum = skip_accum;
   if (mode != MODE_AD) {
     for (const Op& op : P) if ((all || op.group == group) && !(skip_accum && op.accum) && ((op.modes >> mode) & 1u)) op.fn(ex, mode);
   } else {
     for (auto it = P.rbegin(); it != P.rend(); ++it) if ((all || it->group == group) && ((it->modes >> mode) & 1u)) it->fn(ex, mode);
   }
+  ex.skip_accum = false;
 }
 
 inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, double bdt_, int n_split_, int k_split_,
@@ -757,9 +761,14 @@ inline void Dycore::build_acoustic() {
   { DswRa s; s.in[0] = xfx; s.in[1] = yfx; s.out[0] = rax; s.out[1] = ray; s.orect[0] = R(is, ie, jsd, jed); s.orect[1] = R(isd, ied, js, je);
     s.k1 = npz; add(P, "d_sw", s); }
   Fld fx = W("fx", npz), fy = W("fy", npz), gx = W("gx", npz), gy = W("gy", npz);
-  build_tp(P, "d_sw", "tpd", delp, crx, cry, xfx, yfx, rax, ray, xfx, yfx, Fld{}, HORD_DP, DAMP_V, false, fx, fy);
-  add_accum(P, "d_sw", cx, crx, R(is, ie + 1, jsd, jed)); add_accum(P, "d_sw", mfx, fx, R(is, ie + 1, js, je));
-  add_accum(P, "d_sw", cy, cry, R(isd, ied, js, je + 1)); add_accum(P, "d_sw", mfy, fy, R(is, ie, js, je + 1));
+  // the flux capacitors ride along in the fused fv_tp_2d launch of delp (nonlinear + tangent); their staged form serves the adjoint
+  const Fld acc4[4] = {cx, cy, mfx, mfy};
+  const bool tpf_on = !(std::getenv("FV3LM_TP_FUSED") && std::getenv("FV3LM_TP_FUSED")[0] == '0');
+  build_tp(P, "d_sw", "tpd", delp, crx, cry, xfx, yfx, rax, ray, xfx, yfx, Fld{}, HORD_DP, DAMP_V, false, fx, fy, 0, tpf_on ? acc4 : nullptr);
+  { const size_t n0 = P.size();
+    add_accum(P, "d_sw", cx, crx, R(is, ie + 1, jsd, jed)); add_accum(P, "d_sw", mfx, fx, R(is, ie + 1, js, je));
+    add_accum(P, "d_sw", cy, cry, R(isd, ied, js, je + 1)); add_accum(P, "d_sw", mfy, fy, R(is, ie, js, je + 1));
+    if (tpf_on) for (size_t n = n0; n < P.size(); ++n) P[n].modes = 1u << MODE_AD; }
   Fld w_m{}, dw{}, gxw{}, gyw{};
   if (nh) {   // w: damping increment and transport with the mass fluxes (sw_core_tlm.F90:3020-3062)
     Fld d6w = W("del6_w", npz); dw = W("dw", npz); gxw = W("gxw", npz); gyw = W("gyw", npz); w_m = W("w_m", npz);

@@ -34,6 +34,7 @@ struct Exec {
   hipStream_t stream = nullptr;
 #endif
   bool check_boxes = false;   // host emulation only: verify declared stencil boxes
+  bool skip_accum = false;    // the adjoint's trajectory recompute: flux accumulators are left alone (dycore.h run_group)
   bool no_wmask = false;      // adjoint launches accumulate only (a single kernel group run through fv3lm_run_group: the caller clears and seeds the adjoints)
   // Trajectory slots (dycore.h): while tshift != 0 every trajectory pointer into the work arena [wlo, whi) is redirected
   // to the slot of the acoustic step being run, so that the backward sweep finds that step's intermediates without

@@ -21,17 +21,29 @@ struct TpFusedArgs {
   Fld fx, fy;                                    // outputs
   Fld fy2, q_i, fxo, fx2, q_j, fyo;              // trajectory intermediates (nonlinear mode stores them for the staged adjoint)
   int hsel, dsel, use_mass, nk;
+  // flux capacitors of d_sw (sw_core_tlm.F90:3000-3016): cx += crx, cy += cry, mfx += fx, mfy += fy folded into this launch
+  // (t == nullptr: none).  do_acc is cleared for the adjoint's trajectory recompute, which must leave the accumulators alone.
+  Fld acx, acy, amfx, amfy; int do_acc;
 };
-constexpr int TPF_W = 64, TPF_H = 16;            // cells per block
+#ifndef FV3LM_TPF_H
+#define FV3LM_TPF_H 16
+#endif
+#ifndef FV3LM_TPF_THREADS
+#define FV3LM_TPF_THREADS 512
+#endif
+constexpr int TPF_W = 64, TPF_H = FV3LM_TPF_H;   // cells per block
 constexpr int TPF_QW = TPF_W + 6, TPF_QH = TPF_H + 6;
 constexpr int TPF_NQ = TPF_QW * TPF_QH, TPF_NFY2 = TPF_QW * (TPF_H + 1), TPF_NQI = TPF_QW * TPF_H, TPF_NFX2 = (TPF_W + 1) * TPF_QH,
               TPF_NQJ = TPF_W * TPF_QH, TPF_NT = TPF_NQ + TPF_NFY2 + TPF_NQI + TPF_NFX2 + TPF_NQJ;   // doubles per component
-constexpr int TPF_THREADS = 512;
+constexpr int TPF_THREADS = FV3LM_TPF_THREADS;
 
 #ifdef FV3LM_HOST_EMUL
 #define TPF_SYNC() ((void)0)
+#define TPF_LOOP(e, n) for (int e = tid; e < (n); e += nth)
 #else
 #define TPF_SYNC() __syncthreads()
+// constant trip count, unrolled: the global loads of a thread's elements of a phase are issued together
+#define TPF_LOOP(e, n) _Pragma("unroll") for (int e = tid; e < (n); e += TPF_THREADS)
 #endif
 
 template <class T> struct TpfIO;
@@ -68,52 +80,60 @@ DEV void tp_fused_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int
   const int I0 = 1 + bx * TPF_W, I1 = (I0 + TPF_W - 1 < nx) ? I0 + TPF_W - 1 : nx;
   const int J0 = 1 + by * TPF_H, J1 = (J0 + TPF_H - 1 < ny) ? J0 + TPF_H - 1 : ny;
   const bool firstx = bx == 0, lastx = I1 == nx, firsty = by == 0, lasty = J1 == ny;
-  const int W = I1 - I0 + 1, H = J1 - J0 + 1;
   const size_t base = (size_t)(tile * a.nk + k - 1) * g.plane;
   auto at = [&](int i, int j) -> size_t { return base + g.idx(i, j); };
-  const TpfTile<T> q{lds, I0 - 3, J0 - 3, W + 6}, fy2{lds + TPF_NQ, I0 - 3, J0, W + 6}, qi{lds + TPF_NQ + TPF_NFY2, I0 - 3, J0, W + 6},
-      fx2{lds + TPF_NQ + TPF_NFY2 + TPF_NQI, I0, J0 - 3, W + 1}, qj{lds + TPF_NQ + TPF_NFY2 + TPF_NQI + TPF_NFX2, I0, J0 - 3, W};
+  // constant row pitches (the full block's), whatever the block's own width: index arithmetic by compile-time constants
+  const TpfTile<T> q{lds, I0 - 3, J0 - 3, TPF_QW}, fy2{lds + TPF_NQ, I0 - 3, J0, TPF_QW}, qi{lds + TPF_NQ + TPF_NFY2, I0 - 3, J0, TPF_QW},
+      fx2{lds + TPF_NQ + TPF_NFY2 + TPF_NQI, I0, J0 - 3, TPF_W + 1}, qj{lds + TPF_NQ + TPF_NFY2 + TPF_NQI + TPF_NFX2, I0, J0 - 3, TPF_W};
   const int iord = hord_of(c.lev[k - 1], a.hsel);
   // ownership of the stored intermediates: every element of their full regions belongs to exactly one block
   auto own_i = [&](int i) { return (i >= I0 && i <= I1) || (firstx && i < I0) || (lastx && i > I1); };
   auto own_j = [&](int j) { return (j >= J0 && j <= J1) || (firsty && j < J0) || (lasty && j > J1); };
 
   // ---- the block of q and its halo
-  { const int w = W + 6, n = w * (H + 6);
-    for (int e = tid; e < n; e += nth) { const int i = I0 - 3 + e % w, j = J0 - 3 + e / w; q.set(i, j, IO::ld(a.q, at(i, j))); } }
+  { constexpr int w = TPF_QW, n = w * TPF_QH;
+    TPF_LOOP(e, n) { const int i = I0 - 3 + e % w, j = J0 - 3 + e / w; if (i <= I1 + 3 && j <= J1 + 3) q.set(i, j, IO::ld(a.q, at(i, j))); } }
   TPF_SYNC();
   // ---- inner sweeps: fy2 = yppm(q) on the halo'd columns (copy_corners view 2), fx2 = xppm(q) on the halo'd rows (view 1)
-  { const int w = W + 6, n = w * (H + 1);
-    for (int e = tid; e < n; e += nth) {
+  { constexpr int w = TPF_QW, n = w * (TPF_H + 1);
+    TPF_LOOP(e, n) {
       const int i = I0 - 3 + e % w, j = J0 + e / w;
+      if (i > I1 + 3 || j > J1 + 1) continue;
       auto line = [&](int jj) -> T { int ii = i, j2 = jj; if (face) corner_map(g, 2, ii, j2); return q.get(ii, j2); };
       const MetY da{c.m.dya, c, tile, i};
-      const T f = ppm_flux<T>(iord, face, j, ny + 1, line, da, IO::ld(a.cry, at(i, j)));
+      const T cc = IO::ld(a.cry, at(i, j));
+      const T f = ppm_flux<T>(iord, face, j, ny + 1, line, da, cc);
       fy2.set(i, j, f);
       if (STORE && own_i(i) && (j <= J1 || lasty)) a.fy2.t[at(i, j)] = val(f);
+      if (a.do_acc && own_i(i) && (j <= J1 || lasty)) IO::st(a.acy, at(i, j), IO::ld(a.acy, at(i, j)) + cc);
     } }
-  { const int w = W + 1, n = w * (H + 6);
-    for (int e = tid; e < n; e += nth) {
+  { constexpr int w = TPF_W + 1, n = w * TPF_QH;
+    TPF_LOOP(e, n) {
       const int i = I0 + e % w, j = J0 - 3 + e / w;
+      if (i > I1 + 1 || j > J1 + 3) continue;
       auto line = [&](int ii) -> T { int i2 = ii, jj = j; if (face) corner_map(g, 1, i2, jj); return q.get(i2, jj); };
       const MetX da{c.m.dxa, c, tile, j};
-      const T f = ppm_flux<T>(iord, face, i, nx + 1, line, da, IO::ld(a.crx, at(i, j)));
+      const T cc = IO::ld(a.crx, at(i, j));
+      const T f = ppm_flux<T>(iord, face, i, nx + 1, line, da, cc);
       fx2.set(i, j, f);
       if (STORE && own_j(j) && (i <= I1 || lastx)) a.fx2.t[at(i, j)] = val(f);
+      if (a.do_acc && own_j(j) && (i <= I1 || lastx)) IO::st(a.acx, at(i, j), IO::ld(a.acx, at(i, j)) + cc);
     } }
   TPF_SYNC();
   // ---- q_i, q_j: the field advanced by the inner fluxes (tp_core_tlm.F90:149-159, :173-181)
-  { const int w = W + 6, n = w * H;
-    for (int e = tid; e < n; e += nth) {
+  { constexpr int w = TPF_QW, n = w * TPF_H;
+    TPF_LOOP(e, n) {
       const int i = I0 - 3 + e % w, j = J0 + e / w;
+      if (i > I1 + 3 || j > J1) continue;
       const T f0 = IO::ld(a.yfx, at(i, j)) * fy2.get(i, j), f1 = IO::ld(a.yfx, at(i, j + 1)) * fy2.get(i, j + 1);
       const T x = (q.get(i, j) * MET(area, i, j) + f0 - f1) / IO::ld(a.ray, at(i, j));
       qi.set(i, j, x);
       if (STORE && own_i(i)) a.q_i.t[at(i, j)] = val(x);
     } }
-  { const int w = W, n = w * (H + 6);
-    for (int e = tid; e < n; e += nth) {
+  { constexpr int w = TPF_W, n = w * TPF_QH;
+    TPF_LOOP(e, n) {
       const int i = I0 + e % w, j = J0 - 3 + e / w;
+      if (i > I1 || j > J1 + 3) continue;
       const T f0 = IO::ld(a.xfx, at(i, j)) * fx2.get(i, j), f1 = IO::ld(a.xfx, at(i + 1, j)) * fx2.get(i + 1, j);
       const T x = (q.get(i, j) * MET(area, i, j) + f0 - f1) / IO::ld(a.rax, at(i, j));
       qj.set(i, j, x);
@@ -125,9 +145,10 @@ DEV void tp_fused_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int
   const bool dmp = (a.dsel != DAMP_NONE) && (dc > 1.e-4);
   double damp = 0.;
   if (dmp) { damp = dc * c.m.da_min; if (nord == 1) damp = damp * damp; }
-  { const int w = W + 1, n = w * (H + 1);
-    for (int e = tid; e < n; e += nth) {
+  { constexpr int w = TPF_W + 1, n = w * (TPF_H + 1);
+    TPF_LOOP(e, n) {
       const int i = I0 + e % w, j = J0 + e / w;
+      if (i > I1 + 1 || j > J1 + 1) continue;
       if (j <= J1 && (i <= I1 || lastx)) {          // fx(i,j)
         auto line = [&](int ii) -> T { return qi.get(ii, j); };
         const MetX da{c.m.dxa, c, tile, j};
@@ -142,6 +163,7 @@ DEV void tp_fused_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int
           else f = f + f2;
         }
         IO::st(a.fx, at(i, j), f);
+        if (a.do_acc) IO::st(a.amfx, at(i, j), IO::ld(a.amfx, at(i, j)) + f);
       }
       if (i <= I1 && (j <= J1 || lasty)) {          // fy(i,j)
         auto line = [&](int jj) -> T { return qj.get(i, jj); };
@@ -157,6 +179,7 @@ DEV void tp_fused_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int
           else f = f + f2;
         }
         IO::st(a.fy, at(i, j), f);
+        if (a.do_acc) IO::st(a.amfy, at(i, j), IO::ld(a.amfy, at(i, j)) + f);
       }
     } }
 }
@@ -181,7 +204,8 @@ __global__ void __launch_bounds__(TPF_THREADS) k_tp_fused(TpFusedArgs a, Ctx c) 
 // nonlinear / tangent-linear launch (the adjoint runs the staged launches of build_tp)
 inline void run_tp_fused(Exec& ex, int mode, const TpFusedArgs& a0, const Ctx& c) {
   TpFusedArgs a = a0;
-  for (Fld* f : {&a.q, &a.crx, &a.cry, &a.xfx, &a.yfx, &a.rax, &a.ray, &a.mx, &a.my, &a.mass, &a.d2b, &a.fx, &a.fy, &a.fy2, &a.q_i, &a.fxo, &a.fx2, &a.q_j, &a.fyo}) *f = ex.sh(*f);
+  for (Fld* f : {&a.q, &a.crx, &a.cry, &a.xfx, &a.yfx, &a.rax, &a.ray, &a.mx, &a.my, &a.mass, &a.d2b, &a.fx, &a.fy, &a.fy2, &a.q_i, &a.fxo, &a.fx2, &a.q_j, &a.fyo, &a.acx, &a.acy, &a.amfx, &a.amfy}) *f = ex.sh(*f);
+  a.do_acc = (a.acx.t && !ex.skip_accum) ? 1 : 0;
   int nbx, nby; tpf_grid(c.g, nbx, nby);
   ex.mark_begin("TpFused", mode == MODE_TL ? ".tl" : ".nl", tpf_bytes(a, c.g, mode));
 #ifdef FV3LM_HOST_EMUL

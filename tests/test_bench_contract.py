@@ -1,19 +1,40 @@
-"""The bench line committed under profiles/ carries every field of the contract (CPU check of the artefact, no GPU)."""
+"""bench.py's own arithmetic and helpers (CPU): the contract byte count against BASELINE.md §3's worked example, the workload
+string derived from the options in force, and one worker of the cpu_baseline leg end to end on a tiny tile."""
 import json
 import os
+import subprocess
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
 
 
-def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r1_cube_c192l127_bench_final.json")))
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "cpu_baseline"):
-        assert k in d, k
-    assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None and "workload" in d["config"]
-    r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["traffic"] > 0
-    b = d["cpu_baseline"]
-    assert b["kind"] in ("port", "reference") and b["cores"] >= 1 and b["value"] > 0 and b["sample"]
-    # value = columns of the cube / time per step
-    assert abs(d["value"] - 6 * 192 * 192 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
+def test_contract_bytes_match_baseline_md():
+    cells = 6 * 192 * 192 * 127
+    # C192L127 hydrostatic, k_split=2, n_split=6, nq=4 -> 326 GB (TL), 897 GB (TL+AD)
+    b = bench.algorithmic_bytes(cells, 2, 6, 4)
+    assert abs(b / 2.75 - 326e9) < 1e9 and abs(b - 897e9) < 2e9
+    # non-hydrostatic: 1280 B per cell and acoustic step, 384 B remap
+    bn = bench.algorithmic_bytes(cells, 2, 6, 4, nonhydrostatic=True)
+    assert abs(bn / 2.75 / cells / 2 - (6 * 1280 + 208 + 384)) < 1e-6
+
+
+def test_workload_string_follows_the_options():
+    import fv3_jedi_linearmodel_amd as fv3
+    o = fv3.default_options()
+    s = bench.scheme_string(o, False)
+    assert "2/2/2/2/2" in s and "sponge: 1/1/1/1 below level 9" in s and "a_imp" not in s
+    o2 = fv3.default_options(hord_ks_pert=0, hord_ks_traj=0, hydrostatic=0, a_imp=1.0)
+    s2 = bench.scheme_string(o2, True)
+    assert "sponge: off" in s2 and "a_imp=1 (SIM1)" in s2
+
+
+def test_cpu_baseline_worker_runs():
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline_worker.py"), "8", "6", "2", "1", "1", "450", "0", "3"],
+                                  text=True)
+    r = json.loads(out.strip().splitlines()[-1])
+    assert r["columns"] == 64 and r["t_tl"] > 0 and r["t_ad"] > 0
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline_worker.py"), "8", "6", "2", "1", "1", "450", "1", "3"],
+                                  text=True)
+    assert json.loads(out.strip().splitlines()[-1])["columns"] == 64
