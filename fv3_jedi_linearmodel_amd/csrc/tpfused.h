@@ -28,14 +28,19 @@ struct TpFusedArgs {
 #ifndef FV3LM_TPF_H
 #define FV3LM_TPF_H 16
 #endif
-#ifndef FV3LM_TPF_THREADS
-#define FV3LM_TPF_THREADS 512
+// threads per block, per mode (measured on MI355X, C192L127 six faces, ms per launch): nonlinear 512: 1.43, 1024: 1.85;
+// tangent (107 KB of LDS, one block per CU) 512: 3.11, 1024: 2.22; 64 x 8 blocks were slower in both modes
+#ifndef FV3LM_TPF_THREADS_NL
+#define FV3LM_TPF_THREADS_NL 512
+#endif
+#ifndef FV3LM_TPF_THREADS_TL
+#define FV3LM_TPF_THREADS_TL 1024
 #endif
 constexpr int TPF_W = 64, TPF_H = FV3LM_TPF_H;   // cells per block
 constexpr int TPF_QW = TPF_W + 6, TPF_QH = TPF_H + 6;
 constexpr int TPF_NQ = TPF_QW * TPF_QH, TPF_NFY2 = TPF_QW * (TPF_H + 1), TPF_NQI = TPF_QW * TPF_H, TPF_NFX2 = (TPF_W + 1) * TPF_QH,
               TPF_NQJ = TPF_W * TPF_QH, TPF_NT = TPF_NQ + TPF_NFY2 + TPF_NQI + TPF_NFX2 + TPF_NQJ;   // doubles per component
-constexpr int TPF_THREADS = FV3LM_TPF_THREADS;
+constexpr int TPF_THREADS_NL = FV3LM_TPF_THREADS_NL, TPF_THREADS_TL = FV3LM_TPF_THREADS_TL;
 
 #ifdef FV3LM_HOST_EMUL
 #define TPF_SYNC() ((void)0)
@@ -43,7 +48,7 @@ constexpr int TPF_THREADS = FV3LM_TPF_THREADS;
 #else
 #define TPF_SYNC() __syncthreads()
 // constant trip count, unrolled: the global loads of a thread's elements of a phase are issued together
-#define TPF_LOOP(e, n) _Pragma("unroll") for (int e = tid; e < (n); e += TPF_THREADS)
+#define TPF_LOOP(e, n) _Pragma("unroll") for (int e = tid; e < (n); e += NTH)
 #endif
 
 template <class T> struct TpfIO;
@@ -71,7 +76,7 @@ struct TpfTile {
 
 // One block: cells I0..I1 x J0..J1 of level k of one tile.  tid / nth: this thread and the number of threads sharing the block
 // (host emulation: 0 / 1).
-template <class T, bool STORE>
+template <class T, bool STORE, int NTH>
 DEV void tp_fused_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx, int by, double* lds, int tid, int nth) {
   typedef TpfIO<T> IO;
   const Geom& g = c.g;
@@ -193,11 +198,11 @@ inline double tpf_bytes(const TpFusedArgs& a, const Geom& g, int mode) {
 }
 
 #ifndef FV3LM_HOST_EMUL
-template <class T, bool STORE>
-__global__ void __launch_bounds__(TPF_THREADS) k_tp_fused(TpFusedArgs a, Ctx c) {
+template <class T, bool STORE, int NTH>
+__global__ void __launch_bounds__(NTH) k_tp_fused(TpFusedArgs a, Ctx c) {
   extern __shared__ double tpf_lds[];
   int bx = blockIdx.x, by = blockIdx.y; xcd_block(gridDim.x, gridDim.y, bx, by);
-  tp_fused_block<T, STORE>(a, c, blockIdx.z / a.nk, 1 + blockIdx.z % a.nk, bx, by, tpf_lds, threadIdx.x, TPF_THREADS);
+  tp_fused_block<T, STORE, NTH>(a, c, blockIdx.z / a.nk, 1 + blockIdx.z % a.nk, bx, by, tpf_lds, threadIdx.x, NTH);
 }
 #endif
 
@@ -213,17 +218,17 @@ inline void run_tp_fused(Exec& ex, int mode, const TpFusedArgs& a0, const Ctx& c
   for (int z = 0; z < c.g.ntile * a.nk; ++z)
     for (int by = 0; by < nby; ++by)
       for (int bx = 0; bx < nbx; ++bx) {
-        if (mode == MODE_TL) tp_fused_block<Dual, false>(a, c, z / a.nk, 1 + z % a.nk, bx, by, lds.data(), 0, 1);
-        else tp_fused_block<double, true>(a, c, z / a.nk, 1 + z % a.nk, bx, by, lds.data(), 0, 1);
+        if (mode == MODE_TL) tp_fused_block<Dual, false, 1>(a, c, z / a.nk, 1 + z % a.nk, bx, by, lds.data(), 0, 1);
+        else tp_fused_block<double, true, 1>(a, c, z / a.nk, 1 + z % a.nk, bx, by, lds.data(), 0, 1);
       }
 #else
   const dim3 grid(nbx, nby, c.g.ntile * a.nk);
   if (mode == MODE_TL) {
     static bool attr = false;      // 2 x 53.5 KB of LDS per block: above the 64 KB default limit of a launch
-    if (!attr) { if (hipFuncSetAttribute((const void*)k_tp_fused<Dual, false>, hipFuncAttributeMaxDynamicSharedMemorySize, TPF_NT * 16) != hipSuccess) set_sticky("hipFuncSetAttribute(k_tp_fused) failed"); attr = true; }
-    hipLaunchKernelGGL((k_tp_fused<Dual, false>), grid, dim3(TPF_THREADS), TPF_NT * 16, ex.stream, a, c);
+    if (!attr) { if (hipFuncSetAttribute((const void*)k_tp_fused<Dual, false, TPF_THREADS_TL>, hipFuncAttributeMaxDynamicSharedMemorySize, TPF_NT * 16) != hipSuccess) set_sticky("hipFuncSetAttribute(k_tp_fused) failed"); attr = true; }
+    hipLaunchKernelGGL((k_tp_fused<Dual, false, TPF_THREADS_TL>), grid, dim3(TPF_THREADS_TL), TPF_NT * 16, ex.stream, a, c);
   } else {
-    hipLaunchKernelGGL((k_tp_fused<double, true>), grid, dim3(TPF_THREADS), TPF_NT * 8, ex.stream, a, c);
+    hipLaunchKernelGGL((k_tp_fused<double, true, TPF_THREADS_NL>), grid, dim3(TPF_THREADS_NL), TPF_NT * 8, ex.stream, a, c);
   }
 #endif
   ex.mark_end();
