@@ -185,14 +185,7 @@ def main():
                 comm_init_rccl(lib, rank, nact, bcast)
             else:
                 bcast(None)
-            grp = dist.new_group(ranks=list(range(nact)))
-            if rank < nact:
-                from fv3_jedi_linearmodel_amd._lib import set_allreduce_callback
-                def allmax(buf):                          # tracer_2d's max Courant number per level over all faces
-                    t = torch.from_numpy(buf.copy()).cuda()
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=grp)
-                    buf[:] = t.cpu().numpy()
-                set_allreduce_callback(lib, allmax)
+            # tracer_2d's per-level max Courant number over all faces: ncclAllReduce(max) inside the library, on the same communicator
         active = len(cube.faces_of(rank, world)) > 0
         if active:
             nhkw = dict(hydrostatic=0) if args.nonhydrostatic else {}

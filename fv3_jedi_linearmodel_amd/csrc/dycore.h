@@ -261,6 +261,48 @@ struct Dycore {
     op.ad_in = {f0.p, f1.p};          // the adjoint exchange moves halo adjoints onto their source elements: both must hold defined values
     P.push_back(op);
   }
+  // Exchange beside compute.  A halo exchange whose field no launch touches between its producer and its first consumer is split
+  // into a start (right after the last launch that touches the field) and a join (where the exchange used to stand): pack ->
+  // ncclSend/ncclRecv -> unpack (or the local table kernel) run on the exchange stream while the main stream goes on; the adjoint
+  // sweep meets the two in the opposite order and does the same.  Between start and join the field is untouched on the main
+  // stream, so both directions are race-free by construction.  FV3LM_NO_ASYNC_HALO=1 keeps every exchange in line.
+  void halo_window(int mode, bool start, int win, int kind, const Fld& f0, const Fld& f1) {
+#ifndef FV3LM_HOST_EMUL
+    if (ex.xstream) {
+      if (start) {
+        HIPCHK(hipEventRecord(ex.ev_a[win], ex.stream)); HIPCHK(hipStreamWaitEvent(ex.xstream, ex.ev_a[win], 0));
+        hipStream_t main = ex.stream; ex.stream = ex.xstream;
+        halo(mode, kind, f0, f1);
+        ex.stream = main;
+        HIPCHK(hipEventRecord(ex.ev_b[win], ex.xstream));
+      } else HIPCHK(hipStreamWaitEvent(ex.stream, ex.ev_b[win], 0));
+      return;
+    }
+#endif
+    (void)win;
+    if (!start) halo(mode, kind, f0, f1);       // no second stream (host emulation): the exchange stays where it was
+  }
+  // replaces add_halo(P, group, kind, f0, f1) at the point where the exchanged halo is first needed
+  void add_halo_async(Program& P, const char* group, int kind, Fld f0, Fld f1 = Fld{}) {
+    const char* env = std::getenv("FV3LM_NO_ASYNC_HALO");
+    if ((env && env[0] == '1') || n_win >= 4) { add_halo(P, group, kind, f0, f1); return; }
+    size_t at = P.size();        // start goes right after the last op that reads or writes the field
+    while (at > 0) {
+      const Op& o = P[at - 1]; bool touch = false;
+      for (double* q_ : o.ad_in) if (q_ && (q_ == f0.p || q_ == f1.p)) touch = true;
+      for (double* q_ : o.ad_out) if (q_ && (q_ == f0.p || q_ == f1.p)) touch = true;
+      if (touch || o.ad_in.empty()) break;       // ops that declare nothing (none today) are taken to touch everything
+      --at;
+    }
+    const int win = n_win++;
+    Dycore* self = this;
+    Op a{group, [self, kind, f0, f1, win](Exec&, int mode) { self->halo_window(mode, mode != MODE_AD, win, kind, f0, f1); }};
+    Op b{group, [self, kind, f0, f1, win](Exec&, int mode) { self->halo_window(mode, mode == MODE_AD, win, kind, f0, f1); }};
+    a.ad_in = b.ad_in = {f0.p, f1.p}; a.name = "halo_start"; b.name = "halo_join";
+    P.insert(P.begin() + at, a);
+    P.push_back(b);
+  }
+  int n_win = 0;
   bool set_face_data(const double* edge, const double* ecorner);
   bool set_exchange(int kind, const int* rows, int n);
   bool set_exchange_remote(int kind, int npeers, const int* peers, const int* nsend, const int* send_rows, const int* nrecv, const int* recv_rows);
@@ -381,6 +423,9 @@ struct Dycore {
       Op op{grp, [a, cp](Exec& e, int mode) { run_tp_fused(e, mode, a, *cp); }};
       op.modes = (1u << MODE_NL) | (1u << MODE_TL);
       op.name = "TpFused";
+      // what the launch reads / writes (add_halo_async looks for the last op that touches a field; plan_adjoint skips this op: not an adjoint op)
+      for (const Fld* f_ : {&a.q, &a.crx, &a.cry, &a.xfx, &a.yfx, &a.rax, &a.ray, &a.mx, &a.my, &a.mass, &a.d2b}) if (f_->p) op.ad_in.push_back(f_->p);
+      for (const Fld* f_ : {&a.fx, &a.fy, &a.fy2, &a.q_i, &a.fxo, &a.fx2, &a.q_j, &a.fyo, &a.acx, &a.acy, &a.amfx, &a.amfy}) if (f_->p) op.ad_out.push_back(f_->p);
       P.push_back(op);
     }
   }
@@ -471,6 +516,11 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
   }
 #ifndef FV3LM_HOST_EMUL
   HIPCHK(hipStreamCreate(&ex.stream));
+  { const char* env = std::getenv("FV3LM_NO_ASYNC_HALO");
+    if (face && !(env && env[0] == '1')) {
+      HIPCHK(hipStreamCreate(&ex.xstream));
+      for (int w = 0; w < Exec::NWIN; ++w) { HIPCHK(hipEventCreateWithFlags(&ex.ev_a[w], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ex.ev_b[w], hipEventDisableTiming)); }
+    } }
 #endif
   lev_host[npz] = lev_host[npz - 1];          // interface npz+1 of the height transport uses the last layer's schemes
   lev_dev = (LevelParams*)dev_alloc(sizeof(LevelParams) * (npz + 1));
@@ -607,6 +657,7 @@ inline void Dycore::destroy() {
   for (double* q_ : traj_slot_p) dev_free(q_);
 #ifndef FV3LM_HOST_EMUL
   if (ex.stream) (void)hipStreamDestroy(ex.stream);
+  if (ex.xstream) { (void)hipStreamDestroy(ex.xstream); for (int w = 0; w < Exec::NWIN; ++w) { if (ex.ev_a[w]) (void)hipEventDestroy(ex.ev_a[w]); if (ex.ev_b[w]) (void)hipEventDestroy(ex.ev_b[w]); } }
 #endif
 }
 
@@ -708,7 +759,7 @@ inline void Dycore::build_acoustic() {
   Fld uc1 = W("uc1", npz), vc1 = W("vc1", npz);
   { CswUpdateD s; s.in[0] = uc0; s.in[1] = vc0; s.in[2] = u; s.in[3] = v; s.in[4] = vort_c; s.in[5] = ke_c; s.out[0] = uc1; s.out[1] = vc1;
     s.orect[0] = R(is, ie + 1, js, je); s.orect[1] = R(is, ie, js, je + 1); s.dt2 = dt2; s.k1 = npz; add_face(P, "c_sw", s, 1); }
-  if (opt.nord > 0) add_halo(P, "halo_divgd", H_CORNER, divgd);
+  if (opt.nord > 0) add_halo_async(P, "halo_divgd", H_CORNER, divgd);     // first needed by the divergence damping of d_sw: runs beside geopk / p_grad_c / the transports
   // ---- geopk (C grid) + p_grad_c
   Fld pe_c = W("pe_c", npz + 1), peln_c = W("peln_c", npz + 1), pkc = W("pkc", npz + 1), gz = W("gz", npz + 1);
   Fld uc = W("uc", npz), vc = W("vc", npz);
@@ -803,7 +854,9 @@ inline void Dycore::build_acoustic() {
   Fld u_m = W("u_m", npz), v_m = W("v_m", npz);
   { DswUpdateUV s; s.in[0] = u; s.in[1] = v; s.in[2] = ke2; s.in[3] = fxv; s.in[4] = fyv; s.in[5] = wk; s.in[6] = d6; s.out[0] = u_m; s.out[1] = v_m;
     s.orect[0] = R(is, ie, js, je + 1); s.orect[1] = R(is, ie + 1, js, je); s.k1 = npz; add(P, "d_sw", s); }
-  add_halo(P, "halo_dp", H_CELL, delp_o); add_halo(P, "halo_dp", H_CELL, pt_o);
+  // delp, pt of the step: first needed with their halo by geopk / the pressure gradient; the exchange runs beside the KE / vorticity /
+  // damping launches of d_sw
+  add_halo_async(P, "halo_dp", H_CELL, delp_o); add_halo_async(P, "halo_dp", H_CELL, pt_o);
   if (nh) {
     // ---- update_dz_d (nh_utils_tlm.F90:590-722): Courant numbers and area fluxes at the interfaces, transport of the heights
     Fld crx_e = W("crx_e", npz + 1), xfx_e = W("xfx_e", npz + 1), cry_e = W("cry_e", npz + 1), yfx_e = W("yfx_e", npz + 1);

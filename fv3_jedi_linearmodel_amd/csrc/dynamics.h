@@ -84,6 +84,15 @@ struct TrDp1Fn {
     if (mode == MODE_TL) dp1.p[n] = dp2.p[n];
   }
 };
+// max over the resident tiles: out[k] = max_t in[t*npz + k]  (one thread per level)
+struct CmaxTilesFn {
+  int ntile, npz; double* buf;
+  HD void operator()(int k, int, int) const {
+    double m = buf[k];
+    for (int t = 1; t < ntile; ++t) { const double x = buf[(size_t)t * npz + k]; if (m < x) m = x; }
+    buf[k] = m;
+  }
+};
 typedef void (*fv3lm_allreduce_fn)(void* user, double* buf, int n);   // in-place max over ranks (host buffer)
 struct AllReduce { fv3lm_allreduce_fn cb = nullptr; void* user = nullptr; };
 inline AllReduce& allreduce_max_hook() { static AllReduce a; return a; }
@@ -276,9 +285,19 @@ inline void Dynamics::tracer_fwd(int mode) {
   {
     dev_zero(ex, cmax_dev, (size_t)g.ntile * npz * 8);
     for_points(ex, Rect{1, g.nx, 1, 1}, g.ntile * npz, CmaxFn{g, f("cx"), f("cy"), ctx.m.sin_sg[5], cmax_dev}, "tracer_cmax");
-    std::vector<double> cm((size_t)g.ntile * npz), cl(npz, 0.);
-    d2h(ex, cm.data(), cmax_dev, cm.size() * 8);
-    for (int t = 0; t < g.ntile; ++t) for (int k = 0; k < npz; ++k) if (cl[k] < cm[(size_t)t * npz + k]) cl[k] = cm[(size_t)t * npz + k];
+    // mp_reduce_max (fv_tracer2d_tlm.F90:1306): over the resident tiles on the device, over the ranks by ncclAllReduce(max) on the
+    // library stream when an RCCL communicator is up (the one collective of the path: npz doubles per k_split step); the host hook
+    // serves transports without RCCL (gloo rehearsals, host emulation)
+    for_points(ex, Rect{0, npz - 1, 0, 0}, 1, CmaxTilesFn{g.ntile, npz, cmax_dev}, "tracer_cmax_tiles");
+#ifndef FV3LM_HOST_EMUL
+    { Transport& T = transport();
+      if (T.comm && !allreduce_max_hook().cb) {
+        const ncclResult_t r = T.pAllReduce(cmax_dev, cmax_dev, (size_t)npz, ncclDouble, ncclMax, T.comm, ex.stream);
+        if (r != ncclSuccess) set_sticky("ncclAllReduce(max) of the tracer Courant numbers failed (code " + std::to_string((int)r) + ")");
+      } }
+#endif
+    std::vector<double> cl(npz, 0.);
+    d2h(ex, cl.data(), cmax_dev, (size_t)npz * 8);
     if (allreduce_max_hook().cb) allreduce_max_hook().cb(allreduce_max_hook().user, cl.data(), npz);
     double cg = 0.; for (double c : cl) if (!(c < cg)) cg = c;
     const int nsplt = int(1. + cg);

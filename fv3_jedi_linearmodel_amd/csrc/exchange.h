@@ -91,6 +91,7 @@ struct Transport {
   ncclResult_t (*pRecv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*pGroupStart)() = nullptr;
   ncclResult_t (*pGroupEnd)() = nullptr;
+  ncclResult_t (*pAllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   bool load(const char* path, std::string& err) {
     if (lib) return true;
     lib = dlopen(path && path[0] ? path : "librccl.so", RTLD_NOW | RTLD_GLOBAL);
@@ -98,8 +99,8 @@ struct Transport {
     pGetUniqueId = (decltype(pGetUniqueId))dlsym(lib, "ncclGetUniqueId"); pCommInitRank = (decltype(pCommInitRank))dlsym(lib, "ncclCommInitRank");
     pCommDestroy = (decltype(pCommDestroy))dlsym(lib, "ncclCommDestroy"); pSend = (decltype(pSend))dlsym(lib, "ncclSend");
     pRecv = (decltype(pRecv))dlsym(lib, "ncclRecv"); pGroupStart = (decltype(pGroupStart))dlsym(lib, "ncclGroupStart");
-    pGroupEnd = (decltype(pGroupEnd))dlsym(lib, "ncclGroupEnd");
-    if (!pGetUniqueId || !pCommInitRank || !pSend || !pRecv || !pGroupStart || !pGroupEnd) { err = "RCCL symbols missing"; return false; }
+    pGroupEnd = (decltype(pGroupEnd))dlsym(lib, "ncclGroupEnd"); pAllReduce = (decltype(pAllReduce))dlsym(lib, "ncclAllReduce");
+    if (!pGetUniqueId || !pCommInitRank || !pSend || !pRecv || !pGroupStart || !pGroupEnd || !pAllReduce) { err = "RCCL symbols missing"; return false; }
     return true;
   }
 #endif

@@ -32,6 +32,11 @@ struct ProfRec { std::string name; double bytes;
 struct Exec {
 #ifndef FV3LM_HOST_EMUL
   hipStream_t stream = nullptr;
+  // exchange stream: a halo exchange whose field nobody touches for a while runs here beside the launches of the main
+  // stream (dycore.h add_halo_async); ev_a / ev_b: "main reached the start" / "exchange done", one pair per window
+  hipStream_t xstream = nullptr;
+  static constexpr int NWIN = 4;
+  hipEvent_t ev_a[NWIN] = {}, ev_b[NWIN] = {};
 #endif
   bool check_boxes = false;   // host emulation only: verify declared stencil boxes
   bool skip_accum = false;    // the adjoint's trajectory recompute: flux accumulators are left alone (dycore.h run_group)

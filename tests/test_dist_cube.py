@@ -10,7 +10,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,nh", [(2, 0), (4, 0), (2, 1)])
+@pytest.mark.parametrize("world,nh", [(2, 0), (4, 0), (6, 0), (2, 1)])      # 6: one face per rank, the layout of BASELINE config 4
 def test_faces_over_ranks(world, nh):
     from common import build_emul
     build_emul()

@@ -213,7 +213,15 @@ def test_rccl_single_rank_comm():
     from fv3_jedi_linearmodel_amd._lib import comm_init_rccl
     lib = fv3.load_hip_library()
     comm_init_rccl(lib, 0, 1, lambda data: data)
-    assert lib.L.fv3lm_comm_destroy() == 0
+    try:
+        # with a communicator up, tracer_2d's max Courant numbers go through ncclAllReduce(max) on the library stream (one rank: identity)
+        from common import CubeCase
+        from groups import cube_check_tracer
+        cc = CubeCase(n=8, npz=6, n_split=2, k_split=2, backend="hip", oracle=True, nq=2)
+        cube_check_tracer(cc, TL, 1e-11, scale=80.0)
+        assert cc.dy.lib.L.fv3lm_tracer_nsplt(cc.dy.h) >= 2
+    finally:
+        assert lib.L.fv3lm_comm_destroy() == 0
 
 
 def test_tracer_subcycling_gpu():
