@@ -3,10 +3,13 @@ this data motion to FMS (mpp_update_domains / mpp_get_boundary), which is not pa
 are "parity unpinned"  and are checked through invariants instead: the 12 face contacts of
 SURVEY.md A.3, continuity of analytic scalar and wind fields across every face edge (this is what fixes the component
 swap and the sign of rotated contacts), and the exchange / adjoint-exchange dot product on the device path."""
+import os
 import numpy as np
 import pytest
 from fv3_jedi_linearmodel_amd import cube
 from common import CubeCase
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 N = 8
 
@@ -141,3 +144,40 @@ def test_device_exchange_adjoint(ccase, kind, f0, f1):
     Ety = [c.dy.get(n, 1) for n in names]
     lhs = sum(float(np.sum(p * q)) for p, q in zip(Ex, y)); rhs = sum(float(np.sum(p * q)) for p, q in zip(x, Ety))
     assert abs(lhs - rhs) <= 1e-13 * abs(lhs)
+
+
+# ---- breaking the common mode: oracle and product both apply cube.py's tables and metrics; these are re-derived independently
+def test_tables_match_the_derivation_from_the_reference_contact_list():
+    """oracle/cube_topology.py builds the five exchange tables from the contact lines the reference hands to mpp_define_mosaic
+    (TOOLS/fv_mp_nlm_mod.F90:524-572) by index arithmetic alone -- no face frames, no geometry, nothing imported from the package --
+    and must reproduce cube.all_tables row for row (as sets: the row order is an implementation detail)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cube_topology as ct
+    for n in (4, 7, 12):
+        mine, theirs = ct.all_tables(n), cube.all_tables(n)
+        assert set(mine) == set(theirs)
+        for k in theirs:
+            a = {tuple(r) for r in mine[k].tolist()}; b = {tuple(r) for r in theirs[k].tolist()}
+            assert a == b, (n, k, sorted(a ^ b)[:4])
+
+
+def test_metrics_match_lonlat_formulas():
+    """dx, dy, dxa, dya, area and the centre angle recomputed from the corner points in longitude / latitude with textbook
+    spherical trigonometry (oracle/cube_topology.py face_metrics_lonlat) against cube.cubed_sphere_metrics (chords, triple products,
+    tangent projections): 1e-9 relative.  The faces containing the poles go through the same formulas."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cube_topology as ct
+    n, R = 12, 6371.0e3
+    m, da_min, da_min_c, edge, ecorner, geo = cube.cubed_sphere_metrics(n, radius=R)
+    ng = 3
+    for t in range(6):
+        P = geo["corners"][t, ng:ng + n + 1, ng:ng + n + 1]              # corners of the face's own cells
+        w = ct.face_metrics_lonlat(P, R)
+        cell = (t, slice(ng, ng + n), slice(ng, ng + n))
+        for k in ("dxa", "dya", "area", "cos_sg5", "sin_sg5"):
+            a, b = m[k][cell], w[k]
+            assert np.max(np.abs(a - b)) <= 1e-9 * np.max(np.abs(a)) + 1e-12, (t, k)
+        assert np.max(np.abs(m["dx"][t, ng:ng + n + 1, ng:ng + n] - w["dx"])) <= 1e-9 * np.max(w["dx"]), (t, "dx")
+        assert np.max(np.abs(m["dy"][t, ng:ng + n, ng:ng + n + 1] - w["dy"])) <= 1e-9 * np.max(w["dy"]), (t, "dy")
