@@ -58,16 +58,24 @@ def pmc_traffic(kernel, args, cube_mode, world):
 
 
 def cpu_baseline(args, opt):
-    """Oracle port (oracle/liboracle.so) on ALL host cores: P = os.cpu_count() single-core workers at once (the reference TL/AD have
+    """Oracle port (oracle/liboracle.so) on ALL host cores: P = min(host cores, 16) single-core workers at once (the reference TL/AD have
     no threading; P independent workers, each with its own slab of columns, are the zero-communication upper bound of its MPI
-    decomposition).  Bounded sample: one 12x12-column tile per worker with the same npz / k_split / n_split / nq,
+    decomposition).  Bounded sample: one 8x8-column tile per worker with the same npz / k_split / n_split / nq,
     10-30 s of CPU work.  The port's adjoint is a generic operation tape (oracle/scalar.hpp), several times slower than a
     source-transformed adjoint: the tangent-only rate is reported beside it."""
     import subprocess
     P = os.cpu_count() or 1
     if hasattr(os, "sched_getaffinity"):
         P = min(P, len(os.sched_getaffinity(0)))
-    nx = 12
+    # the GPU box gives one GPU a share of 16 host cores; a worker holds the port's operation tape (about 3 GB for an 8x8-column
+    # L127 tile): the pool is sized to both
+    P = min(P, 16)
+    try:
+        avail_gb = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] / 1048576.0
+        P = max(1, min(P, int(avail_gb / 8.0)))
+    except Exception:
+        pass
+    nx = 8
     env = dict(os.environ); env["HIP_VISIBLE_DEVICES"] = ""; env["OMP_NUM_THREADS"] = "1"
     cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline_worker.py"), str(nx), str(args.npz), str(args.n_split), str(args.k_split),
            str(args.nq), str(args.dt), "1" if args.nonhydrostatic else "0"]
@@ -84,7 +92,7 @@ def cpu_baseline(args, opt):
     cols = sum(r["columns"] for r in res)
     return {"value": cols / (t_tl + t_ad), "unit": "column-updates/s", "cores": P, "kind": "port",
             "tangent_only_value": cols / t_tl,
-            "sample": "oracle C++ port, %d single-core workers at once (all host cores), each one %dx%d-column periodic tile, L%d, k_split=%d "
+            "sample": "oracle C++ port, %d single-core workers at once (the host cores of one GPU's share), each one %dx%d-column periodic tile, L%d, k_split=%d "
                       "n_split=%d nq=%d %s: slowest worker TL (dual numbers) %.2f s + AD (taped forward + reverse sweep, %.0fx the tangent) "
                       "%.2f s; wall %.1f s incl. start-up" % (P, nx, nx, args.npz, args.k_split, args.n_split, args.nq,
                                                               "non-hydrostatic" if args.nonhydrostatic else "hydrostatic", t_tl,

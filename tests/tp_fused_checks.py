@@ -44,10 +44,18 @@ def _run(make_case, fused):
     return out, launches
 
 
-def check_fused_equals_staged(make_case):
+def check_fused_equals_staged(make_case, rtol=0.0):
+    """rtol = 0: bit for bit (host emulation: one compiler, no contraction).  On the device the two forms are different kernels and
+    hipcc contracts a*b+c into fused multiply-adds per kernel, so agreement there is to rounding (rtol 1e-13), not bitwise."""
     a, la = _run(make_case, True)
     b, lb = _run(make_case, False)
+    worst = 0.0
     for key in a:
-        assert np.array_equal(a[key], b[key]), key
         assert np.isfinite(a[key]).all() and np.abs(a[key]).max() > 0, key
-    return la, lb
+        if rtol == 0.0:
+            assert np.array_equal(a[key], b[key]), key
+        else:
+            e = float(np.max(np.abs(a[key] - b[key])) / np.max(np.abs(b[key])))
+            assert e <= rtol, (key, e)
+            worst = max(worst, e)
+    return worst
