@@ -420,7 +420,9 @@ struct Dycore {
       a.do_acc = 0;
       if (acc4) { a.acx = acc4[0]; a.acy = acc4[1]; a.amfx = acc4[2]; a.amfy = acc4[3]; }
       Ctx* cp = &ctx;
-      Op op{grp, [a, cp](Exec& e, int mode) { run_tp_fused(e, mode, a, *cp); }};
+      // FV3LM_TP_FUSED=2: the tiled form (tpfused.h, first half); default: the marching form
+      const bool tiled = fenv && fenv[0] == '2';
+      Op op{grp, [a, cp, tiled](Exec& e, int mode) { if (tiled) run_tp_fused(e, mode, a, *cp); else run_tp_march(e, mode, a, *cp); }};
       op.modes = (1u << MODE_NL) | (1u << MODE_TL);
       op.name = "TpFused";
       // what the launch reads / writes (add_halo_async looks for the last op that touches a field; plan_adjoint skips this op: not an adjoint op)

@@ -242,16 +242,16 @@ def test_tracer_subcycling_gpu():
 def test_fused_tp_equals_staged_periodic():
     from common import Case
     from tp_fused_checks import check_fused_equals_staged
-    check_fused_equals_staged(lambda: Case(nx=70, ny=20, npz=3, n_split=2, k_split=1, dt=900.0, backend="hip", oracle=False, nq=2), rtol=1e-13)
+    check_fused_equals_staged(lambda: Case(nx=70, ny=20, npz=3, n_split=2, k_split=1, dt=900.0, backend="hip", oracle=False, nq=2), rtol=1e-12)
 
 
 def test_fused_tp_equals_staged_cube():
     from common import CubeCase
     from tp_fused_checks import check_fused_equals_staged
-    check_fused_equals_staged(lambda: CubeCase(n=66, npz=10, n_split=1, k_split=1, dt=225.0, backend="hip", nq=1), rtol=1e-13)
+    check_fused_equals_staged(lambda: CubeCase(n=66, npz=10, n_split=1, k_split=1, dt=225.0, backend="hip", nq=1), rtol=1e-12)
 
 
 def test_fused_tp_equals_staged_nonhydrostatic():
     from common import Case
     from tp_fused_checks import check_fused_equals_staged
-    check_fused_equals_staged(lambda: Case(nx=66, ny=18, npz=10, n_split=1, k_split=1, dt=300.0, backend="hip", oracle=False, hydrostatic=0), rtol=1e-13)
+    check_fused_equals_staged(lambda: Case(nx=66, ny=18, npz=10, n_split=1, k_split=1, dt=300.0, backend="hip", oracle=False, hydrostatic=0), rtol=1e-12)
