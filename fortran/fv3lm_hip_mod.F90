@@ -17,6 +17,7 @@ module fv3lm_hip_mod
   public :: fv3lm_options, fv3lm_dims, fv3lm_hip_type
   public :: fv3lm_hip_create, fv3lm_hip_destroy, fv3lm_hip_put, fv3lm_hip_get
   public :: fv3lm_hip_step_tl, fv3lm_hip_step_ad
+  public :: fv3lm_hip_traj_to_fv3, fv3lm_hip_pert_to_fv3, fv3lm_hip_fv3_to_pert
 
   integer, parameter :: ng = 3   ! halo width, tools/fv_mp_nlm_mod.F90:67
 
@@ -129,6 +130,24 @@ module fv3lm_hip_mod
       type(c_ptr), value :: h
       integer(c_int) :: rc
     end function
+    function c_traj_to_fv3(h, u, v, t, delp, q, w, delz, phis) bind(C, name="fv3lm_traj_to_fv3") result(rc)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h, u, v, t, delp, w, delz, phis
+      type(c_ptr), intent(in) :: q(*)
+      integer(c_int) :: rc
+    end function
+    function c_pert_to_fv3(h, u, v, t, delp, q, w, delz) bind(C, name="fv3lm_pert_to_fv3") result(rc)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h, u, v, t, delp, w, delz
+      type(c_ptr), intent(in) :: q(*)
+      integer(c_int) :: rc
+    end function
+    function c_fv3_to_pert(h, u, v, t, delp, q, w, delz) bind(C, name="fv3lm_fv3_to_pert") result(rc)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h, u, v, t, delp, w, delz
+      type(c_ptr), intent(in) :: q(*)
+      integer(c_int) :: rc
+    end function
     function c_last_error() bind(C, name="fv3lm_last_error") result(p)
       import :: c_ptr
       type(c_ptr) :: p
@@ -233,6 +252,54 @@ contains
     call check(c_get(self%handle, trim(name)//c_null_char, int(which, c_int), pad), 'get '//name)
     a = pad(ilo:ubound(a, 1), jlo:ubound(a, 2), :)
   end subroutine fv3lm_hip_get
+
+  !> traj_to_fv3 / pert_to_fv3 / fv3_to_pert on the device (fv3jedi_lm_dynamics_mod.F90:717-933): the host's own traj% / pert% arrays,
+  !! (isc:iec, jsc:jec, npz), no halo -- halos, D-grid edge rows, phis halo and pressures are the library's business.  q(:,:,:,n) in
+  !! the reference's tracer order; w, delz only when hydrostatic = .false. (pass any array otherwise: not read).
+  subroutine fv3lm_hip_traj_to_fv3(self, u, v, t, delp, q, phis, w, delz)
+    type(fv3lm_hip_type), intent(in) :: self
+    real(c_double), intent(in), target, contiguous :: u(:, :, :), v(:, :, :), t(:, :, :), delp(:, :, :), q(:, :, :, :), phis(:, :)
+    real(c_double), intent(in), target, contiguous, optional :: w(:, :, :), delz(:, :, :)
+    type(c_ptr) :: qp(max(1, size(q, 4))), wp, zp
+    integer :: n
+    do n = 1, size(q, 4)
+      qp(n) = c_loc(q(1, 1, 1, n))
+    end do
+    wp = c_null_ptr; zp = c_null_ptr
+    if (present(w)) wp = c_loc(w)
+    if (present(delz)) zp = c_loc(delz)
+    call check(c_traj_to_fv3(self%handle, c_loc(u), c_loc(v), c_loc(t), c_loc(delp), qp, wp, zp, c_loc(phis)), 'traj_to_fv3')
+  end subroutine fv3lm_hip_traj_to_fv3
+
+  subroutine fv3lm_hip_pert_to_fv3(self, u, v, t, delp, q, w, delz)
+    type(fv3lm_hip_type), intent(in) :: self
+    real(c_double), intent(in), target, contiguous :: u(:, :, :), v(:, :, :), t(:, :, :), delp(:, :, :), q(:, :, :, :)
+    real(c_double), intent(in), target, contiguous, optional :: w(:, :, :), delz(:, :, :)
+    type(c_ptr) :: qp(max(1, size(q, 4))), wp, zp
+    integer :: n
+    do n = 1, size(q, 4)
+      qp(n) = c_loc(q(1, 1, 1, n))
+    end do
+    wp = c_null_ptr; zp = c_null_ptr
+    if (present(w)) wp = c_loc(w)
+    if (present(delz)) zp = c_loc(delz)
+    call check(c_pert_to_fv3(self%handle, c_loc(u), c_loc(v), c_loc(t), c_loc(delp), qp, wp, zp), 'pert_to_fv3')
+  end subroutine fv3lm_hip_pert_to_fv3
+
+  subroutine fv3lm_hip_fv3_to_pert(self, u, v, t, delp, q, w, delz)
+    type(fv3lm_hip_type), intent(in) :: self
+    real(c_double), intent(inout), target, contiguous :: u(:, :, :), v(:, :, :), t(:, :, :), delp(:, :, :), q(:, :, :, :)
+    real(c_double), intent(inout), target, contiguous, optional :: w(:, :, :), delz(:, :, :)
+    type(c_ptr) :: qp(max(1, size(q, 4))), wp, zp
+    integer :: n
+    do n = 1, size(q, 4)
+      qp(n) = c_loc(q(1, 1, 1, n))
+    end do
+    wp = c_null_ptr; zp = c_null_ptr
+    if (present(w)) wp = c_loc(w)
+    if (present(delz)) zp = c_loc(delz)
+    call check(c_fv3_to_pert(self%handle, c_loc(u), c_loc(v), c_loc(t), c_loc(delp), qp, wp, zp), 'fv3_to_pert')
+  end subroutine fv3lm_hip_fv3_to_pert
 
   !> Replaces compute_fv3_pressures_tlm + fv_dynamics_tlm (fv3jedi_lm_dynamics_mod.F90:404-438).
   subroutine fv3lm_hip_step_tl(self)

@@ -51,6 +51,8 @@ program shim_driver
   call put_all(0, u, v, pt, delp, q); call put_all(1, up, vp, ptp, delpp, qp)
   call fv3lm_hip_step_ad(dyn)
   call get_all(1)
+  ! ---- the host's own boundary: compact traj% / pert% arrays (isc:iec, jsc:jec, npz), no halo (traj_to_fv3, pert_to_fv3, fv3_to_pert)
+  call boundary_run()
   close(12)
   call fv3lm_hip_destroy(dyn)
   write(*, '(a)') 'shim_driver OK'
@@ -65,6 +67,20 @@ contains
       call fv3lm_hip_put(dyn, trim(qn), which, aq(:, :, :, n), isd, jsd)
     end do
   end subroutine put_all
+  subroutine boundary_run()
+    real(c_double), allocatable :: cu(:, :, :), cv(:, :, :), ct(:, :, :), cd(:, :, :), cq(:, :, :, :), cph(:, :)
+    real(c_double), allocatable :: pu(:, :, :), pv(:, :, :), pt_(:, :, :), pd(:, :, :), pq(:, :, :, :)
+    allocate(cu(nx, ny, npz), cv(nx, ny, npz), ct(nx, ny, npz), cd(nx, ny, npz), cq(nx, ny, npz, nq), cph(nx, ny))
+    allocate(pu(nx, ny, npz), pv(nx, ny, npz), pt_(nx, ny, npz), pd(nx, ny, npz), pq(nx, ny, npz, nq))
+    cu = u(1:nx, 1:ny, :); cv = v(1:nx, 1:ny, :); ct = pt(1:nx, 1:ny, :); cd = delp(1:nx, 1:ny, :); cq = q(1:nx, 1:ny, :, :)
+    cph = phis(1:nx, 1:ny)
+    pu = up(1:nx, 1:ny, :); pv = vp(1:nx, 1:ny, :); pt_ = ptp(1:nx, 1:ny, :); pd = delpp(1:nx, 1:ny, :); pq = qp(1:nx, 1:ny, :, :)
+    call fv3lm_hip_traj_to_fv3(dyn, cu, cv, ct, cd, cq, cph)
+    call fv3lm_hip_pert_to_fv3(dyn, pu, pv, pt_, pd, pq)
+    call fv3lm_hip_step_tl(dyn)
+    call fv3lm_hip_fv3_to_pert(dyn, pu, pv, pt_, pd, pq)
+    write(12) pu, pv, pt_, pd, pq
+  end subroutine boundary_run
   subroutine get_all(which)
     integer, intent(in) :: which
     real(c_double), allocatable :: gu(:, :, :), gv(:, :, :), ga(:, :, :)

@@ -209,6 +209,42 @@ class Dycore:
         role: nonlinear sweep storing the stage checkpoints)."""
         self._chk(self.lib.L.fv3lm_step_ad(self.h))
 
+    # ---- the host's boundary copies on the device (compact arrays [ntile, nk, ny, nx], no halo) ----
+    def _cptrs(self, d, names, out=False):
+        keep = []
+        def one(n):
+            if n not in d or d[n] is None:
+                return None
+            a = d[n] if out else np.ascontiguousarray(d[n], dtype=np.float64)
+            assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"], n
+            keep.append(a)
+            return a.ctypes.data_as(_dp)
+        nq = self.dims.nq
+        qarr = (_dp * max(1, nq))(*[one("q%d" % (m + 1)) for m in range(nq)])
+        return [one(n) for n in names], qarr, keep
+
+    def traj_to_fv3(self, d):
+        """d: dict of compact arrays u v pt delp q1.. (w delz) and optionally phis [ntile, ny, nx] (traj_to_fv3, :717-807)"""
+        (u, v, t, dp, w, dz, ph), q, keep = self._cptrs(d, ["u", "v", "pt", "delp", "w", "delz", "phis"])
+        f = self.lib.L.fv3lm_traj_to_fv3
+        f.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, C.POINTER(_dp), _dp, _dp, _dp]
+        self._chk(f(self.h, u, v, t, dp, q, w, dz, ph))
+
+    def pert_to_fv3(self, d):
+        (u, v, t, dp, w, dz), q, keep = self._cptrs(d, ["u", "v", "pt", "delp", "w", "delz"])
+        f = self.lib.L.fv3lm_pert_to_fv3
+        f.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, C.POINTER(_dp), _dp, _dp]
+        self._chk(f(self.h, u, v, t, dp, q, w, dz))
+
+    def fv3_to_pert(self, names):
+        shp = (self.dims.ntile, self.dims.npz, self.dims.ny, self.dims.nx)
+        d = {n: np.empty(shp) for n in names}
+        (u, v, t, dp, w, dz), q, keep = self._cptrs(d, ["u", "v", "pt", "delp", "w", "delz"], out=True)
+        f = self.lib.L.fv3lm_fv3_to_pert
+        f.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, C.POINTER(_dp), _dp, _dp]
+        self._chk(f(self.h, u, v, t, dp, q, w, dz))
+        return d
+
     def state_save(self):
         self.lib.L.fv3lm_state_save.argtypes = [C.c_void_p]
         self._chk(self.lib.L.fv3lm_state_save(self.h))

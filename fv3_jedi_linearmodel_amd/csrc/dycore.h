@@ -132,7 +132,8 @@ struct Op {
   // inputs) and the ones it reads (its forward outputs); stage ops can be switched to store-instead-of-accumulate per input
   std::vector<double*> ad_in, ad_out;
   std::vector<int> ad_in_slot;                 // stage input index of each ad_in entry
-  std::function<void(unsigned)> set_wmask;     // stage ops only
+  std::function<void(unsigned, Rect)> set_wmask;     // stage ops only: write-mode inputs and the rectangle the stores must cover
+  std::vector<Rect> ad_out_rect;               // where the op writes each ad_out in the forward direction (empty: unknown -> whole plane)
   std::string name;                            // stage name (diagnostics)
   Op() = default;
   Op(std::string g_, std::function<void(Exec&, int)> f_, bool acc_ = false) : group(std::move(g_)), fn(std::move(f_)), accum(acc_) {}
@@ -216,7 +217,7 @@ struct Dycore {
   template <class St>
   static void declare(Op& op, const St& s) {
     for (int m = 0; m < St::NIN; ++m) if (St::wants(m) && s.in[m].p) { op.ad_in.push_back(s.in[m].p); op.ad_in_slot.push_back(m); }
-    for (int n = 0; n < St::NOUT; ++n) op.ad_out.push_back(s.out[n].p);
+    for (int n = 0; n < St::NOUT; ++n) { op.ad_out.push_back(s.out[n].p); op.ad_out_rect.push_back(s.orect[n]); }
   }
   template <class St>
   void add(Program& P, const char* group, const St& s) {
@@ -224,7 +225,7 @@ struct Dycore {
     auto sp = std::make_shared<St>(s);
     Op op{group, [sp, cp](Exec& e, int mode) { run(e, mode, *sp, *cp); }};
     declare(op, s);
-    op.set_wmask = [sp](unsigned w) { sp->wmask = w; };
+    op.set_wmask = [sp](unsigned w, Rect r) { sp->wmask = w; sp->wrect = r; };
     op.name = St::name();
     P.push_back(op);
   }
@@ -259,6 +260,7 @@ struct Dycore {
       self->halo(mode, kind, f0, f1);
     }};
     op.ad_in = {f0.p, f1.p};          // the adjoint exchange moves halo adjoints onto their source elements: both must hold defined values
+    op.name = "halo";
     P.push_back(op);
   }
   // Exchange beside compute.  A halo exchange whose field no launch touches between its producer and its first consumer is split
@@ -309,7 +311,7 @@ struct Dycore {
   void add_accum(Program& P, const char* group, Fld acc, Fld x, Rect r) {
     Geom gg = g;
     Op op{group, [acc, x, r, gg](Exec& e, int mode) { run_accum(e, mode, gg, acc, x, r); }, true};
-    op.ad_in = {x.p}; op.ad_out = {acc.p};
+    op.ad_in = {x.p}; op.ad_out = {acc.p}; op.ad_out_rect = {r};
     P.push_back(op);
   }
   // Backward sweep without clearing the work adjoints.  Walking the program in reverse (= the order of the backward sweep), the
@@ -323,10 +325,29 @@ struct Dycore {
     for (auto& kv : F) if (kv.second.p >= A.p && kv.second.p < A.p + A.cap) size[kv.second.p] = (size_t)g.ntile * kv.second.nk * g.plane;
     auto inA = [&](double* q_) { return q_ && q_ >= A.p && q_ < A.p + A.cap; };
     std::set<double*> written(preset.begin(), preset.end()), zero;
+    // A stored adjoint must be defined wherever somebody reads it later in the sweep: where its producer wrote the field (the
+    // producer's adjoint reads the whole of that), and on the whole padded plane if an exchange moves its halo adjoints around.
+    const Rect whole{g.isd(), g.ied() + 1, g.jsd(), g.jed() + 1};
+    std::map<double*, Rect> prod; std::set<double*> everywhere;
+    for (const Op& o : P) {
+      if (!((o.modes >> MODE_AD) & 1u)) continue;
+      if (o.name == "halo" || o.name == "halo_start" || o.name == "halo_join") for (double* q_ : o.ad_in) if (q_) everywhere.insert(q_);
+      for (size_t n = 0; n < o.ad_out.size(); ++n) {
+        double* q_ = o.ad_out[n];
+        if (!q_) continue;
+        if (n >= o.ad_out_rect.size()) { everywhere.insert(q_); continue; }
+        const Rect& r = o.ad_out_rect[n];
+        if (r.i0 > r.i1 || r.j0 > r.j1) continue;
+        auto f_ = prod.find(q_);
+        if (f_ == prod.end()) prod[q_] = r;
+        else { Rect& u = f_->second; u.i0 = std::min(u.i0, r.i0); u.i1 = std::max(u.i1, r.i1); u.j0 = std::min(u.j0, r.j0); u.j1 = std::max(u.j1, r.j1); }
+      }
+    }
     const bool off = std::getenv("FV3LM_NO_AD_WRITE_MODE") != nullptr;     // debugging aid: every work adjoint cleared, every launch accumulates
     for (auto it = P.rbegin(); it != P.rend(); ++it) {
       if (!((it->modes >> MODE_AD) & 1u)) continue;
-      unsigned w = 0;
+      unsigned w = 0; Rect wr{1, 0, 1, 0};
+      auto grow = [&](const Rect& r) { if (wr.i0 > wr.i1) wr = r; else { wr.i0 = std::min(wr.i0, r.i0); wr.i1 = std::max(wr.i1, r.i1); wr.j0 = std::min(wr.j0, r.j0); wr.j1 = std::max(wr.j1, r.j1); } };
       for (double* q_ : it->ad_out) if (inA(q_) && !written.count(q_)) zero.insert(q_);
       for (size_t n = 0; n < it->ad_in.size(); ++n) {
         double* q_ = it->ad_in[n];
@@ -334,11 +355,14 @@ struct Dycore {
         const char* skip = std::getenv("FV3LM_AD_WRITE_SKIP");        // debugging aid: stage names (comma separated) kept in accumulate mode
         const bool skipped = skip && ("," + std::string(skip) + ",").find("," + it->name + ",") != std::string::npos;
         if (std::getenv("FV3LM_AD_WRITE_LIST") && it->set_wmask && !skipped && !zero.count(q_)) std::fprintf(stderr, "write-mode %s input %d\n", it->name.c_str(), it->ad_in_slot[n]);
-        if (!off && !skipped && it->set_wmask && n < it->ad_in_slot.size() && !zero.count(q_)) w |= 1u << it->ad_in_slot[n];
+        if (!off && !skipped && it->set_wmask && n < it->ad_in_slot.size() && !zero.count(q_)) {
+          w |= 1u << it->ad_in_slot[n];
+          grow((everywhere.count(q_) || !prod.count(q_)) ? whole : prod[q_]);
+        }
         else zero.insert(q_);
         written.insert(q_);
       }
-      if (it->set_wmask) it->set_wmask(w);
+      if (it->set_wmask) it->set_wmask(w, wr);
     }
     std::vector<std::pair<double*, size_t>> out;
     for (double* q_ : zero) {      // std::set iterates in address order: merge neighbours
@@ -420,8 +444,8 @@ struct Dycore {
       a.do_acc = 0;
       if (acc4) { a.acx = acc4[0]; a.acy = acc4[1]; a.amfx = acc4[2]; a.amfy = acc4[3]; }
       Ctx* cp = &ctx;
-      // FV3LM_TP_FUSED=2: the tiled form (tpfused.h, first half); default: the marching form
-      const bool tiled = fenv && fenv[0] == '2';
+      // default: the tiled form (tpfused.h, first half); FV3LM_TP_FUSED=3: the marching form (second half; measured slower, kept for reference)
+      const bool tiled = !(fenv && fenv[0] == '3');
       Op op{grp, [a, cp, tiled](Exec& e, int mode) { if (tiled) run_tp_fused(e, mode, a, *cp); else run_tp_march(e, mode, a, *cp); }};
       op.modes = (1u << MODE_NL) | (1u << MODE_TL);
       op.name = "TpFused";
@@ -687,7 +711,7 @@ inline void Dycore::add_col(Program& P, const char* group, int kind, const NhCol
   const int nin = kind == NHC_RIEM_C ? 4 : kind == NHC_RIEM3 ? 4 : kind == NHC_EDGE ? 2 : kind == NHC_RING ? 1 : 0;
   const int nout = kind == NHC_RIEM_C ? 2 : kind == NHC_RIEM3 ? 9 : kind == NHC_EDGE ? 2 : kind == NHC_RING ? 1 : 0;
   for (int n = 0; n < nin; ++n) op.ad_in.push_back(a.f[n].p);
-  for (int n = 0; n < nout; ++n) op.ad_out.push_back(a.f[nin + n].p);
+  for (int n = 0; n < nout; ++n) { op.ad_out.push_back(a.f[nin + n].p); op.ad_out_rect.push_back(r); }
   P.push_back(op);
 }
 inline bool Dycore::nh_overflow() {
@@ -781,7 +805,7 @@ inline void Dycore::build_acoustic() {
   { GeopkArgs a; a.g = g; a.R = R(is - 1, ie + 1, js - 1, je + 1); a.delp = delpc; a.pt = ptc; a.pe = pe_c; a.peln = peln_c; a.pk = pkc;
     a.gz = gz; a.pkz = Fld{}; a.hs = hs_dev; a.ptop = opt.ptop; a.akap = opt.akap; a.cp_air = opt.cp_air; a.cg = 1;
     Op op{"geopk_c", [a](Exec& e, int mode) { run_geopk(e, mode, a); }};
-    op.ad_in = {a.delp.p, a.pt.p}; op.ad_out = {a.pe.p, a.peln.p, a.pk.p, a.gz.p};
+    op.ad_in = {a.delp.p, a.pt.p}; op.ad_out = {a.pe.p, a.peln.p, a.pk.p, a.gz.p}; op.ad_out_rect.assign(4, a.R);
     P.push_back(op); }
   { PGradC s; s.in[0] = pkc; s.in[1] = gz; s.in[2] = uc1; s.in[3] = vc1; s.out[0] = uc; s.out[1] = vc;
     s.orect[0] = R(is, ie + 1, js, je); s.orect[1] = R(is, ie, js, je + 1); s.dt2 = dt2; s.k1 = npz; add(P, "p_grad_c", s); }
@@ -898,7 +922,7 @@ inline void Dycore::build_acoustic() {
   { GeopkArgs a; a.g = g; a.R = R(is - 2, ie + 2, js - 2, je + 2); a.delp = delp_o; a.pt = pt_o; a.pe = pe; a.peln = peln; a.pk = pkd;
     a.gz = gzd; a.pkz = pkz; a.hs = hs_dev; a.ptop = opt.ptop; a.akap = opt.akap; a.cp_air = opt.cp_air; a.cg = 0;
     Op op{"geopk_d", [a](Exec& e, int mode) { run_geopk(e, mode, a); }};
-    op.ad_in = {a.delp.p, a.pt.p}; op.ad_out = {a.pe.p, a.peln.p, a.pk.p, a.gz.p, a.pkz.p};
+    op.ad_in = {a.delp.p, a.pt.p}; op.ad_out = {a.pe.p, a.peln.p, a.pk.p, a.gz.p, a.pkz.p}; op.ad_out_rect.assign(5, a.R);
     P.push_back(op); }
   Fld pkb = W("pk_b", npz + 1), gzb = W("gz_b", npz + 1);
   build_a2b(P, "one_grad_p", "a2bp", pkd, pkb, npz + 1);

@@ -93,6 +93,19 @@ struct CmaxTilesFn {
     buf[k] = m;
   }
 };
+// Boundary copies on the device (traj_to_fv3 / pert_to_fv3 / fv3_to_pert, DYN/fv3jedi_lm_dynamics_mod.F90:717-933): the host's arrays are
+// compact -- (isc:iec, jsc:jec, nk) per tile, no halo.  Unpack: padded plane <- compact, halo zeroed (the reference zeroes the whole
+// FV_Atm array first); pack: compact <- interior of the padded plane.
+struct CompactFn {
+  Geom g; double* pad; double* cmp; int nk, dir;      // dir 0: unpack (pad <- cmp, zeros outside), 1: pack (cmp <- pad)
+  HD void operator()(int i, int j, int z) const {
+    const size_t n = (size_t)z * g.plane + g.idx(i, j);
+    const bool in = i >= 1 && i <= g.nx && j >= 1 && j <= g.ny;
+    const size_t m = ((size_t)z * g.ny + (j - 1)) * g.nx + (i - 1);
+    if (dir == 0) pad[n] = in ? cmp[m] : 0.0;
+    else if (in) cmp[m] = pad[n];
+  }
+};
 typedef void (*fv3lm_allreduce_fn)(void* user, double* buf, int n);   // in-place max over ranks (host buffer)
 struct AllReduce { fv3lm_allreduce_fn cb = nullptr; void* user = nullptr; };
 inline AllReduce& allreduce_max_hook() { static AllReduce a; return a; }
@@ -122,6 +135,25 @@ struct Dynamics : Dycore {
   bool tracer_subcycle_error = false;
   std::vector<std::pair<double*, size_t>> tracer_zero;     // plan_adjoint(tracer_q, twork)
   std::vector<double*> snap;   // device snapshot of the prognostic state (fv3lm_state_save)
+  double* stage_dev = nullptr;   // compact staging buffer of the boundary copies (one field)
+  // one field between the host's compact array and the device state.  which: 0 trajectory, 1 perturbation / adjoint
+  void compact_in(const Fld& f, int which, const double* host) {
+    const size_t n = (size_t)g.ntile * f.nk * g.nx * g.ny;
+    if (!stage_dev) stage_dev = (double*)dev_alloc((size_t)g.ntile * (g.npz + 1) * g.nx * g.ny * 8);
+    h2d(ex, stage_dev, host, n * 8);
+    for_points(ex, Rect{g.isd(), g.ied() + 1, g.jsd(), g.jed() + 1}, g.ntile * f.nk, CompactFn{g, which ? f.p : f.t, stage_dev, f.nk, 0}, "boundary_unpack");
+  }
+  void compact_out(const Fld& f, int which, double* host) {
+    const size_t n = (size_t)g.ntile * f.nk * g.nx * g.ny;
+    if (!stage_dev) stage_dev = (double*)dev_alloc((size_t)g.ntile * (g.npz + 1) * g.nx * g.ny * 8);
+    for_points(ex, Rect{1, g.nx, 1, g.ny}, g.ntile * f.nk, CompactFn{g, which ? f.p : f.t, stage_dev, f.nk, 1}, "boundary_pack");
+    d2h(ex, host, stage_dev, n * 8);
+  }
+  bool traj_to_fv3(const double* u, const double* v, const double* t, const double* delp, const double* const* qs, const double* w,
+                   const double* delz, const double* phis);
+  bool pert_to_fv3(const double* u, const double* v, const double* t, const double* delp, const double* const* qs, const double* w,
+                   const double* delz);
+  bool fv3_to_pert(double* u, double* v, double* t, double* delp, double* const* qs, double* w, double* delz);
 
   bool init2(const double* ak, const double* bk);
   void destroy2();
@@ -187,10 +219,46 @@ inline bool Dynamics::init2(const double* ak, const double* bk) {
   return true;
 }
 inline void Dynamics::destroy2() {
+  dev_free(stage_dev); stage_dev = nullptr;
   dev_free(ak_dev); dev_free(bk_dev); dev_free(remap_ws); dev_free(cmax_dev); dev_free(ck_k); dev_free(ck_0); dev_free(ck_nh);
   tshared.destroy(); twork.destroy();
   for (double* p : snap) dev_free(p);
   for (auto& kv : sub_ck) dev_free(kv.second);
+}
+
+// traj_to_fv3 (DYN/fv3jedi_lm_dynamics_mod.F90:717-807): halos zeroed, interiors from the host's compact arrays, the D-grid edge rows
+// u(:, jec+1), v(iec+1, :) from the neighbours (mpp_get_boundary :781-793), halo of phis (:798), pe / peln / pk / pkz (:803-805)
+inline bool Dynamics::traj_to_fv3(const double* u, const double* v, const double* t, const double* delp, const double* const* qs, const double* w,
+                                  const double* delz, const double* phis) {
+  if (!u || !v || !t || !delp || (nq > 0 && !qs) || (nh && (!w || !delz))) { err = "traj_to_fv3: null array"; return false; }
+  compact_in(f("u"), 0, u); compact_in(f("v"), 0, v); compact_in(f("pt"), 0, t); compact_in(f("delp"), 0, delp);
+  for (int n = 0; n < nq; ++n) { if (!qs[n]) { err = "traj_to_fv3: null tracer array"; return false; } compact_in(q[n], 0, qs[n]); }
+  if (nh) { compact_in(f("w"), 0, w); compact_in(f("delz"), 0, delz); }
+  halo(MODE_NL, H_DEDGE, f("u"), f("v"));
+  if (phis) { Fld hs; hs.t = hs_dev; hs.p = nullptr; hs.nk = 1; compact_in(hs, 0, phis); halo(MODE_NL, H_CELL, hs); }
+  pressures(MODE_NL);
+  return true;
+}
+// pert_to_fv3 (:846-889): perturbation / adjoint arrays, halos zeroed
+inline bool Dynamics::pert_to_fv3(const double* u, const double* v, const double* t, const double* delp, const double* const* qs, const double* w,
+                                  const double* delz) {
+  if (!u || !v || !t || !delp || (nq > 0 && !qs) || (nh && (!w || !delz))) { err = "pert_to_fv3: null array"; return false; }
+  compact_in(f("u"), 1, u); compact_in(f("v"), 1, v); compact_in(f("pt"), 1, t); compact_in(f("delp"), 1, delp);
+  for (int n = 0; n < nq; ++n) compact_in(q[n], 1, qs[n]);
+  if (nh) { compact_in(f("w"), 1, w); compact_in(f("delz"), 1, delz); }
+  return true;
+}
+// fv3_to_pert (:893-933): compute-domain values back to the host; the device perturbation is cleared as the reference clears FV_AtmP
+inline bool Dynamics::fv3_to_pert(double* u, double* v, double* t, double* delp, double* const* qs, double* w, double* delz) {
+  if (!u || !v || !t || !delp || (nq > 0 && !qs) || (nh && (!w || !delz))) { err = "fv3_to_pert: null array"; return false; }
+  compact_out(f("u"), 1, u); compact_out(f("v"), 1, v); compact_out(f("pt"), 1, t); compact_out(f("delp"), 1, delp);
+  for (int n = 0; n < nq; ++n) compact_out(q[n], 1, qs[n]);
+  if (nh) { compact_out(f("w"), 1, w); compact_out(f("delz"), 1, delz); }
+  std::vector<Fld> fs{f("u"), f("v"), f("pt"), f("delp")};
+  for (auto& x : q) fs.push_back(x);
+  if (nh) { fs.push_back(f("w")); fs.push_back(f("delz")); }
+  for (const Fld& x : fs) dev_zero(ex, x.p, n3 * 8);
+  return true;
 }
 
 inline void Dynamics::build_remap_nh() {

@@ -217,7 +217,8 @@ HD void body_ad_joint(const S& s, const Ctx& c, const Rect& R, int i, int j, int
     }
     // Store.  Default: accumulate onto what later stages (earlier in this backward sweep) left.  Write mode (bit m of s.wmask,
     // set by Dycore::plan_adjoint for the first stage of the backward sweep that touches the buffer): store, with zeros outside
-    // the stage's reach, over the whole padded plane -- which is what lets the sweep run without clearing the work adjoints.
+    // the stage's reach, over the launch rectangle (widened to where the buffer is read later, s.wrect) -- which is what lets the sweep
+    // run without clearing the work adjoints.
 #pragma unroll
     for (int m = 0; m < N; ++m)
       if (kclass_of((const S*)nullptr, m) == KC && S::wants(m) && s.in[m].p) {
@@ -320,7 +321,10 @@ inline Rect ad_input_rect(const S& s, const Ctx& c, const Rect& R) {
     if (R.j0 + b.dj0 < q.j0) q.j0 = R.j0 + b.dj0;
     if (R.j1 + b.dj1 > q.j1) q.j1 = R.j1 + b.dj1;
   }
-  if (s.wmask) return Rect{c.g.isd(), c.g.ied() + 1, c.g.jsd(), c.g.jed() + 1};     // write mode covers the whole padded plane
+  if (s.wmask && s.wrect.i0 <= s.wrect.i1) {     // write mode: also where the stored adjoints are read later although this stage does not reach
+    if (s.wrect.i0 < q.i0) q.i0 = s.wrect.i0; if (s.wrect.i1 > q.i1) q.i1 = s.wrect.i1;
+    if (s.wrect.j0 < q.j0) q.j0 = s.wrect.j0; if (s.wrect.j1 > q.j1) q.j1 = s.wrect.j1;
+  }
   if (q.i0 < c.g.isd()) q.i0 = c.g.isd();
   if (q.j0 < c.g.jsd()) q.j0 = c.g.jsd();
   if (q.i1 > c.g.ied() + 1) q.i1 = c.g.ied() + 1;

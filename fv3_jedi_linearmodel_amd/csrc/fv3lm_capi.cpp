@@ -165,6 +165,20 @@ int fv3lm_fv_dynamics(fv3lm_handle* h, int mode) { h->d.fv_dynamics(mode); retur
 int fv3lm_step_tl(fv3lm_handle* h) { h->d.step_tl(); return status(h); }
 int fv3lm_step_nl(fv3lm_handle* h) { h->d.step_nl(); return status(h); }
 int fv3lm_step_ad(fv3lm_handle* h) { h->d.step_ad(); return status(h); }
+int fv3lm_traj_to_fv3(fv3lm_handle* h, const double* u, const double* v, const double* t, const double* delp, const double* const* q,
+                      const double* w, const double* delz, const double* phis) {
+  if (!h->d.traj_to_fv3(u, v, t, delp, q, w, delz, phis)) return fail(h->d.err);
+  return status(h);
+}
+int fv3lm_pert_to_fv3(fv3lm_handle* h, const double* u, const double* v, const double* t, const double* delp, const double* const* q,
+                      const double* w, const double* delz) {
+  if (!h->d.pert_to_fv3(u, v, t, delp, q, w, delz)) return fail(h->d.err);
+  return status(h);
+}
+int fv3lm_fv3_to_pert(fv3lm_handle* h, double* u, double* v, double* t, double* delp, double* const* q, double* w, double* delz) {
+  if (!h->d.fv3_to_pert(u, v, t, delp, q, w, delz)) return fail(h->d.err);
+  return status(h);
+}
 int fv3lm_zero_work_adjoint(fv3lm_handle* h) { h->d.zero_work_adjoint(); return 0; }
 int fv3lm_sync(fv3lm_handle* h) { dev_sync(h->d.ex); return status(h); }
 long fv3lm_launch_count(fv3lm_handle* h) { return h->d.ex.launches; }

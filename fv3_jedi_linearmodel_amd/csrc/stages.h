@@ -18,6 +18,7 @@ namespace fv3 {
   Rect orect[NO];                                                    \
   int k0 = 1, k1 = 1;                                                \
   unsigned wmask = 0;   /* adjoint: inputs whose adjoint this instance stores instead of accumulating (exec.h body_ad_joint) */ \
+  Rect wrect{1, 0, 1, 0};   /* ... and the rectangle those stores must cover besides the stage's own reach (dycore.h plan_adjoint) */ \
   static const char* name() { return NAME; }                        \
   static const char* ename() { return NAME "e"; }
 // Adjoint refinements a stage may override: uses(M, di, dj, dk) = does any output read input M at that

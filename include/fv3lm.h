@@ -136,6 +136,19 @@ int fv3lm_dyn_core(fv3lm_handle* h, int mode);   /* DYN_CORE_TLM dyn_core_tlm.F9
 int fv3lm_step_tl(fv3lm_handle* h);
 int fv3lm_step_nl(fv3lm_handle* h);
 int fv3lm_step_ad(fv3lm_handle* h);
+/* The host's boundary copies on the device -- traj_to_fv3, pert_to_fv3, fv3_to_pert (DYN/fv3jedi_lm_dynamics_mod.F90:717-807, :846-889,
+ * :893-933).  Arrays are the host's own traj% / pert% fields: COMPACT, (isc:iec, jsc:jec, npz) per resident tile in Fortran order
+ * (i fastest, tile slowest), no halo; q[n] one array per tracer (qv ql qi o3 ...), w / delz only when hydrostatic = 0, phis
+ * (isc:iec, jsc:jec) or NULL to keep the one given at create.
+ *   fv3lm_traj_to_fv3: halos zeroed, interiors copied, the D-grid edge rows u(:, jec+1) / v(iec+1, :) filled from the neighbour faces
+ *                      (mpp_get_boundary :781-793), halo of phis updated (:798), pe / peln / pk / pkz computed (:803-805).
+ *   fv3lm_pert_to_fv3: perturbation (step_tl) or adjoint forcing (step_ad) in, halos zeroed.
+ *   fv3lm_fv3_to_pert: compute-domain perturbation / adjoint out; the device copy is cleared as the reference clears FV_AtmP. */
+int fv3lm_traj_to_fv3(fv3lm_handle* h, const double* u, const double* v, const double* t, const double* delp, const double* const* q,
+                      const double* w, const double* delz, const double* phis);
+int fv3lm_pert_to_fv3(fv3lm_handle* h, const double* u, const double* v, const double* t, const double* delp, const double* const* q,
+                      const double* w, const double* delz);
+int fv3lm_fv3_to_pert(fv3lm_handle* h, double* u, double* v, double* t, double* delp, double* const* q, double* w, double* delz);
 /* Sub-operators, same mode argument (tests and kernel-level benchmarks): */
 int fv3lm_pressures(fv3lm_handle* h, int mode);                 /* compute_fv3_pressures{,_tlm,_bwd} TLM/fv_pressure.F90 */
 int fv3lm_tracer_2d(fv3lm_handle* h, int mode);                 /* TRACER_2D_TLM fv_tracer2d_tlm.F90:757 / _FWD+_BWD */

@@ -20,9 +20,12 @@ def build_driver(libdir, libname, out):
         return out
     mod = os.path.join(os.path.dirname(out), "mod_" + libname)
     os.makedirs(mod, exist_ok=True)
-    obj = os.path.join(mod, "fv3lm_hip_mod.o")
-    subprocess.check_call(["amdflang", "-cpp", "-fPIC", "-c", srcs[0], "-o", obj, "-module-dir", mod])
-    subprocess.check_call(["amdflang", "-cpp", srcs[1], obj, "-I", mod, "-o", out, "-L", libdir, "-l" + libname, "-Wl,-rpath," + libdir])
+    # compiled from copies inside the build directory: a stale fv3lm_hip_mod.mod next to the sources must not be picked up
+    import shutil
+    for s_ in srcs:
+        shutil.copy(s_, mod)
+    subprocess.check_call(["amdflang", "-cpp", "-fPIC", "-c", "fv3lm_hip_mod.F90", "-o", "fv3lm_hip_mod.o"], cwd=mod)
+    subprocess.check_call(["amdflang", "-cpp", "shim_driver.F90", "fv3lm_hip_mod.o", "-o", out, "-L", libdir, "-l" + libname, "-Wl,-rpath," + libdir], cwd=mod)
     return out
 
 
@@ -75,6 +78,10 @@ def run_shim_check(c, driver, tmpdir):
         for n in names:
             shp = shapes.get(n, (nx + 6, ny + 6, npz)); cnt = int(np.prod(shp))
             got[(tag, n)] = raw[pos:pos + cnt].reshape(shp, order="F"); pos += cnt
+    nb = nx * ny * npz
+    bnd = {}
+    for n in names:
+        bnd[n] = raw[pos:pos + nb].reshape((nx, ny, npz), order="F"); pos += nb
     assert pos == raw.size
     # ---- the same calls through ctypes; the shim zero-fills what lies outside the reference's array bounds
     def put(D, which):
@@ -89,3 +96,11 @@ def run_shim_check(c, driver, tmpdir):
         b = np.transpose(ref[key][sl.get(key[1], cell)], (2, 1, 0))
         assert np.array_equal(a, b), key
         assert np.isfinite(a).all() and np.abs(a).max() > 0, key
+    # ---- the boundary entry points through the shim (compact arrays, no halo) against the same calls through ctypes
+    I = (slice(None), slice(None), slice(3, 3 + ny), slice(3, 3 + nx))
+    c.dy.traj_to_fv3({**{n: T[n][None][I] for n in names}, "phis": np.ascontiguousarray(c.phis[:, 3:3 + ny, 3:3 + nx])})
+    c.dy.pert_to_fv3({n: P[n][None][I] for n in names})
+    c.dy.step_tl()
+    out = c.dy.fv3_to_pert(names)
+    for n in names:
+        assert np.array_equal(bnd[n], np.transpose(out[n][0], (2, 1, 0))), ("boundary", n)

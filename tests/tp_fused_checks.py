@@ -7,9 +7,12 @@ import numpy as np
 from groups import step_state, cube_step_state
 
 
+FUSED_VALUE = "1"        # which fused form stands against the staged launches (1: tiled default, 3: marching)
+
+
 def _run(make_case, fused):
     old = os.environ.get("FV3LM_TP_FUSED")
-    os.environ["FV3LM_TP_FUSED"] = "1" if fused else "0"
+    os.environ["FV3LM_TP_FUSED"] = FUSED_VALUE if fused else "0"
     try:
         c = make_case()
     finally:
