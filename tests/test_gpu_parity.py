@@ -255,3 +255,12 @@ def test_fused_tp_equals_staged_nonhydrostatic():
     from common import Case
     from tp_fused_checks import check_fused_equals_staged
     check_fused_equals_staged(lambda: Case(nx=66, ny=18, npz=10, n_split=1, k_split=1, dt=300.0, backend="hip", oracle=False, hydrostatic=0), rtol=1e-12)
+
+
+def test_boundary_copies_on_the_device():
+    """fv3lm_traj_to_fv3 / _pert_to_fv3 / _fv3_to_pert (compact host arrays, halos / edge rows / pressures done by the library) against the
+    whole-field put / get sequence: step_tl and step_ad bit for bit (boundary_checks.py)"""
+    from common import Case, CubeCase
+    from boundary_checks import check_boundary_copies
+    check_boundary_copies(Case(nx=24, ny=20, npz=16, n_split=2, k_split=1, dt=900.0, backend="hip", oracle=False, nq=2))
+    check_boundary_copies(CubeCase(n=12, npz=8, n_split=2, k_split=2, backend="hip", nq=2), cube=True)
