@@ -609,3 +609,24 @@ def repeated_adjoint(c, seed=17):
     c.dy.step_nl()
     fresh = backward(yb)
     return max(relerr(second[n], fresh[n]) for n in names)
+
+
+def check_step_nl(c, tol):
+    """fv3lm_step_nl (nonlinear propagation of the trajectory with the schemes in force) against the oracle's nonlinear fv_dynamics:
+    the state after one step, field by field"""
+    from oracle import NL
+    T, P = step_state(c)
+    nq = c.nq
+    ins_n = ["u", "v", "pt", "delp", "pe", "peln", "pk", "pkz"] + ["q%d" % (n + 1) for n in range(nq)]
+    outs = [("u", "U"), ("v", "V"), ("pt", "A"), ("delp", "A")] + [("q%d" % (n + 1), "A") for n in range(nq)]
+    ot, _ = c.oracle.fv_dynamics(NL, nq, c.dims.dt, c.dims.n_split, c.dims.k_split, [T[n] for n in ins_n])
+    for n, _rk in outs:
+        c.dy.put(n, T[n][None], 0)
+    c.dy.step_nl()
+    worst = 0.0
+    for (n, rk), a in zip(outs, ot):
+        r = c.rect(*rects(c)[rk])
+        e = relerr(c.dy.get(n, 0)[0][r], a[r])
+        assert e < tol, (n, "nl", e)
+        worst = max(worst, e)
+    return worst

@@ -131,3 +131,11 @@ def test_trajectory_slots(slots, monkeypatch):
     check_dyn_core(c, AD, 1e-10)
     lhs, rhs = dot_product_test(c)
     assert abs(lhs - rhs) <= 1e-12 * abs(lhs), (lhs, rhs)
+
+
+def test_step_nl_matches_the_oracle():
+    """the step_nl entry point (reference: fv3jedi_lm_dynamics_type%step_nl, DYN/fv3jedi_lm_dynamics_mod.F90:268-343, with the schemes
+    the TL/AD path implements) against the oracle's nonlinear step"""
+    from groups import check_step_nl
+    c = Case(nx=12, ny=10, npz=10, n_split=2, k_split=2, dt=1800.0, backend="emul", nq=3)
+    check_step_nl(c, 1e-12)

@@ -264,3 +264,8 @@ def test_boundary_copies_on_the_device():
     from boundary_checks import check_boundary_copies
     check_boundary_copies(Case(nx=24, ny=20, npz=16, n_split=2, k_split=1, dt=900.0, backend="hip", oracle=False, nq=2))
     check_boundary_copies(CubeCase(n=12, npz=8, n_split=2, k_split=2, backend="hip", nq=2), cube=True)
+
+
+def test_step_nl_matches_the_oracle(case_q):
+    from groups import check_step_nl
+    check_step_nl(case_q, 1e-11)
