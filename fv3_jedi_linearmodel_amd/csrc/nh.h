@@ -655,11 +655,32 @@ struct NhColFn {
     }
   }
 };
+// Algorithmic bytes of one column-operator launch (bench.py roofline leg): the operator's input and output fields, each touched once
+// per cell (8 B), x2 in the tangent mode, and inputs + outputs read plus input adjoints read-modify-written in the adjoint -- the same
+// rule as exec.h stage_bytes.  Workspace and tape traffic is not algorithmic: it shows up as the gap between this and the PMC traffic.
+inline double nh_col_bytes(const NhColArgs& a, int kind, int mode, const Rect& R, const Rect& skip) {
+  int nin = 0, nout = 0;
+  switch (kind) {
+    case NHC_RIEM_C: nin = 4; nout = 2; break;
+    case NHC_RIEM3: nin = 4; nout = a.last_call ? 9 : 5; break;
+    case NHC_EDGE: nin = 2; nout = 2; break;
+    case NHC_ZH_INIT: nin = 1; nout = 1; break;
+    case NHC_RING: nin = 1; nout = 1; break;
+    case NHC_RM_FIELD: case NHC_RM_W: nin = a.what == 0 ? 5 : a.what == 3 ? 2 : 3; nout = 1; break;
+    default: nin = 6; nout = 4; break;      // NHC_RM_PRESS
+  }
+  double cols = double(R.i1 - R.i0 + 1) * double(R.j1 - R.j0 + 1);
+  if (skip.i0 <= skip.i1 && skip.j0 <= skip.j1) cols -= double(skip.i1 - skip.i0 + 1) * double(skip.j1 - skip.j0 + 1);
+  const double cells = cols * a.g.ntile * a.g.npz;
+  const double per = mode == MODE_NL ? nin + nout : mode == MODE_TL ? 2. * (nin + nout) : (nin + nout + 2. * nin);
+  return 8. * per * cells;
+}
 template <int KIND, int MODE>
 inline void run_nh_col_km(Exec& ex, const NhColArgs& a, const Rect& R, const Rect& skip, const char* tag) {
-  if (MODE != MODE_AD || !a.use_tape) { for_points(ex, R, a.g.ntile, NhColFn<KIND, MODE>{a, skip, 0}, tag); return; }   // hand-written adjoints need no tape
+  const double bytes = nh_col_bytes(a, KIND, MODE, R, skip);
+  if (MODE != MODE_AD || !a.use_tape) { for_points(ex, R, a.g.ntile, NhColFn<KIND, MODE>{a, skip, 0}, tag, bytes); return; }   // hand-written adjoints need no tape
   const int chunk = (int)(a.tape.stride / a.g.plane);       // tiles the tape holds at once (dycore.h sizes it from the free HBM)
-  for (int z = 0; z < a.g.ntile; z += chunk) for_points(ex, R, std::min(chunk, a.g.ntile - z), NhColFn<KIND, MODE>{a, skip, z}, tag);
+  for (int z = 0; z < a.g.ntile; z += chunk) for_points(ex, R, std::min(chunk, a.g.ntile - z), NhColFn<KIND, MODE>{a, skip, z}, tag, bytes * std::min(chunk, a.g.ntile - z) / a.g.ntile);
 }
 template <int KIND>
 inline void run_nh_col_k(Exec& ex, int mode, const NhColArgs& a, const Rect& R, const Rect& skip, const char* tag) {

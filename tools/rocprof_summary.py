@@ -27,6 +27,9 @@ def short(name):
     m = re.search(r"k_stage_ad_lds<fv3::(?:Edged<fv3::)?([A-Za-z0-9_]+?)D?(?:_?<|,)", name)
     if m:
         return "%s.ad(lds)" % m.group(1).rstrip("_")
+    m = re.search(r"k_tp_(fused|march)<(fv3::Dual|double)", name)
+    if m:       # fv_tp_2d as one launch (tpfused.h): tiled or marching form; Dual = tangent, double = nonlinear (stores the intermediates)
+        return "%s.%s" % ("TpFused" if m.group(1) == "fused" else "TpMarch", "tl" if "Dual" in m.group(2) else "nl")
     m = re.search(r"k_points<fv3::([A-Za-z0-9_]+(?:<[^>]*>)?)", name)
     if m:
         return "points<%s>" % m.group(1)
