@@ -348,7 +348,6 @@ inline double stage_bytes(const S& s, const Ctx& c, const Rect& R, int mode) {
 #ifndef FV3LM_HOST_EMUL
 // ---- HIP kernels ---------------------------------------------------------------------------
 constexpr int BX = 64, BY = 4;
-constexpr int XREM = 8;     // a row remainder of up to this many points (beyond a multiple of BX) gets no block column of its own
 // tr: narrow column strips (face-edge stages) run with the 64 lanes of a wave along j instead of i
 // XCD-aware block order.  Workgroups go to the 8 XCDs round-robin by linear id, so with the plain (x, y) order the
 // blocks above and below a block — which re-read 2/3 of its stencil rows — sit on other XCDs and their private L2s
@@ -366,20 +365,15 @@ HD void thread_point(const Rect& R, int tr, int bx, int by, int tx, int ty, int&
   if (tr) { const int rows = BX / tr; i = R.i0 + bx * tr + tx % tr; j = R.j0 + (by * BY + ty) * rows + tx / tr; }
   else { i = R.i0 + bx * BX + tx; j = R.j0 + by * BY + ty; }
 }
-// Rows a few points wider than a multiple of 64 (193 .. 199 on a C192 face: the +1 of the staggered points and the halo) would
-// spend a fourth block column on those few points; grid_for leaves it out and the lanes that cover the remainder take a second
-// point (the x loop below runs once for everybody else).
 template <class S>
 __global__ void __launch_bounds__(BX* BY) k_stage_nl(S s, Ctx c, Rect R, int tr) {
   int i, j, bx = blockIdx.x, by = blockIdx.y; xcd_block(gridDim.x, gridDim.y, bx, by); thread_point(R, tr, bx, by, threadIdx.x, threadIdx.y, i, j);
-  if (j > R.j1) return;
-  for (; i <= R.i1; i += tr ? (1 << 30) : BX * (int)gridDim.x) body_nl(s, c, i, j, blockIdx.z);
+  if (i <= R.i1 && j <= R.j1) body_nl(s, c, i, j, blockIdx.z);
 }
 template <class S>
 __global__ void __launch_bounds__(BX* BY) k_stage_tl(S s, Ctx c, Rect R, int tr) {
   int i, j, bx = blockIdx.x, by = blockIdx.y; xcd_block(gridDim.x, gridDim.y, bx, by); thread_point(R, tr, bx, by, threadIdx.x, threadIdx.y, i, j);
-  if (j > R.j1) return;
-  for (; i <= R.i1; i += tr ? (1 << 30) : BX * (int)gridDim.x) body_tl(s, c, i, j, blockIdx.z);
+  if (i <= R.i1 && j <= R.j1) body_tl(s, c, i, j, blockIdx.z);
 }
 // ---- LDS-staged forward launch (nonlinear / tangent) ----------------------------------------------------------------------
 // A stage opts in with `static constexpr bool LDS_FW / LDS_AD = true` (bulk stencil stages whose reads stay inside their declared
@@ -473,8 +467,7 @@ __global__ void __launch_bounds__(BX* S::LDS_BY) k_stage_fw_lds(S s, Ctx c, Rect
 template <class S>
 __global__ void __launch_bounds__(BX* BY) k_stage_ad(S s, Ctx c, Rect R, Rect Q, int nkmax, int tr) {
   int i, j, bx = blockIdx.x, by = blockIdx.y; xcd_block(gridDim.x, gridDim.y, bx, by); thread_point(Q, tr, bx, by, threadIdx.x, threadIdx.y, i, j);
-  if (j > Q.j1) return;
-  for (; i <= Q.i1; i += tr ? (1 << 30) : BX * (int)gridDim.x) ad_point(s, c, R, i, j, blockIdx.z, nkmax);
+  if (i <= Q.i1 && j <= Q.j1) ad_point(s, c, R, i, j, blockIdx.z, nkmax);
 }
 template <class S>
 __global__ void __launch_bounds__(64) k_stage_ad_alias(S s, Ctx c, Rect R) {
@@ -488,12 +481,9 @@ inline int strip_tr(const Rect& R) {
   if (h < BX / 2) return 0;
   return w <= 8 ? 8 : w <= 16 ? 16 : 0;
 }
-inline dim3 grid_for(const Rect& R, int nz, int tr = 0, bool fold = false) {      // fold: the kernel loops in x (see k_stage_nl)
+inline dim3 grid_for(const Rect& R, int nz, int tr = 0) {
   if (tr) { const int rows = BY * (BX / tr); return dim3((R.i1 - R.i0 + tr) / tr, (R.j1 - R.j0 + rows) / rows, nz); }
-  const int w = R.i1 - R.i0 + 1;
-  int gx = (w + BX - 1) / BX;
-  if (fold && w > BX && w % BX != 0 && w % BX <= XREM) gx = w / BX;      // the remainder rides in the existing block columns (kernels loop in x)
-  return dim3(gx, (R.j1 - R.j0 + BY) / BY, nz);
+  return dim3((R.i1 - R.i0 + BX) / BX, (R.j1 - R.j0 + BY) / BY, nz);
 }
 // ---- LDS-staged adjoint launch (joint gather form, single level class, no vertical stencil, no corner aliases) -----
 // The thread that owns input point p evaluates the stage at the outputs o = p - u (u in the union box U of the inputs);
@@ -612,7 +602,7 @@ template <class S>
 void run_nl(Exec& ex, const S& s, const Ctx& c) {
   Rect R = rect_union(s.orect, S::NOUT);
   ex.mark_begin(S::name(), ".nl", stage_bytes(s, c, R, MODE_NL));
-  hipLaunchKernelGGL(k_stage_nl<S>, grid_for(R, c.g.ntile * (s.k1 - s.k0 + 1), strip_tr(R), true), dim3(BX, BY), 0, ex.stream, s, c, R, strip_tr(R));
+  hipLaunchKernelGGL(k_stage_nl<S>, grid_for(R, c.g.ntile * (s.k1 - s.k0 + 1), strip_tr(R)), dim3(BX, BY), 0, ex.stream, s, c, R, strip_tr(R));
   ex.mark_end();
   ex.launches++;
 }
@@ -623,7 +613,7 @@ void run_tl(Exec& ex, const S& s, const Ctx& c) {
   if constexpr (lds_fw<S>::value) if constexpr (TileLayout<S>::total > 0 && TileLayout<S>::total * 16 <= 60000) { if (strip_tr(R) == 0) {
     launch_fw_lds<S, true>(ex, s, c, R);
     ex.mark_end(); ex.launches++; return; } }
-  hipLaunchKernelGGL(k_stage_tl<S>, grid_for(R, c.g.ntile * (s.k1 - s.k0 + 1), strip_tr(R), true), dim3(BX, BY), 0, ex.stream, s, c, R, strip_tr(R));
+  hipLaunchKernelGGL(k_stage_tl<S>, grid_for(R, c.g.ntile * (s.k1 - s.k0 + 1), strip_tr(R)), dim3(BX, BY), 0, ex.stream, s, c, R, strip_tr(R));
   ex.mark_end();
   ex.launches++;
 }
@@ -641,7 +631,7 @@ void run_ad(Exec& ex, const S& s, const Ctx& c) {
       const dim3 gq((Q.i1 - Q.i0 + BX) / BX, (Q.j1 - Q.j0 + S::LDS_BY) / S::LDS_BY, c.g.ntile * s.in[0].nk);
       hipLaunchKernelGGL(k_stage_ad_lds<S>, gq, dim3(BX, S::LDS_BY), TileLayoutAd<S>::total * 8, ex.stream, s, c, R, Q);
       ex.mark_end(); ex.launches++; return; } } }
-  hipLaunchKernelGGL(k_stage_ad<S>, grid_for(Q, c.g.ntile * nkmax, strip_tr(Q), true), dim3(BX, BY), 0, ex.stream, s, c, R, Q, nkmax, strip_tr(Q));
+  hipLaunchKernelGGL(k_stage_ad<S>, grid_for(Q, c.g.ntile * nkmax, strip_tr(Q)), dim3(BX, BY), 0, ex.stream, s, c, R, Q, nkmax, strip_tr(Q));
   ex.mark_end();
   ex.launches++;
   if constexpr (S::NALIAS > 0) if (c.g.face) {
@@ -725,15 +715,14 @@ void run_multi(Exec& ex, int mode, const S* s0, int n, const Ctx& c) {
 // generic per-point functor launch: f(i, j, z)
 template <class F>
 __global__ void __launch_bounds__(BX* BY) k_points(F f, Rect R) {
-  const int j = R.j0 + blockIdx.y * BY + threadIdx.y;
-  if (j > R.j1) return;
-  for (int i = R.i0 + blockIdx.x * BX + threadIdx.x; i <= R.i1; i += BX * (int)gridDim.x) f(i, j, (int)blockIdx.z);
+  const int i = R.i0 + blockIdx.x * BX + threadIdx.x, j = R.j0 + blockIdx.y * BY + threadIdx.y;
+  if (i <= R.i1 && j <= R.j1) f(i, j, (int)blockIdx.z);
 }
 template <class F>
 void for_points(Exec& ex, const Rect& R, int nz, const F& f, const char* tag = "points", double bytes = 0.) {
   if (nz <= 0) return;
   ex.mark_begin(tag, "", bytes);
-  hipLaunchKernelGGL(k_points<F>, grid_for(R, nz, 0, true), dim3(BX, BY), 0, ex.stream, f, R);
+  hipLaunchKernelGGL(k_points<F>, grid_for(R, nz), dim3(BX, BY), 0, ex.stream, f, R);
   ex.mark_end();
   ex.launches++;
 }
