@@ -134,6 +134,7 @@ struct Op {
   std::vector<int> ad_in_slot;                 // stage input index of each ad_in entry
   std::function<void(unsigned, Rect)> set_wmask;     // stage ops only: write-mode inputs and the rectangle the stores must cover
   std::vector<Rect> ad_out_rect;               // where the op writes each ad_out in the forward direction (empty: unknown -> whole plane)
+  std::vector<double*> ad_store;               // adjoints the op's adjoint STORES over everything read later (hand-written fused adjoints)
   std::string name;                            // stage name (diagnostics)
   Op() = default;
   Op(std::string g_, std::function<void(Exec&, int)> f_, bool acc_ = false) : group(std::move(g_)), fn(std::move(f_)), accum(acc_) {}
@@ -349,6 +350,7 @@ struct Dycore {
       unsigned w = 0; Rect wr{1, 0, 1, 0};
       auto grow = [&](const Rect& r) { if (wr.i0 > wr.i1) wr = r; else { wr.i0 = std::min(wr.i0, r.i0); wr.i1 = std::max(wr.i1, r.i1); wr.j0 = std::min(wr.j0, r.j0); wr.j1 = std::max(wr.j1, r.j1); } };
       for (double* q_ : it->ad_out) if (inA(q_) && !written.count(q_)) zero.insert(q_);
+      for (double* q_ : it->ad_store) if (inA(q_)) written.insert(q_);
       for (size_t n = 0; n < it->ad_in.size(); ++n) {
         double* q_ = it->ad_in[n];
         if (!inA(q_) || written.count(q_)) continue;
@@ -415,11 +417,15 @@ struct Dycore {
     ppm_y(q, fy2, R(isd, ied, js, je + 1), 2);
     TpQi b; b.in[0] = q; b.in[1] = fy2; b.in[2] = yfx; b.in[3] = ray; b.out[0] = q_i; b.orect[0] = R(isd, ied, js, je); b.k1 = npz;
     add(P, grp, b);
+    const size_t o1a = P.size();
     ppm_x(q_i, fxo, R(is, ie + 1, js, je), 0);
+    const size_t o1b = P.size();
     ppm_x(q, fx2, R(is, ie + 1, jsd, jed), 1);
     TpQj e; e.in[0] = q; e.in[1] = fx2; e.in[2] = xfx; e.in[3] = rax; e.out[0] = q_j; e.orect[0] = R(is, ie, jsd, jed); e.k1 = npz;
     add(P, grp, e);
+    const size_t o2a = P.size();
     ppm_y(q_j, fyo, R(is, ie, js, je + 1), 0);
+    const size_t o2b = P.size();
     Fld d2b{};
     if (dsel != DAMP_NONE) {
       d2b = W((pre + "_d2b").c_str(), npz);
@@ -431,6 +437,7 @@ struct Dycore {
     for (int n = 6; n < 9; ++n) if (!t.in[n].t) t.in[n].nk = npz;
     t.out[0] = fx; t.out[1] = fy; t.orect[0] = R(is, ie + 1, js, je); t.orect[1] = R(is, ie, js, je + 1); t.k1 = npz;
     t.dsel = dsel; t.use_mass = use_mass;
+    const size_t o3 = P.size();
     add(P, grp, t);
     if (fused) {
       size_t d2_op = P.size();      // the damping Laplacian (TpD2) stays a stage of its own in every mode
@@ -453,6 +460,27 @@ struct Dycore {
       for (const Fld* f_ : {&a.q, &a.crx, &a.cry, &a.xfx, &a.yfx, &a.rax, &a.ray, &a.mx, &a.my, &a.mass, &a.d2b}) if (f_->p) op.ad_in.push_back(f_->p);
       for (const Fld* f_ : {&a.fx, &a.fy, &a.fy2, &a.q_i, &a.fxo, &a.fx2, &a.q_j, &a.fyo, &a.acx, &a.acy, &a.amfx, &a.amfy}) if (f_->p) op.ad_out.push_back(f_->p);
       P.push_back(op);
+      // adjoint: flux assembly + the two outer sweeps as one hand-written launch (tpfused.h tp_outer_ad_block); their staged launches
+      // then never run, the damping part of the flux keeps a (small) stage of its own.  FV3LM_TP_AD_FUSED=0: all staged.
+      const char* aenv = std::getenv("FV3LM_TP_AD_FUSED");
+      if (!(aenv && aenv[0] == '0')) {
+        for (size_t n = o1a; n < o1b; ++n) P[n].modes = 0;
+        for (size_t n = o2a; n < o2b; ++n) P[n].modes = 0;
+        P[o3].modes = 0;
+        if (dsel != DAMP_NONE) {
+          TpDamp dm; dm.in[0] = q; dm.in[1] = d2b; dm.in[2] = use_mass ? mass : Fld{};
+          for (int n = 1; n < 3; ++n) if (!dm.in[n].t) dm.in[n].nk = npz;
+          dm.out[0] = fx; dm.out[1] = fy; dm.orect[0] = R(is, ie + 1, js, je); dm.orect[1] = R(is, ie, js, je + 1); dm.k1 = npz;
+          dm.dsel = dsel; dm.use_mass = use_mass;
+          add(P, grp, dm); P.back().modes = 1u << MODE_AD;
+        }
+        Op ad{grp, [a, cp](Exec& e, int) { run_tp_outer_ad(e, a, *cp); }};
+        ad.modes = 1u << MODE_AD; ad.name = "TpOuter";
+        ad.ad_out = {fx.p, fy.p}; ad.ad_out_rect = {R(is, ie + 1, js, je), R(is, ie, js, je + 1)};
+        ad.ad_store = {q_i.p, q_j.p, fx2.p, fy2.p};
+        ad.ad_in = {crx.p, cry.p, mx.p, my.p};
+        P.push_back(ad);
+      }
     }
   }
   // a2b_ord4 (a2b_edge_tlm.F90:48-542): q (nk levels) -> qb on is..ie+1, js..je+1

@@ -90,6 +90,27 @@ HD T ppm_flux(int iord, bool face, int m, int n1, const Q& q, const D& da, T cc)
   return (2.0 * q(m - 1) + 5.0 * q(m) - q(m + 1)) / 6.0 - 0.5 * cc * (q(m) - q(m - 1)) + cc * cc / 6.0 * (q(m + 1) - 2.0 * q(m) + q(m - 1));
 }
 
+// d flux(m) / d q(k) of the same schemes in closed form (they are linear in q for a given Courant number): the transposed sweep of
+// the hand-written outer adjoint (tpfused.h).  al(x) = sum_e w_e(x) q(x - 2 + e) with the edge-aware weights of edges.h ppm_w.
+template <class D>
+HD double ppm_al_coef(bool face, int x, int n1, const D& da, int k) {
+  const int e = k - x + 2;
+  if (e < 0 || e > 3) return 0.;
+  double w[4]; ppm_w(face, x, n1, da, w);
+  return w[e];
+}
+template <class D>
+HD double ppm_dq(int iord, bool face, int m, int n1, int k, const D& da, double c) {
+  if (iord == 1) return (c > 0.) ? (k == m - 1 ? 1. : 0.) : (k == m ? 1. : 0.);
+  if (iord == 2) {   // c > 0: qt c(3-2c) + al(m) (1-c)^2 - al(m-1) c(1-c);  else: qt (-c)(3+2c) + al(m) (1+c)^2 + al(m+1) c(1+c)
+    if (c > 0.) return (1. - c) * (1. - c) * ppm_al_coef(face, m, n1, da, k) - c * (1. - c) * ppm_al_coef(face, m - 1, n1, da, k) + (k == m - 1 ? c * (3. - 2. * c) : 0.);
+    return (1. + c) * (1. + c) * ppm_al_coef(face, m, n1, da, k) + c * (1. + c) * ppm_al_coef(face, m + 1, n1, da, k) + (k == m ? -c * (3. + 2. * c) : 0.);
+  }
+  const double c2 = c * c / 6.;      // iord == 333
+  if (c > 0.) return k == m ? 2. / 6. - 0.5 * c + c2 : k == m - 1 ? 5. / 6. + 0.5 * c - 2. * c2 : k == m - 2 ? -1. / 6. + c2 : 0.;
+  return k == m - 1 ? 2. / 6. + 0.5 * c + c2 : k == m ? 5. / 6. - 0.5 * c - 2. * c2 : k == m + 1 ? -1. / 6. + c2 : 0.;
+}
+
 // xtp_u / ytp_v flux at interface m (sw_core_tlm.F90:7272-7486, :7490-7759): cfl = c * rd(upwind cell).
 template <class T, class Q, class D>
 HD T tp_uv_flux(int iord, bool face, int m, int n1, bool row_edge, const Q& q, const D& dd, T cc, double rd_m, double rd_0) {
@@ -651,6 +672,38 @@ struct TpFlux {
         else f = f + f2;
       }
       o[1] = f;
+    }
+  }
+};
+
+// The damping part of the flux assembly alone (deln_flux, tp_core_tlm.F90:1918-2043): fx, fy <- the del-2 / del-4 fluxes of q.  Used in
+// the adjoint mode only, beside the fused outer adjoint of tpfused.h (which handles 0.5 (f_outer + f_inner) m): the flux is the sum of the
+// two parts, so the adjoints with respect to q, d2b and mass are exactly this stage's.
+struct TpDamp {
+  STAGE_BASE("TpDamp", 3, 2)   // in: q d2b mass   out: fx fy (adjoints read; never run forward)
+  STAGE_NO_ALIAS
+  int dsel; int use_mass;
+  HD static constexpr bool uses(int, int di, int dj, int) { return !(di == -1 && dj == -1); }
+  HD static constexpr unsigned wants(int) { return 0x3u; }
+  HD static constexpr Box box(int) { return Box{-1, 0, -1, 0, 0, 0}; }
+  template <class T, class A>
+  HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
+    int nord; double dc; damp_of(c.lev[k - 1], dsel, nord, dc);
+    const bool dmp = (dsel != DAMP_NONE) && (dc > 1.e-4);
+    o[0] = o[1] = T(0.);
+    if (!dmp) return;
+    double damp = dc * c.m.da_min; if (nord == 1) damp = damp * damp;
+    if ((a.want & 0x1u) && orect[0].has(i, j)) {
+      T f2;
+      if (nord == 0) { f2 = MET(del6_v, i, j) * (IN(0, i - 1, j) - IN(0, i, j)); if (!use_mass) f2 = damp * f2; }
+      else f2 = MET(del6_v, i, j) * (IN(1, i, j) - IN(1, i - 1, j));
+      o[0] = use_mass ? (0.5 * damp) * (IN(2, i - 1, j) + IN(2, i, j)) * f2 : f2;
+    }
+    if ((a.want & 0x2u) && orect[1].has(i, j)) {
+      T f2;
+      if (nord == 0) { f2 = MET(del6_u, i, j) * (IN(0, i, j - 1) - IN(0, i, j)); if (!use_mass) f2 = damp * f2; }
+      else f2 = MET(del6_u, i, j) * (IN(1, i, j) - IN(1, i, j - 1));
+      o[1] = use_mass ? (0.5 * damp) * (IN(2, i, j - 1) + IN(2, i, j)) * f2 : f2;
     }
   }
 };

@@ -236,6 +236,162 @@ inline void run_tp_fused(Exec& ex, int mode, const TpFusedArgs& a0, const Ctx& c
 }
 
 // =====================================================================================================================
+// Hand-written adjoint of the OUTER half of fv_tp_2d: flux assembly + outer x-sweep (q_i -> fxo) + outer y-sweep (q_j -> fyo), one
+// LDS-tiled launch instead of three gather launches + four strip launches.
+//   fxo_ad = 0.5 mx fx_ad               fx2_ad  = 0.5 mx fx_ad  (stored)            mx_ad += 0.5 (fxo + fx2) fx_ad
+//   q_i_ad(k) = sum_{m = k-2 .. k+3} d flux(m)/d q_i(k) fxo_ad(m)   (stored)       crx_ad(m) += d flux(m)/d c  fxo_ad(m)
+// and the same in y.  The schemes are linear in q for a given Courant number, so d flux/d q is a closed form of c and the edge-aware
+// weights (stages.h ppm_dq) -- no dual-number evaluation per offset as in the generic gather; d flux/d c is one ppm_flux<Dual> with
+// only c seeded.  The damping part of the flux is a stage of its own in the adjoint (stages.h TpDamp).  The launch is the first
+// one of the backward pass through the routine: it STORES the adjoints of q_i, q_j, fx2, fy2 over the rectangles the staged launches
+// that follow (TpQi, TpQj, the inner sweeps) read, zeros included, and accumulates into crx, cry, mx, my.
+// =====================================================================================================================
+constexpr int TPA_AW = TPF_W + 6;                                   // pitch of the x-halo'd tiles
+constexpr int TPA_NA = TPA_AW * TPF_H, TPA_NC = TPF_W * (TPF_H + 6);
+constexpr int TPA_NT = 3 * TPA_NA + 3 * TPA_NC;                     // fxo_ad, crx, q_i | fyo_ad, cry, q_j
+constexpr int TPA_THREADS = 512;
+
+template <int NTH>
+DEV void tp_outer_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx, int by, double* lds, int tid, int nth) {
+  (void)nth;
+  const Geom& g = c.g;
+  const int nx = g.nx, ny = g.ny;
+  const bool face = g.face != 0;
+  const int I0 = 1 + bx * TPF_W, I1 = (I0 + TPF_W - 1 < nx) ? I0 + TPF_W - 1 : nx;
+  const int J0 = 1 + by * TPF_H, J1 = (J0 + TPF_H - 1 < ny) ? J0 + TPF_H - 1 : ny;
+  const bool firstx = bx == 0, lastx = I1 == nx, firsty = by == 0, lasty = J1 == ny;
+  const size_t base = (size_t)(tile * a.nk + k - 1) * g.plane;
+  auto at = [&](int i, int j) -> size_t { return base + g.idx(i, j); };
+  const int iord = hord_of(c.lev[k - 1], a.hsel);
+  // tiles: x-halo'd [I0-3, I1+3] x [J0, J1] and y-halo'd [I0, I1] x [J0-3, J1+3]
+  double* fxa = lds; double* cxt = lds + TPA_NA; double* qit = lds + 2 * TPA_NA;
+  double* fya = lds + 3 * TPA_NA; double* cyt = fya + TPA_NC; double* qjt = fya + 2 * TPA_NC;
+  auto ex_ = [&](int i, int j) { return (j - J0) * TPA_AW + (i - (I0 - 3)); };
+  auto ey_ = [&](int i, int j) { return (j - (J0 - 3)) * TPF_W + (i - I0); };
+  { constexpr int n = TPA_NA;
+    TPF_LOOP(e, n) {
+      const int i = I0 - 3 + e % TPA_AW, j = J0 + e / TPA_AW;
+      double f = 0., cc = 0., q = 0.;
+      if (i <= I1 + 3 && j <= J1) {
+        q = a.q_i.t[at(i, j)];
+        if (i >= 1 && i <= nx + 1) { cc = a.crx.t[at(i, j)]; f = 0.5 * a.mx.t[at(i, j)] * a.fx.p[at(i, j)]; }
+      }
+      fxa[e] = f; cxt[e] = cc; qit[e] = q;
+    } }
+  { constexpr int n = TPA_NC;
+    TPF_LOOP(e, n) {
+      const int i = I0 + e % TPF_W, j = J0 - 3 + e / TPF_W;
+      double f = 0., cc = 0., q = 0.;
+      if (i <= I1 && j <= J1 + 3) {
+        q = a.q_j.t[at(i, j)];
+        if (j >= 1 && j <= ny + 1) { cc = a.cry.t[at(i, j)]; f = 0.5 * a.my.t[at(i, j)] * a.fy.p[at(i, j)]; }
+      }
+      fya[e] = f; cyt[e] = cc; qjt[e] = q;
+    } }
+  TPF_SYNC();
+  // ---- flux points of the block: Courant-number and mass-flux adjoints, the stored inner-flux adjoints
+  { constexpr int w = TPF_W + 1, n = w * (TPF_H + 1);
+    TPF_LOOP(e, n) {
+      const int i = I0 + e % w, j = J0 + e / w;
+      if (i > I1 + 1 || j > J1 + 1) continue;
+      if (j <= J1 && (i <= I1 || lastx)) {
+        const double fo = fxa[ex_(i, j)], cc = cxt[ex_(i, j)];
+        auto line = [&](int ii) -> Dual { return Dual(qit[ex_(ii, j)], 0.); };
+        const MetX da{c.m.dxa, c, tile, j};
+        const Dual fl = ppm_flux<Dual>(iord, face, i, nx + 1, line, da, Dual(cc, 1.));
+        a.crx.p[at(i, j)] += fl.d * fo;
+        a.mx.p[at(i, j)] += 0.5 * (a.fxo.t[at(i, j)] + a.fx2.t[at(i, j)]) * a.fx.p[at(i, j)];
+        a.fx2.p[at(i, j)] = fo;
+      }
+      if (i <= I1 && (j <= J1 || lasty)) {
+        const double fo = fya[ey_(i, j)], cc = cyt[ey_(i, j)];
+        auto line = [&](int jj) -> Dual { return Dual(qjt[ey_(i, jj)], 0.); };
+        const MetY da{c.m.dya, c, tile, i};
+        const Dual fl = ppm_flux<Dual>(iord, face, j, ny + 1, line, da, Dual(cc, 1.));
+        a.cry.p[at(i, j)] += fl.d * fo;
+        a.my.p[at(i, j)] += 0.5 * (a.fyo.t[at(i, j)] + a.fy2.t[at(i, j)]) * a.fy.p[at(i, j)];
+        a.fy2.p[at(i, j)] = fo;
+      }
+    } }
+  // the stored inner-flux adjoints are zero where the flux assembly does not reach: fx2 on the halo rows, fy2 on the halo columns
+  if (firsty || lasty) {
+    constexpr int w = TPF_W + 1, n = w * 6;
+    TPF_LOOP(e, n) {
+      const int i = I0 + e % w, r = e / w;
+      if (i > I1 + 1 || !(i <= I1 || lastx)) continue;
+      if (firsty && r < 3) a.fx2.p[at(i, r - 2)] = 0.;             // rows -2 .. 0
+      if (lasty && r >= 3) a.fx2.p[at(i, ny + r - 2)] = 0.;        // rows ny+1 .. ny+3
+    } }
+  if (firstx || lastx) {
+    constexpr int n = 6 * (TPF_H + 1);
+    TPF_LOOP(e, n) {
+      const int r = e % 6, j = J0 + e / 6;
+      if (j > J1 + 1 || !(j <= J1 || lasty)) continue;
+      if (firstx && r < 3) a.fy2.p[at(r - 2, j)] = 0.;
+      if (lastx && r >= 3) a.fy2.p[at(nx + r - 2, j)] = 0.;
+    } }
+  // ---- transposed outer sweeps: q_i_ad on the halo'd columns, q_j_ad on the halo'd rows (stored)
+  { constexpr int n = TPA_NA;
+    TPF_LOOP(e, n) {
+      const int i = I0 - 3 + e % TPA_AW, j = J0 + e / TPA_AW;
+      if (i > I1 + 3 || j > J1) continue;
+      if (!((i >= I0 && i <= I1) || (firstx && i < I0) || (lastx && i > I1))) continue;
+      const MetX da{c.m.dxa, c, tile, j};
+      double s = 0.;
+#pragma unroll
+      for (int m = i - 2; m <= i + 3; ++m) {
+        if (m < 1 || m > nx + 1 || m < I0 - 3 || m > I1 + 3) continue;
+        const double f = fxa[ex_(m, j)];
+        if (f != 0.) s += ppm_dq(iord, face, m, nx + 1, i, da, cxt[ex_(m, j)]) * f;
+      }
+      a.q_i.p[at(i, j)] = s;
+    } }
+  { constexpr int n = TPA_NC;
+    TPF_LOOP(e, n) {
+      const int i = I0 + e % TPF_W, j = J0 - 3 + e / TPF_W;
+      if (i > I1 || j > J1 + 3) continue;
+      if (!((j >= J0 && j <= J1) || (firsty && j < J0) || (lasty && j > J1))) continue;
+      const MetY da{c.m.dya, c, tile, i};
+      double s = 0.;
+#pragma unroll
+      for (int m = j - 2; m <= j + 3; ++m) {
+        if (m < 1 || m > ny + 1 || m < J0 - 3 || m > J1 + 3) continue;
+        const double f = fya[ey_(i, m)];
+        if (f != 0.) s += ppm_dq(iord, face, m, ny + 1, j, da, cyt[ey_(i, m)]) * f;
+      }
+      a.q_j.p[at(i, j)] = s;
+    } }
+}
+
+#ifndef FV3LM_HOST_EMUL
+__global__ void __launch_bounds__(TPA_THREADS) k_tp_outer_ad(TpFusedArgs a, Ctx c) {
+  extern __shared__ double tpa_lds[];
+  int bx = blockIdx.x, by = blockIdx.y; xcd_block(gridDim.x, gridDim.y, bx, by);
+  tp_outer_ad_block<TPA_THREADS>(a, c, blockIdx.z / a.nk, 1 + blockIdx.z % a.nk, bx, by, tpa_lds, threadIdx.x, TPA_THREADS);
+}
+#endif
+
+inline void run_tp_outer_ad(Exec& ex, const TpFusedArgs& a0, const Ctx& c) {
+  TpFusedArgs a = a0;
+  for (Fld* f : {&a.q, &a.crx, &a.cry, &a.xfx, &a.yfx, &a.rax, &a.ray, &a.mx, &a.my, &a.mass, &a.d2b, &a.fx, &a.fy, &a.fy2, &a.q_i, &a.fxo, &a.fx2, &a.q_j, &a.fyo}) *f = ex.sh(*f);
+  int nbx, nby; tpf_grid(c.g, nbx, nby);
+  // algorithmic bytes: trajectory q_i, q_j, crx, cry, mx, my, fxo, fx2, fyo, fy2 and the adjoints fx, fy read; q_i, q_j, fx2, fy2 adjoints written;
+  // crx, cry, mx, my adjoints read-modify-written
+  const double cells = double(c.g.nx) * c.g.ny * c.g.ntile * a.nk;
+  ex.mark_begin("TpOuter", ".ad", 8. * cells * (10. + 2. + 4. + 8.));
+#ifdef FV3LM_HOST_EMUL
+  std::vector<double> lds((size_t)TPA_NT);
+  for (int z = 0; z < c.g.ntile * a.nk; ++z)
+    for (int by = 0; by < nby; ++by)
+      for (int bx = 0; bx < nbx; ++bx) tp_outer_ad_block<1>(a, c, z / a.nk, 1 + z % a.nk, bx, by, lds.data(), 0, 1);
+#else
+  hipLaunchKernelGGL(k_tp_outer_ad, dim3(nbx, nby, c.g.ntile * a.nk), dim3(TPA_THREADS), TPA_NT * 8, ex.stream, a, c);
+#endif
+  ex.mark_end();
+  ex.launches++;
+}
+
+// =====================================================================================================================
 // Marching form of the same routine.  One wavefront owns a strip of MW output columns (lane l <-> column I0 - 3 + l, three
 // halo columns on either side) and walks down the rows of its chunk.  Every input row is read from HBM exactly once per strip, as
 // one coalesced row piece; the y-direction stencils live in per-lane register windows (the last six rows of q and of q_j), the

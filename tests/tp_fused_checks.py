@@ -55,8 +55,11 @@ def check_fused_equals_staged(make_case, rtol=0.0):
     worst = 0.0
     for key in a:
         assert np.isfinite(a[key]).all() and np.abs(a[key]).max() > 0, key
-        if rtol == 0.0:
+        if rtol == 0.0 and key[0] != "ad":
             assert np.array_equal(a[key], b[key]), key
+        elif rtol == 0.0:       # the fused outer adjoint sums in another order than the staged gather: rounding, not bits
+            e = float(np.max(np.abs(a[key] - b[key])) / np.max(np.abs(b[key])))
+            assert e <= 1e-13, (key, e)
         else:
             e = float(np.max(np.abs(a[key] - b[key])) / np.max(np.abs(b[key])))
             assert e <= rtol, (key, e)
