@@ -112,8 +112,8 @@ HD void map_col_ad_iv(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, con
                       const MapAdSlots& S, double qs, double* qs_ad) {
   // ---- forward replay with storage
   const double dp1_1 = pe1(2) - pe1(1), dp1_2 = pe1(3) - pe1(2);
-  const double grat = dp1_2 / dp1_1, bet1 = grat * (grat + 0.5);
-  if (IV == -2) {
+  static_assert(IV == -2, "the general profile has the streaming form below (map_col_ad_s)");
+  {
     double qf = 1.5 * q1(1), dp_prev = dp1_1;
     ws.at(S.SF, 1) = qf; ws.at(S.SG, 2) = 0.5;
     for (int k = 2; k <= km - 1; ++k) {
@@ -128,23 +128,6 @@ HD void map_col_ad_iv(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, con
     double qe = qf;
     ws.at(S.SE, km + 1) = qs; ws.at(S.SE, km) = qe;
     for (int k = km - 1; k >= 1; --k) { qe = ws.at(S.SF, k) - ws.at(S.SG, k + 1) * qe; ws.at(S.SE, k) = qe; }
-  } else {
-    double qf = ((grat + grat) * (grat + 1.) * q1(1) + q1(2)) / bet1, gam = (1. + grat * (grat + 1.5)) / bet1;
-    ws.at(S.SF, 1) = qf; ws.at(S.SG, 1) = gam; ws.at(S.SD, 1) = grat;
-    double d4 = grat, a_prev = q1(1), dp_prev = dp1_1;
-    for (int k = 2; k <= km; ++k) {
-      const double dpk = pe1(k + 1) - pe1(k), ak_ = q1(k);
-      d4 = dp_prev / dpk;
-      const double bet = 2. + d4 + d4 - gam;
-      qf = (3. * (a_prev + d4 * ak_) - qf) / bet;
-      gam = d4 / bet;
-      ws.at(S.SF, k) = qf; ws.at(S.SG, k) = gam; ws.at(S.SD, k) = d4;      // bet is recomputed on the way back
-      a_prev = ak_; dp_prev = dpk;
-    }
-    const double a_bot = 1. + d4 * (d4 + 1.5), den = d4 * (d4 + 0.5) - a_bot * gam;
-    double qe = (2. * d4 * (d4 + 1.) * q1(km) + q1(km - 1) - a_bot * qf) / den;
-    ws.at(S.SF, km + 1) = qe; ws.at(S.SE, km + 1) = qe;
-    for (int k = km; k >= 1; --k) { qe = ws.at(S.SF, k) - ws.at(S.SG, k) * qe; ws.at(S.SE, k) = qe; }
   }
   // accumulated by the mapping loop; SFA / SGA are written before they are read, the sweeps below carry their recurrences in registers
   for (int k = 0; k <= km + 1; ++k) { ws.at(S.SDP, k) = 0.; ws.at(S.SEA, k) = 0.; }
@@ -214,7 +197,7 @@ HD void map_col_ad_iv(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, con
     p2k += pl_ad / dpl; ws.at(S.SP1, l) -= pl_ad / dpl; ws.at(S.SDP, l) -= pl * pl_ad / dpl;
   }
   ws.at(S.SP2, km) += p2k; ws.at(S.SP2, km + 1) += p2k1;
-  if (IV == -2) {
+  {
     // reverse of  q(k) = qf(k) - gam(k+1) q(k+1), k = km-1..1 ;  q(km) = qf(km) ;  q(km+1) = qs
     double carry = 0.;
     for (int k = 1; k <= km - 1; ++k) {
@@ -243,71 +226,191 @@ HD void map_col_ad_iv(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, con
     }
     ws.at(S.SQ1, 1) += 1.5 * sfa;
     if (qs_ad) *qs_ad += a_qs;
-  } else {
-  // ---- reverse of the back substitution  qe(k) = qf(k) - gam(k) qe(k+1), k = km..1
-  double fa_bot;
-  {
-    double carry = 0.;     // pending update of qe_ad(k) from level k-1
-    for (int k = 1; k <= km; ++k) {
-      const double e = ws.at(S.SEA, k) + carry;
-      ws.at(S.SFA, k) = e;
-      ws.at(S.SGA, k) = -ws.at(S.SE, k + 1) * e;
-      carry = -ws.at(S.SG, k) * e;
-    }
-    fa_bot = ws.at(S.SEA, km + 1) + carry;     // adjoint of qf(km+1)
-  }
-  // ---- bottom edge value, then the reverse of the forward elimination k = km..2 with qf_ad, gam_ad and the pending
-  //      contributions to q1_ad / dp1_ad of the level above carried in registers
-  double sfa, sga, sda, qpk, qpkm1, dpend = 0.;
-  {
-    const double d = ws.at(S.SD, km), gamk = ws.at(S.SG, km), qfk = ws.at(S.SF, km);
-    const double a_bot = 1. + d * (d + 1.5), den = d * (d + 0.5) - a_bot * gamk;
-    const double numb_ad = fa_bot / den, den_ad = -ws.at(S.SF, km + 1) * fa_bot / den;
-    double d_ad = 2. * (2. * d + 1.) * q1(km) * numb_ad + (2. * d + 0.5) * den_ad;
-    qpk = 2. * d * (d + 1.) * numb_ad; qpkm1 = numb_ad;
-    const double abot_ad = -qfk * numb_ad - gamk * den_ad;
-    sfa = ws.at(S.SFA, km) - a_bot * numb_ad;
-    sga = ws.at(S.SGA, km) - a_bot * den_ad;
-    d_ad += (2. * d + 1.5) * abot_ad;
-    sda = d_ad;
-  }
-  double gam_k = ws.at(S.SG, km);
-  for (int k = km; k >= 2; --k) {
-    const double gam = gam_k, gam_km1 = ws.at(S.SG, k - 1), qf = ws.at(S.SF, k), d4 = ws.at(S.SD, k);
-    const double bet = 2. + d4 + d4 - gam_km1;
-    gam_k = gam_km1;
-    double d4_ad = sda + sga / bet;
-    double bet_ad = -gam * sga / bet;
-    const double t = sfa / bet;
-    ws.at(S.SQ1, k) += qpk + 3. * d4 * t;
-    qpk = qpkm1 + 3. * t; qpkm1 = 0.;
-    d4_ad += 3. * q1(k) * t;
-    bet_ad -= qf * t;
-    d4_ad += 2. * bet_ad;
-    sfa = ws.at(S.SFA, k - 1) - t;
-    sga = ws.at(S.SGA, k - 1) - bet_ad;
-    sda = 0.;
-    const double dpk = pe1(k + 1) - pe1(k);
-    ws.at(S.SDP, k) += dpend - d4 * d4_ad / dpk;
-    dpend = d4_ad / dpk;
-  }
-  {
-    const double gam1 = ws.at(S.SG, 1), qf1 = ws.at(S.SF, 1);
-    double grat_ad = (2. * grat + 1.5) / bet1 * sga;
-    double bet_ad = -gam1 * sga / bet1;
-    const double t = sfa / bet1;
-    bet_ad -= qf1 * t;
-    grat_ad += 2. * (2. * grat + 1.) * q1(1) * t;
-    ws.at(S.SQ1, 1) += qpk + 2. * grat * (grat + 1.) * t; ws.at(S.SQ1, 2) += t;
-    grat_ad += (2. * grat + 0.5) * bet_ad;
-    ws.at(S.SDP, 2) += grat_ad / dp1_1; ws.at(S.SDP, 1) += dpend - grat * grat_ad / dp1_1;
-  }
   }
   for (int k = 1; k <= km; ++k) { const double a = ws.at(S.SDP, k); ws.at(S.SP1, k + 1) += a; ws.at(S.SP1, k) -= a; }
 }
+// ---------------------------------------------------------------- adjoint column map, streaming form (iv != -2)
+// Four sweeps, every work vector written once and read once per sweep that needs it, nothing read-modify-written:
+//   A  top-down    forward elimination                      -> SF (qf), SG (gam)
+//   B  bottom-up   back substitution                        -> SE (edge values)
+//   C  top-down    reverse of the mapping loop FUSED with the reverse of the back substitution.  Targets are visited in
+//                  order and their source layers l .. m never move up, so the adjoint accumulators of the one source level
+//                  still open (q1_ad, dp1_ad, pe1_ad and the two edge-value adjoints) sit in registers; a level is closed
+//                  when the search moves past it: its edge-value adjoint then enters the back-substitution recurrence
+//                  (-> SFA, SGA) and its partial q1_ad / pe1_ad are stored (-> SQ, SP).  pe2_ad leaves through p2out.
+//   D  bottom-up   reverse of the forward elimination (d4 = dp(k-1) / dp(k) recomputed from pe1), final q1_ad, pe1_ad
+//                  through q1out / p1out, once per level.
+// SQ / SP may be the very vectors q1out / p1out store to.
+struct MapAdWs { int SG, SF, SE, SFA, SGA, SQ, SP; };
+template <class FP1, class FQ1, class FP2, class FAd, class OQ1, class OP1, class OP2>
+HD void map_col_ad_s(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const FAd& q2_ad, const ColWs& ws, const MapAdWs& S,
+                     const OQ1& q1out, const OP1& p1out, const OP2& p2out) {
+  const double dp1_1 = pe1(2) - pe1(1), dp1_2 = pe1(3) - pe1(2);
+  const double grat = dp1_2 / dp1_1, bet1 = grat * (grat + 0.5);
+  double qbot;
+  {   // ---- A
+    double qf = ((grat + grat) * (grat + 1.) * q1(1) + q1(2)) / bet1, gam = (1. + grat * (grat + 1.5)) / bet1;
+    ws.at(S.SF, 1) = qf; ws.at(S.SG, 1) = gam;
+    double d4 = grat, a_prev = q1(1), dp_prev = dp1_1;
+    for (int k = 2; k <= km; ++k) {
+      const double dpk = pe1(k + 1) - pe1(k), ak_ = q1(k);
+      d4 = dp_prev / dpk;
+      const double bet = 2. + d4 + d4 - gam;
+      qf = (3. * (a_prev + d4 * ak_) - qf) / bet;
+      gam = d4 / bet;
+      ws.at(S.SF, k) = qf; ws.at(S.SG, k) = gam;
+      a_prev = ak_; dp_prev = dpk;
+    }
+    const double a_bot = 1. + d4 * (d4 + 1.5), den = d4 * (d4 + 0.5) - a_bot * gam;
+    qbot = (2. * d4 * (d4 + 1.) * q1(km) + q1(km - 1) - a_bot * qf) / den;
+  }
+  {   // ---- B
+    double qe = qbot;
+    ws.at(S.SE, km + 1) = qe;
+    for (int k = km; k >= 1; --k) { qe = ws.at(S.SF, k) - ws.at(S.SG, k) * qe; ws.at(S.SE, k) = qe; }
+  }
+  double fa_bot;
+  {   // ---- C
+    int b = 1;                                          // the open source level
+    double aQ = 0., aD = 0., aP = 0., aPn = 0., aE = 0., aEn = 0.;   // q1_ad(b), dp1_ad(b), pe1_ad(b), pe1_ad(b+1), qe_ad(b), qe_ad(b+1)
+    double ecarry = 0., dprev = 0.;                     // back-substitution carry into qe_ad(b); dp1_ad(b-1)
+    // close levels b .. nb-1; the levels strictly between lo and hi lie wholly inside the current target (weight qsa)
+    auto close_to = [&](int nb, int lo, int hi, double qsa) {
+      while (b < nb) {
+        const double e = aE + ecarry;
+        ws.at(S.SFA, b) = e; ws.at(S.SGA, b) = -ws.at(S.SE, b + 1) * e; ecarry = -ws.at(S.SG, b) * e;
+        ws.at(S.SQ, b) = aQ; ws.at(S.SP, b) = aP - aD + dprev; dprev = aD;
+        ++b;
+        const bool in = b > lo && b < hi;
+        aQ = in ? (pe1(b + 1) - pe1(b)) * qsa : 0.; aD = in ? q1(b) * qsa : 0.;
+        aP = aPn; aE = aEn; aPn = 0.; aEn = 0.;
+      }
+    };
+    auto addq = [&](double a2_ad, double a3_ad, double a4_ad) {   // a4 = 3 (2 a1 - a2 - a3) of the open level
+      aQ += 6. * a4_ad; aE += a2_ad - 3. * a4_ad; aEn += a3_ad - 3. * a4_ad;
+    };
+    double p2k = 0., p2k1 = 0.;      // pending pe2_ad(k), pe2_ad(k+1)
+    for (int k = 1; k <= km; ++k) {
+      if (k > 1) p2out(k - 1, p2k);
+      p2k = p2k1; p2k1 = 0.;
+      const double g = q2_ad(k);
+      const double p2t = pe2(k), p2b = pe2(k + 1);
+      int l; bool found = false;
+      for (l = b; l <= km; ++l)
+        if (p2t >= pe1(l) && p2t <= pe1(l + 1)) { found = true; break; }
+      if (!found) continue;   // (stale-qsum path of the reference: never taken for ordered pressures)
+      close_to(l, 0, 0, 0.);
+      const double p1l = pe1(l), p1r = pe1(l + 1), dpl = p1r - p1l;
+      const double a1 = q1(l), a2 = ws.at(S.SE, l), a3 = ws.at(S.SE, l + 1), a4 = 3. * (2. * a1 - (a2 + a3)), Sm = a4 + a3 - a2;
+      const double pl = (p2t - p1l) / dpl;
+      if (p2b <= p1r) {
+        const double pr = (p2b - p1l) / dpl, s = pr + pl, w = pr * s + pl * pl;
+        addq((1. - 0.5 * s) * g, 0.5 * s * g, (0.5 * s - R3 * w) * g);
+        const double pr_ad = (0.5 * Sm - a4 * R3 * (2. * pr + pl)) * g, pl_ad = (0.5 * Sm - a4 * R3 * (pr + 2. * pl)) * g;
+        p2k1 += pr_ad / dpl; aP -= pr_ad / dpl; aD -= pr * pr_ad / dpl;
+        p2k += pl_ad / dpl; aP -= pl_ad / dpl; aD -= pl * pl_ad / dpl;
+        continue;
+      }
+      const double D = p2b - p2t;
+      const double E = a2 + 0.5 * Sm * (1. + pl) - a4 * (R3 * (1. + pl * (1. + pl)));
+      double qsum = (p1r - p2t) * E;
+      int m; bool bottom = false;
+      for (m = l + 1; m <= km; ++m) {
+        if (p2b > pe1(m + 1)) qsum += (pe1(m + 1) - pe1(m)) * q1(m);
+        else { bottom = true; break; }
+      }
+      double dp = 0., esl = 0., Fm = 0., b2 = 0., b3 = 0., b4 = 0., dpm = 1.;
+      if (bottom) {
+        const double p1m = pe1(m); dpm = pe1(m + 1) - p1m;
+        const double b1 = q1(m); b2 = ws.at(S.SE, m); b3 = ws.at(S.SE, m + 1); b4 = 3. * (2. * b1 - (b2 + b3));
+        dp = p2b - p1m; esl = dp / dpm;
+        Fm = b2 + 0.5 * esl * (b3 - b2 + b4 * (1. - R23 * esl));
+        qsum += dp * Fm;
+      }
+      const double q2v = qsum / D, qs_ad = g / D, D_ad = -q2v * g / D;
+      p2k1 += D_ad; p2k -= D_ad;
+      const double W_ad = E * qs_ad, E_ad = (p1r - p2t) * qs_ad;
+      aPn += W_ad; p2k -= W_ad;
+      addq((1. - 0.5 * (1. + pl)) * E_ad, 0.5 * (1. + pl) * E_ad, (0.5 * (1. + pl) - R3 * (1. + pl * (1. + pl))) * E_ad);
+      const double pl_ad = (0.5 * Sm - a4 * R3 * (1. + 2. * pl)) * E_ad;
+      p2k += pl_ad / dpl; aP -= pl_ad / dpl; aD -= pl * pl_ad / dpl;
+      if (bottom) {
+        close_to(m, l, m, qs_ad);
+        double dp_ad = Fm * qs_ad;
+        const double F_ad = dp * qs_ad;
+        addq((1. - 0.5 * esl) * F_ad, 0.5 * esl * F_ad, 0.5 * esl * (1. - R23 * esl) * F_ad);
+        const double esl_ad = (0.5 * (b3 - b2 + b4 * (1. - R23 * esl)) - 0.5 * esl * b4 * R23) * F_ad;
+        dp_ad += esl_ad / dpm; aD -= esl * esl_ad / dpm;
+        p2k1 += dp_ad; aP -= dp_ad;
+      } else {
+        close_to(km + 1, l, km + 1, qs_ad);     // the target reaches below the last source layer: nothing further is found
+      }
+    }
+    p2out(km, p2k); p2out(km + 1, p2k1);
+    close_to(km + 1, 0, 0, 0.);
+    fa_bot = aE + ecarry;                   // adjoint of the bottom edge value
+    ws.at(S.SP, km + 1) = aP + dprev;
+  }
+  {   // ---- D
+    double dpk = pe1(km + 1) - pe1(km), dpm1 = pe1(km) - pe1(km - 1);
+    double d4 = dpm1 / dpk, gam_k = ws.at(S.SG, km);
+    double sfa, sga, sda, qpk, qpkm1, dpend = 0., dnext = 0., q2hold = 0., d2loop = 0.;
+    {
+      const double d = d4, qfk = ws.at(S.SF, km);
+      const double a_bot = 1. + d * (d + 1.5), den = d * (d + 0.5) - a_bot * gam_k;
+      const double numb_ad = fa_bot / den, den_ad = -qbot * fa_bot / den;
+      double d_ad = 2. * (2. * d + 1.) * q1(km) * numb_ad + (2. * d + 0.5) * den_ad;
+      qpk = 2. * d * (d + 1.) * numb_ad; qpkm1 = numb_ad;
+      const double abot_ad = -qfk * numb_ad - gam_k * den_ad;
+      sfa = ws.at(S.SFA, km) - a_bot * numb_ad;
+      sga = ws.at(S.SGA, km) - a_bot * den_ad;
+      d_ad += (2. * d + 1.5) * abot_ad;
+      sda = d_ad;
+    }
+    for (int k = km; k >= 2; --k) {
+      const double gam = gam_k, gam_km1 = ws.at(S.SG, k - 1), qf = ws.at(S.SF, k);
+      const double bet = 2. + d4 + d4 - gam_km1;
+      gam_k = gam_km1;
+      double d4_ad = sda + sga / bet;
+      double bet_ad = -gam * sga / bet;
+      const double t = sfa / bet;
+      const double qk = ws.at(S.SQ, k) + qpk + 3. * d4 * t;
+      if (k > 2) q1out(k, qk); else q2hold = qk;
+      qpk = qpkm1 + 3. * t; qpkm1 = 0.;
+      d4_ad += 3. * q1(k) * t;
+      bet_ad -= qf * t;
+      d4_ad += 2. * bet_ad;
+      sfa = ws.at(S.SFA, k - 1) - t;
+      sga = ws.at(S.SGA, k - 1) - bet_ad;
+      sda = 0.;
+      const double dk = dpend - d4 * d4_ad / dpk;       // dp1_ad(k) of this sweep
+      dpend = d4_ad / dpk;
+      if (k > 2) { p1out(k + 1, ws.at(S.SP, k + 1) + dk - dnext); dnext = dk; } else d2loop = dk;
+      dpk = dpm1;
+      if (k > 2) { dpm1 = pe1(k - 1) - pe1(k - 2); d4 = dpm1 / dpk; }
+    }
+    {
+      const double gam1 = gam_k, qf1 = ws.at(S.SF, 1);
+      double grat_ad = (2. * grat + 1.5) / bet1 * sga;
+      double bet_ad = -gam1 * sga / bet1;
+      const double t = sfa / bet1;
+      bet_ad -= qf1 * t;
+      grat_ad += 2. * (2. * grat + 1.) * q1(1) * t;
+      q1out(2, q2hold + t);
+      q1out(1, ws.at(S.SQ, 1) + qpk + 2. * grat * (grat + 1.) * t);
+      grat_ad += (2. * grat + 0.5) * bet_ad;
+      const double d2 = d2loop + grat_ad / dp1_1, d1 = dpend - grat * grat_ad / dp1_1;
+      p1out(3, ws.at(S.SP, 3) + d2 - dnext);
+      p1out(2, ws.at(S.SP, 2) + d1 - d2);
+      p1out(1, ws.at(S.SP, 1) - d1);
+    }
+  }
+}
+// accumulating interface on the slots of MapAdSlots (non-hydrostatic remap, nh.h): SP1, SQ1, SP2 receive +=
 template <class FP1, class FQ1, class FP2, class FAd>
 HD void map_col_ad(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const FAd& q2_ad, const ColWs& ws, const MapAdSlots& S) {
-  map_col_ad_iv<1>(km, pe1, q1, pe2, q2_ad, ws, S, 0., nullptr);
+  map_col_ad_s(km, pe1, q1, pe2, q2_ad, ws, MapAdWs{S.SG, S.SF, S.SE, S.SFA, S.SGA, S.SEA, S.SDP},
+               [&](int k, double x) { ws.at(S.SQ1, k) += x; }, [&](int k, double x) { ws.at(S.SP1, k) += x; }, [&](int k, double x) { ws.at(S.SP2, k) += x; });
 }
 
 // ---------------------------------------------------------------- kernels
@@ -419,14 +522,13 @@ HD void remap_wind_col_ad(const RemapArgs& a, int dir, int i, int j, int tile, s
   auto pe3 = [&](int k) -> double { return (dir == 1 && k == 1) ? a.ak[0] : a.ak[k - 1] + (0.5 * a.bk[k - 1]) * pss; };
   auto q1 = [&](int k) { return wf.t[fidx(g, wf, tile, i, j, k)]; };
   auto q2ad = [&](int k) { return wf.p[fidx(g, wf, tile, i, j, k)]; };
-  const MapAdSlots S{0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12};
-  for (int k = 0; k <= km + 1; ++k) { ws.at(S.SP1, k) = 0.; ws.at(S.SQ1, k) = 0.; ws.at(S.SP2, k) = 0.; }
-  map_col_ad(km, pe0, q1, pe3, q2ad, ws, S);
   double pss_ad = 0.;
-  for (int k = 1; k <= km + 1; ++k) if (!(dir == 1 && k == 1)) pss_ad += 0.5 * a.bk[k - 1] * ws.at(S.SP2, k);
-  for (int k = 1; k <= km; ++k) wf.p[fidx(g, wf, tile, i, j, k)] = ws.at(S.SQ1, k);
-  // hand-over: level k (1..km+1) = d/d pe0(k); the ps-sum adjoint is folded into level km+1 of both neighbours
-  for (int k = 1; k <= km + 1; ++k) ho.p[fidx(g, ho, tile, i, j, k)] = ws.at(S.SP1, k);
+  // the adjoint of the input wind replaces wf.p; hand-over: level k (1..km+1) = d/d pe0(k); the ps-sum adjoint is folded into
+  // level km+1 of both neighbours
+  map_col_ad_s(km, pe0, q1, pe3, q2ad, ws, MapAdWs{0, 1, 2, 3, 4, 5, 6},
+               [&](int k, double x) { wf.p[fidx(g, wf, tile, i, j, k)] = x; },
+               [&](int k, double x) { ho.p[fidx(g, ho, tile, i, j, k)] = x; },
+               [&](int k, double x) { if (!(dir == 1 && k == 1)) pss_ad += 0.5 * a.bk[k - 1] * x; });
   ho.t[fidx(g, ho, tile, i, j, 1)] = pss_ad;   // stored in the (otherwise unused) trajectory side, level 1
 }
 
@@ -464,9 +566,11 @@ HD void remap_pe_gather_ad(const RemapArgs& a, int i, int j, int tile) {
 //   k1, per column:          trajectory of the remapped T_v and q_v, final conversion, pkz / pk / peln / delp adjoints
 //   k2, per (column, field): adjoint of one column map (field 0: T_v in log p; field n: tracer n in p), own workspace slots
 //   k3, per column:          sums the pressure adjoints of all maps, T_v -> pt, pk2 / pn2 chain, write-back
-// Workspace slots: 0..21 shared accumulators (as named below), 22 + 13 f .. for the map of field f.
-struct RemapAdSlots { static constexpr int SPE1 = 13, SPN1 = 14, SPK1 = 15, SPE2 = 16, SPN2 = 17, SPK2 = 18, ST2 = 19, SQ2 = 20, SV = 21, FBASE = 22, FN = 13; };
-HD MapAdSlots remap_field_slots(int f) { const int b = RemapAdSlots::FBASE + RemapAdSlots::FN * f; return MapAdSlots{b, b + 1, b + 2, b + 3, b + 4, b + 5, b + 6, b + 7, b + 8, b + 9, b + 10, b + 11, b + 12}; }
+// Workspace slots: 0..21 shared accumulators (as named below), 22 + 8 f .. for the map of field f: its pe1_ad, q1_ad (T map only),
+// pe2_ad outputs and the five work vectors of map_col_ad_s (whose SP / SQ streams share the output vectors).
+struct RemapAdSlots { static constexpr int SPE1 = 13, SPN1 = 14, SPK1 = 15, SPE2 = 16, SPN2 = 17, SPK2 = 18, ST2 = 19, SQ2 = 20, SV = 21, FBASE = 22, FN = 8; };
+struct FieldAdSlots { int SP1, SQ1, SP2; MapAdWs w; };
+HD FieldAdSlots remap_field_slots(int f) { const int b = RemapAdSlots::FBASE + RemapAdSlots::FN * f; return FieldAdSlots{b, b + 1, b + 2, MapAdWs{b + 3, b + 4, b + 5, b + 6, b + 7, b + 1, b}}; }
 
 HD void remap_ad_k1(const RemapArgs& a, int i, int j, int tile, size_t col) {
   const Geom& g = a.g; const int km = g.npz;
@@ -525,24 +629,24 @@ HD void remap_ad_k1(const RemapArgs& a, int i, int j, int tile, size_t col) {
 HD void remap_ad_k2(const RemapArgs& a, int field, int i, int j, int tile, size_t col) {
   const Geom& g = a.g; const int km = g.npz;
   const ColWs ws{a.ws + col, a.ws_stride, km + 2};
-  const MapAdSlots S = remap_field_slots(field);
+  const FieldAdSlots S = remap_field_slots(field);
   auto pe1 = [&](int k) { return a.pe.t[fidx(g, a.pe, tile, i, j, k)]; };
   const double ps = pe1(km + 1);
   auto pe2 = [&](int k) -> double { return k == 1 ? a.ptop : (k == km + 1 ? ps : a.ak[k - 1] + a.bk[k - 1] * ps); };
-  for (int k = 0; k <= km + 1; ++k) { ws.at(S.SP1, k) = 0.; ws.at(S.SQ1, k) = 0.; ws.at(S.SP2, k) = 0.; }
+  auto p1out = [&](int k, double x) { ws.at(S.SP1, k) = x; };
+  auto p2out = [&](int k, double x) { ws.at(S.SP2, k) = x; };
   if (field == 0) {   // T map (coordinates pn1 -> pn2)
     auto pn1 = [&](int k) { return a.peln.t[fidx(g, a.peln, tile, i, j, k)]; };
     auto pk1 = [&](int k) { return a.pk.t[fidx(g, a.pk, tile, i, j, k)]; };
     auto pn2 = [&](int k) -> double { return (k == 1 || k == km + 1) ? pn1(k) : log(pe2(k)); };
     auto tv = [&](int k) -> double { return a.pt.t[fidx(g, a.pt, tile, i, j, k)] * (pk1(k + 1) - pk1(k)) / (a.akap * (pn1(k + 1) - pn1(k))); };
     auto q2ad = [&](int k) { return ws.at(RemapAdSlots::SV, k); };
-    map_col_ad(km, pn1, tv, pn2, q2ad, ws, S);
+    map_col_ad_s(km, pn1, tv, pn2, q2ad, ws, S.w, [&](int k, double x) { ws.at(S.SQ1, k) = x; }, p1out, p2out);
   } else {            // tracer map (coordinates pe1 -> pe2)
     const Fld& qf = a.q[field - 1];
     auto q1 = [&](int k) { return qf.t[fidx(g, qf, tile, i, j, k)]; };
     auto q2ad = [&](int k) { return qf.p[fidx(g, qf, tile, i, j, k)]; };
-    map_col_ad(km, pe1, q1, pe2, q2ad, ws, S);
-    for (int k = 1; k <= km; ++k) qf.p[fidx(g, qf, tile, i, j, k)] = ws.at(S.SQ1, k);
+    map_col_ad_s(km, pe1, q1, pe2, q2ad, ws, S.w, [&](int k, double x) { qf.p[fidx(g, qf, tile, i, j, k)] = x; }, p1out, p2out);
   }
 }
 HD void remap_ad_k3(const RemapArgs& a, int i, int j, int tile, size_t col) {
@@ -557,7 +661,7 @@ HD void remap_ad_k3(const RemapArgs& a, int i, int j, int tile, size_t col) {
   auto pn2 = [&](int k) -> double { return (k == 1 || k == km + 1) ? pn1(k) : log(pe2(k)); };
   auto pk2 = [&](int k) -> double { return (k == 1 || k == km + 1) ? pk1(k) : exp(a.akap * pn2(k)); };
   {   // T map: pressure adjoints into the log-p accumulators, T_v(k) = pt * dpk / (akap * dln)
-    const MapAdSlots S = remap_field_slots(0);
+    const FieldAdSlots S = remap_field_slots(0);
     for (int k = 1; k <= km + 1; ++k) { ws.at(R_::SPN1, k) += ws.at(S.SP1, k); ws.at(R_::SPN2, k) += ws.at(S.SP2, k); }
     for (int k = 1; k <= km; ++k) {
       const double tv_ad = ws.at(S.SQ1, k), dpk = pk1(k + 1) - pk1(k), den = a.akap * (pn1(k + 1) - pn1(k)), pt0 = a.pt.t[fidx(g, a.pt, tile, i, j, k)];
@@ -569,7 +673,7 @@ HD void remap_ad_k3(const RemapArgs& a, int i, int j, int tile, size_t col) {
     }
   }
   for (int n = 0; n < a.nq; ++n) {   // tracer maps: pressure adjoints, in tracer order
-    const MapAdSlots S = remap_field_slots(1 + n);
+    const FieldAdSlots S = remap_field_slots(1 + n);
     for (int k = 1; k <= km + 1; ++k) { ws.at(R_::SPE1, k) += ws.at(S.SP1, k); ws.at(R_::SPE2, k) += ws.at(S.SP2, k); }
   }
   // pk2 = exp(akap pn2), pn2 = log pe2 on interior interfaces; end levels pass through to pk1/pn1
@@ -648,7 +752,7 @@ struct RemapPeFn {
   }
 };
 
-// Workspace: 22 shared slots + 13 per scalar field (T and the tracers) of (npz+2) doubles per column, columns = ntile*plane.
+// Workspace: 22 shared slots + 8 per scalar field (T and the tracers) of (npz+2) doubles per column, columns = ntile*plane.
 inline int remap_ws_slots(int nq) { return RemapAdSlots::FBASE + RemapAdSlots::FN * (1 + nq); }
 inline void run_remap(Exec& ex, int mode, const RemapArgs& a) {
   const Geom& g = a.g;
