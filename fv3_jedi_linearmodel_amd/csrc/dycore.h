@@ -56,6 +56,8 @@ inline void dev_sync(Exec& ex) { HIPCHK(hipStreamSynchronize(ex.stream)); }
 // is cleared with a single memset per backward acoustic step.
 struct Arena {
   double* t = nullptr; double* p = nullptr; size_t cap = 0, used = 0;
+  // sizing pass: hands out distinct non-null addresses that are never dereferenced (the program built on them is thrown away)
+  void measure() { cap = (size_t)1 << 56; t = p = (double*)(uintptr_t)4096; used = 0; }
   void init(size_t ndoubles) { cap = ndoubles; t = (double*)dev_alloc(cap * 8); p = (double*)dev_alloc(cap * 8); used = 0; }
   void destroy() { dev_free(t); dev_free(p); t = p = nullptr; }
   Fld take(size_t n, int nk) {
@@ -180,8 +182,9 @@ struct Dycore {
     if (it == F.end()) { set_sticky(std::string("internal error: unknown field ") + n); static Fld none; none = Fld{}; return none; }
     return it->second;
   }
-  Fld S(const char* n, int nk) { Fld x = state.take((size_t)g.ntile * nk * g.plane, nk); F[n] = x; return x; }
-  Fld W(const char* n, int nk) { Fld x = work.take((size_t)g.ntile * nk * g.plane, nk); F[n] = x; return x; }
+  Fld S(const char* n, int nk) { (nk == g.npz ? nS3 : nS3p)++; Fld x = state.take((size_t)g.ntile * nk * g.plane, nk); F[n] = x; return x; }
+  int nW3 = 0, nW3p = 0, nS3 = 0, nS3p = 0;
+  Fld W(const char* n, int nk) { (nk == g.npz ? nW3 : nW3p)++; Fld x = work.take((size_t)g.ntile * nk * g.plane, nk); F[n] = x; return x; }
 
   Rect R(int i0, int i1, int j0, int j1) const { return Rect{i0, i1, j0, j1}; }
   static Rect empty_in(const Rect& r) { return Rect{r.i0 + 1, r.i0, r.j0 + 1, r.j0}; }   // contains nothing, leaves the union with r alone
@@ -597,8 +600,8 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
   if (phis_host) h2d(ex, hs_dev, phis_host, np * 8);
   ctx.g = g; ctx.lev = lev_dev; ctx.nlev = npz;
   n3 = np * npz; n3p = np * (npz + 1);
-  state.init(n3 * (16 + 3 * (size_t)nq + (nh ? 6 + (size_t)nq : 0)) + n3p * (8 + (nh ? 1 : 0)) + np);
-  work.init(n3 * ((g.face ? 120 : 114) + (nh ? 28 : 0)) + n3p * (14 + (nh ? 46 : 0)));
+  // the state arena holds exactly the fields build_acoustic and Dynamics::init2 take (an overflow fails create)
+  state.init(n3 * (12 + (size_t)nq + (nh ? 5 + (size_t)nq : 0)) + n3p * (6 + (nh ? 2 : 0)) + np);
   if (nh) {
     nh_ws = (double*)dev_alloc((size_t)NH_WS_SLOTS * (npz + 2) * np * 8);
     const char* tape_env = std::getenv("FV3LM_NH_TAPE");
@@ -618,6 +621,14 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
     nh_tape.idx = (TapeIdx*)dev_alloc((size_t)nh_tape.cap * nh_tape.stride * sizeof(TapeIdx));
     nh_tape.adj = (double*)dev_alloc((size_t)nh_tape.cap * nh_tape.stride * 8);
     nh_tape.overflow = (int*)dev_alloc(8);
+  }
+  {   // the work arena is sized by a dry run of the builder: which fields exist depends on the options
+    const size_t state_mark = state.used;
+    work.measure();
+    build_acoustic();
+    const size_t need = work.used;
+    acoustic.clear(); n_win = 0; state.used = state_mark; nW3 = nW3p = nS3 = nS3p = 0;
+    work.init(need);
   }
   build_acoustic();
   { std::vector<double*> pre; for (const char* n_ : st_out) pre.push_back(f(n_).p);
@@ -687,7 +698,8 @@ inline bool Dycore::set_exchange_remote(int kind, int npeers, const int* peers, 
 
 // called after every other allocation (Dynamics::init2): take what is left of the HBM, minus a reserve
 inline void Dycore::init_traj_slots() {
-  const size_t slot_bytes = work.cap * 8, extra_bytes = (3 * n3p + n3) * 8;
+  const size_t slot_bytes = work.used * 8, extra_bytes = (3 * n3p + n3) * 8;     // the fields taken, not the arena's capacity
+  if (std::getenv("FV3LM_VERBOSE")) std::fprintf(stderr, "fv3lm: face %d nh %d nq %d: work arena %zu of %zu doubles (%d + %d fields), state %zu of %zu (%d + %d fields)\n", g.face, (int)nh, nq, work.used, work.cap, nW3, nW3p, state.used, state.cap, nS3, nS3p);
   int want = n_split * k_split;
   if (const char* e = std::getenv("FV3LM_TRAJ_SLOTS")) want = std::min(want, std::max(0, std::atoi(e)));
 #ifndef FV3LM_HOST_EMUL

@@ -121,6 +121,7 @@ struct Dynamics : Dycore {
   std::vector<Fld> q;
   Fld dp1, qc, qc_o, pe2, pu_ad, pv_ad;
   double *ak_dev = nullptr, *bk_dev = nullptr, *remap_ws = nullptr, *cmax_dev = nullptr;
+  bool remap_ws_own = false;
   // non-hydrostatic vertical remap (nh.h): column operators into the staging fields, handed back to the state afterwards
   Program remap_nh;
   Fld t_m, w_m, dz_m; std::vector<Fld> q_m;
@@ -198,9 +199,14 @@ inline bool Dynamics::init2(const double* ak, const double* bk) {
   for (int n = 0; n < nq; ++n) { char nm[16]; std::snprintf(nm, sizeof nm, "q%d", n + 1); q.push_back(S(nm, npz)); }
   dp1 = S("dp1", npz); qc = S("qc", npz); qc_o = S("qc_o", npz);
   pe2 = S("pe2", npz + 1); pu_ad = S("pu_ad", npz + 1); pv_ad = S("pv_ad", npz + 1);
-  remap_ws = (double*)dev_alloc((size_t)remap_ws_slots(nq) * (npz + 2) * g.ntile * g.plane * 8);
+  {   // the column workspace of the remap lives in the perturbation side of the acoustic work arena when it fits: every work
+      // array is dead between acoustic steps (each step's first touch of a work tangent / adjoint is a store or a planned clear)
+    const size_t need = (size_t)remap_ws_slots(nq) * (npz + 2) * g.ntile * g.plane;
+    remap_ws_own = need > work.cap;
+    remap_ws = remap_ws_own ? (double*)dev_alloc(need * 8) : work.p;
+  }
   cmax_dev = (double*)dev_alloc((size_t)g.ntile * npz * 8);
-  tshared.init(n3 * 10); twork.init(n3 * 10);
+  tshared.init(n3 * 9);       // build_tracer's nine shared fields; its per-tracer work arena is sized by a dry run
   tr_ksplt_km.assign(k_split, std::vector<int>(npz, 1)); tr_nsplt_km.assign(k_split, 1);
   build_tracer();
   if (nh) {
@@ -220,7 +226,7 @@ inline bool Dynamics::init2(const double* ak, const double* bk) {
 }
 inline void Dynamics::destroy2() {
   dev_free(stage_dev); stage_dev = nullptr;
-  dev_free(ak_dev); dev_free(bk_dev); dev_free(remap_ws); dev_free(cmax_dev); dev_free(ck_k); dev_free(ck_0); dev_free(ck_nh);
+  dev_free(ak_dev); dev_free(bk_dev); if (remap_ws_own) dev_free(remap_ws); dev_free(cmax_dev); dev_free(ck_k); dev_free(ck_0); dev_free(ck_nh);
   tshared.destroy(); twork.destroy();
   for (double* p : snap) dev_free(p);
   for (auto& kv : sub_ck) dev_free(kv.second);
@@ -317,12 +323,17 @@ inline void Dynamics::build_tracer() {
   { TrDp2Ra s; s.in[0] = dp1; s.in[1] = mfxs; s.in[2] = mfys; s.in[3] = xfx; s.in[4] = yfx; s.out[0] = dp2; s.out[1] = rax; s.out[2] = ray;
     s.orect[0] = R(is, ie, js, je); s.orect[1] = R(is, ie, jsd, jed); s.orect[2] = R(isd, ied, js, je); s.k1 = npz; add(tracer_pre, "tracer", s); }
   // per tracer and sub-step, on the staging field qc -> qc_o, work arrays in twork
-  Arena save = work; work = twork;
-  Fld fx = W("tr_fx", npz), fy = W("tr_fy", npz);
-  build_tp(tracer_q, "tracer", "tpq", qc, cxs, cys, xfx, yfx, rax, ray, mfxs, mfys, Fld{}, HORD_TR, DAMP_NONE, false, fx, fy);
-  { TrUpdate s; s.in[0] = qc; s.in[1] = dp1; s.in[2] = dp2; s.in[3] = fx; s.in[4] = fy; s.out[0] = qc_o; s.orect[0] = R(is, ie, js, je); s.k1 = npz;
-    add(tracer_q, "tracer", s); }
-  twork = work; work = save;
+  auto build_q = [&]() {
+    Arena save = work; work = twork;
+    Fld fx = W("tr_fx", npz), fy = W("tr_fy", npz);
+    build_tp(tracer_q, "tracer", "tpq", qc, cxs, cys, xfx, yfx, rax, ray, mfxs, mfys, Fld{}, HORD_TR, DAMP_NONE, false, fx, fy);
+    { TrUpdate s; s.in[0] = qc; s.in[1] = dp1; s.in[2] = dp2; s.in[3] = fx; s.in[4] = fy; s.out[0] = qc_o; s.orect[0] = R(is, ie, js, je); s.k1 = npz;
+      add(tracer_q, "tracer", s); }
+    twork = work; work = save;
+  };
+  twork.measure(); build_q();
+  { const size_t need = twork.used; tracer_q.clear(); twork.init(need); }
+  build_q();
   tracer_zero = plan_adjoint(tracer_q, twork);
 }
 
