@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #ifdef FV3LM_HOST_EMUL
 #define HD inline
@@ -137,8 +138,11 @@ constexpr int NMETRIC = 32 + 18;
 
 // Per-level resolved options (dyn_core_tlm.F90:741-921), device array of npz entries.
 struct LevelParams {
-  int hord_mt, hord_vt, hord_tm, hord_dp, hord_tr;
+  int hord_mt, hord_vt, hord_tm, hord_dp, hord_tr;       // the schemes the tangent / adjoint is taken of (the *_pert flags where they differ)
   int hord_tm_g;            // flagstruct%hord_tm as passed to UPDATE_DZ_D for all npz+1 interfaces (dyn_core_tlm.F90:1091): no sponge override
+  // trajectory schemes (split_hord): where one differs from the scheme above, that transport's VALUES come from a second, values-only
+  // pass with this scheme and the trajectory damping (sw_core_tlm.F90:1664-1682); may be monotone (8, 10)
+  int hord_vt_t, hord_tm_t, hord_dp_t, hord_tr_t, hord_tm_g_t;
   int nord, nord_v, nord_w, nord_t, nord_v_pert;
   double d2_divg, damp_vt, damp_w, damp_t, d_con, damp_vt_pert;
   // tracer_2d sub-cycling of the current call (fv_tracer2d_tlm.F90:1306-1345): sub-steps this level takes and 1/that

@@ -68,8 +68,8 @@ struct Arena {
 
 typedef fv3lm_options Options;   // include/fv3lm.h
 
-// Per-level selection, dyn_core_tlm.F90:741-921.  Returns false on a trajectory/perturbation
-// advection-order split at level k (that recompute path is not built yet).
+// Per-level selection, dyn_core_tlm.F90:741-921.  Returns false on a trajectory/perturbation split of hord_mt at level k
+// (xtp_u / ytp_v with two schemes: not built); the fv_tp_2d transports carry both schemes.
 inline bool resolve_level(const Options& o, int k, int npz, LevelParams& lp) {
   int hord_m = o.hord_mt, hord_t = o.hord_tm, hord_v = o.hord_vt, hord_p = o.hord_dp;
   int nord_k = o.nord, nord_v = (2 > o.nord) ? o.nord : 2;
@@ -117,12 +117,13 @@ inline bool resolve_level(const Options& o, int k, int npz, LevelParams& lp) {
     else d2p = 0.01;
     if (o.do_vort_damp_pert) { nord_v_pert = 0; damp_vt_pert = 0.5 * d2p; }
   }
-  lp.hord_mt = hord_m; lp.hord_vt = hord_v; lp.hord_tm = hord_t; lp.hord_dp = hord_p; lp.hord_tr = o.hord_tr;
-  lp.hord_tm_g = o.hord_tm;
+  lp.hord_mt = hmp; lp.hord_vt = hvp; lp.hord_tm = htp; lp.hord_dp = hpp; lp.hord_tr = o.hord_tr_pert;
+  lp.hord_tm_g = o.hord_tm_pert;
+  lp.hord_vt_t = hord_v; lp.hord_tm_t = hord_t; lp.hord_dp_t = hord_p; lp.hord_tr_t = o.hord_tr; lp.hord_tm_g_t = o.hord_tm;
   lp.nord = nord_k; lp.nord_v = nord_v; lp.nord_w = nord_w; lp.nord_t = nord_t; lp.nord_v_pert = nord_v_pert;
   lp.d2_divg = d2_divg; lp.damp_vt = damp_vt; lp.damp_w = damp_w; lp.damp_t = damp_t; lp.d_con = d_con_k;
   lp.damp_vt_pert = damp_vt_pert;
-  return hord_m == hmp && hord_t == htp && hord_v == hvp && hord_p == hpp;
+  return hord_m == hmp;
 }
 
 struct Op {
@@ -432,16 +433,20 @@ struct Dycore {
     Fld d2b{};
     if (dsel != DAMP_NONE) {
       d2b = W((pre + "_d2b").c_str(), npz);
-      TpD2D h; h.in[0] = q; h.out[0] = d2b; h.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); h.k1 = npz; h.dsel = dsel; h.use_mass = use_mass;
+      TpD2D h; h.in[0] = q; h.out[0] = d2b; h.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); h.k1 = npz; h.dsel = dsel; h.use_mass = use_mass; h.hsel = hsel;
       add_face(P, grp, h, 1);
     }
+    // split_hord: some level runs this transport with a trajectory scheme other than the scheme the tangent / adjoint is taken of
+    bool any_split = false;
+    for (int k = 0; k < npz && k < (int)lev_host.size(); ++k) any_split = any_split || level_split(lev_host[k], hsel);
     TpFlux t; t.in[0] = fxo; t.in[1] = fx2; t.in[2] = mx; t.in[3] = fyo; t.in[4] = fy2; t.in[5] = my;
     t.in[6] = (dsel != DAMP_NONE) ? q : Fld{}; t.in[7] = d2b; t.in[8] = use_mass ? mass : Fld{};
     for (int n = 6; n < 9; ++n) if (!t.in[n].t) t.in[n].nk = npz;
     t.out[0] = fx; t.out[1] = fy; t.orect[0] = R(is, ie + 1, js, je); t.orect[1] = R(is, ie, js, je + 1); t.k1 = npz;
-    t.dsel = dsel; t.use_mass = use_mass;
+    t.dsel = dsel; t.use_mass = use_mass; t.hsel = hsel;
     const size_t o3 = P.size();
     add(P, grp, t);
+    if (any_split && !(fused && !(fenv && fenv[0] == '3'))) set_sticky("split_hord needs the tiled fused fv_tp_2d (unset FV3LM_TP_FUSED)");
     if (fused) {
       size_t d2_op = P.size();      // the damping Laplacian (TpD2) stays a stage of its own in every mode
       for (size_t n = first_op; n < P.size(); ++n) if (P[n].name == "TpD2" || P[n].name == "TpD2e") d2_op = n;
@@ -463,6 +468,23 @@ struct Dycore {
       for (const Fld* f_ : {&a.q, &a.crx, &a.cry, &a.xfx, &a.yfx, &a.rax, &a.ray, &a.mx, &a.my, &a.mass, &a.d2b}) if (f_->p) op.ad_in.push_back(f_->p);
       for (const Fld* f_ : {&a.fx, &a.fy, &a.fy2, &a.q_i, &a.fxo, &a.fx2, &a.q_j, &a.fyo, &a.acx, &a.acy, &a.amfx, &a.amfy}) if (f_->p) op.ad_out.push_back(f_->p);
       P.push_back(op);
+      if (any_split) {       // the trajectory pass of the split levels: its own damping Laplacian (run as a nonlinear launch in the tangent mode too), then the chain
+        if (dsel != DAMP_NONE) {
+          Fld d2t = W((pre + "_d2t").c_str(), npz);
+          TpD2D h; h.in[0] = q; h.out[0] = d2t; h.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); h.k1 = npz; h.dsel = dsel; h.use_mass = use_mass; h.hsel = hsel; h.traj = 1;
+          const size_t n0 = P.size();
+          add_face(P, grp, h, 1);
+          for (size_t n = n0; n < P.size(); ++n) {
+            auto f = P[n].fn;
+            P[n].fn = [f](Exec& e, int) { f(e, MODE_NL); };
+            P[n].modes = (1u << MODE_NL) | (1u << MODE_TL); P[n].ad_in.clear(); P[n].ad_in_slot.clear(); P[n].ad_out.clear(); P[n].ad_out_rect.clear(); P[n].set_wmask = nullptr;
+          }
+          a.d2b_t = d2t;
+        }
+        Op tr{grp, [a, cp](Exec& e, int mode) { run_tp_fused(e, mode, a, *cp, true); }};
+        tr.modes = (1u << MODE_NL) | (1u << MODE_TL); tr.name = "TpFusedTraj";
+        P.push_back(tr);
+      }
       // adjoint: flux assembly + the two outer sweeps as one hand-written launch (tpfused.h tp_outer_ad_block); their staged launches
       // then never run, the damping part of the flux keeps a (small) stage of its own.  FV3LM_TP_AD_FUSED=0: all staged.
       const char* aenv = std::getenv("FV3LM_TP_AD_FUSED");
@@ -474,7 +496,7 @@ struct Dycore {
           TpDamp dm; dm.in[0] = q; dm.in[1] = d2b; dm.in[2] = use_mass ? mass : Fld{};
           for (int n = 1; n < 3; ++n) if (!dm.in[n].t) dm.in[n].nk = npz;
           dm.out[0] = fx; dm.out[1] = fy; dm.orect[0] = R(is, ie + 1, js, je); dm.orect[1] = R(is, ie, js, je + 1); dm.k1 = npz;
-          dm.dsel = dsel; dm.use_mass = use_mass;
+          dm.dsel = dsel; dm.use_mass = use_mass; dm.hsel = hsel;
           add(P, grp, dm); P.back().modes = 1u << MODE_AD;
         }
         Op ad{grp, [a, cp](Exec& e, int) { run_tp_outer_ad(e, a, *cp); }};
@@ -561,15 +583,19 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
     if ((kd < 0 ? -kd : kd) <= 16) { err = "kord_tm/kord_mt/kord_wz/kord_tr: only |kord| > 16 (the linear profile of the TL/AD reference) is built"; return false; }
   //   tracer advection: the perturbation runs with the trajectory scheme (no split_hord recompute); hord_tr_ks_* are read by the
   //   reference's namelist but used nowhere on the path (fv_control_tlmadm.F90:166-172), so they are accepted and ignored here too
-  if (nq_ > 0 && o.hord_tr != o.hord_tr_pert) { err = "trajectory/perturbation hord split (split_hord) not supported: hord_tr != hord_tr_pert"; return false; }
-  if (nh && o.hord_tm != o.hord_tm_pert) { err = "trajectory/perturbation hord split (split_hord) not supported: hord_tm != hord_tm_pert (update_dz_d)"; return false; }
-  if (nh && o.hord_tm != 1 && o.hord_tm != 2 && o.hord_tm != 333) { err = "hord must be 1, 2 or 333 (the schemes the TL/AD reference implements)"; return false; }
+  //   advection schemes: the tangent / adjoint exists for 1, 2, 333 (tp_core_tlm.F90:2393-2487); a trajectory scheme that differs
+  //   (split_hord) gives the values in a second pass and may also be the monotone 8 or 10 -- for the fv_tp_2d transports; the
+  //   momentum fluxes xtp_u / ytp_v (hord_mt) with two schemes are not built
   lev_host.resize(npz + 1);
   for (int k = 1; k <= npz; ++k) {
-    if (!resolve_level(o, k, npz, lev_host[k - 1])) { err = "trajectory/perturbation hord split (split_hord) not supported"; return false; }
+    if (!resolve_level(o, k, npz, lev_host[k - 1])) { err = "trajectory/perturbation hord split (split_hord) of hord_mt (xtp_u / ytp_v) not supported"; return false; }
     const LevelParams& l = lev_host[k - 1];
-    for (int h : {l.hord_mt, l.hord_vt, l.hord_tm, l.hord_dp, l.hord_tr})
-      if (h != 1 && h != 2 && h != 333) { err = "hord must be 1, 2 or 333 (the schemes the TL/AD reference implements)"; return false; }
+    for (int h : {l.hord_mt, l.hord_vt, l.hord_tm, l.hord_dp, l.hord_tr, l.hord_tm_g})
+      if (h != 1 && h != 2 && h != 333) { err = "perturbation hord must be 1, 2 or 333 (the schemes the TL/AD reference implements)"; return false; }
+    for (int h : {l.hord_vt_t, l.hord_tm_t, l.hord_dp_t, l.hord_tr_t, l.hord_tm_g_t})
+      if (h != 1 && h != 2 && h != 333 && h != 8 && h != 10) { err = "trajectory hord must be 1, 2, 333 (differentiated) or, with a different perturbation scheme, 8 or 10"; return false; }
+    const int pairs[5][2] = {{l.hord_vt_t, l.hord_vt}, {l.hord_tm_t, l.hord_tm}, {l.hord_dp_t, l.hord_dp}, {l.hord_tr_t, l.hord_tr}, {l.hord_tm_g_t, l.hord_tm_g}};
+    for (auto& pr : pairs) if (pr[0] == pr[1] && pr[0] != 1 && pr[0] != 2 && pr[0] != 333) { err = "hord must be 1, 2 or 333 where trajectory and perturbation share the scheme"; return false; }
   }
 #ifndef FV3LM_HOST_EMUL
   HIPCHK(hipStreamCreate(&ex.stream));

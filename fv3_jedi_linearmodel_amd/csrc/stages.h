@@ -111,6 +111,71 @@ HD double ppm_dq(int iord, bool face, int m, int n1, int k, const D& da, double 
   return k == m - 1 ? 2. / 6. + 0.5 * c + c2 : k == m ? 5. / 6. - 0.5 * c - 2. * c2 : k == m + 1 ? -1. / 6. + c2 : 0.;
 }
 
+// ---- monotone PPM of the NONLINEAR xppm / yppm, iord 8 and 10 (tp_core_tlm.F90:592-955, :1339-1723; pert_ppm :1853-1915) -- values
+// only: the reference never differentiates them; with split schemes they give the trajectory values of a transport whose tangent
+// / adjoint is taken of the perturbation scheme (sw_core_tlm.F90:1664-1682).  Point-wise form: the slopes bl, br of ONE cell from
+// the cells within three of it, so the flux at interface m reads q(m-3 .. m+2), inside the three-cell halo like the reference.
+constexpr double MONO_R3 = 1. / 3., MONO_S11 = 11. / 14., MONO_S14 = 4. / 7., MONO_S15 = 3. / 14., MONO_NEAR_ZERO = 1.e-25;
+HD double mono_sign(double a, double b) { return b >= 0. ? fabs(a) : -fabs(a); }     // Fortran SIGN(a, b)
+template <class Q>
+HD double mono_dm(const Q& q, int i) {                                                // :596-640
+  const double a = q(i - 1), b = q(i), c_ = q(i + 1), xt = 0.25 * (c_ - a);
+  const double hi = fmax(fmax(a, b), c_) - b, lo = b - fmin(fmin(a, b), c_);
+  return mono_sign(fmin(fmin(fabs(xt), hi), lo), xt);
+}
+template <class Q>
+HD double mono_al(const Q& q, int i) { return 0.5 * (q(i - 1) + q(i)) + MONO_R3 * (mono_dm(q, i - 1) - mono_dm(q, i)); }   // :641-642
+HD void mono_pert_ppm(double& al, double& ar) {                                       // pert_ppm, iv = 1 (:1893-1913)
+  if (al * ar < 0.) {
+    const double da1 = al - ar, da2 = da1 * da1, a6da = 3. * (al + ar) * da1;
+    if (a6da < -da2) ar = -(2. * al);
+    else if (a6da > da2) al = -(2. * ar);
+  } else { al = 0.; ar = 0.; }
+}
+template <class Q, class D>
+HD void mono_blbr(int iord, bool face, int i, int n1, const Q& q, const D& da, double& bl, double& br) {
+  if (face && (i <= 2 || i >= n1 - 2)) {       // the three cells each side of a cube edge (:828-942)
+    auto two_sided = [&](int e) {
+      double xt = 0.5 * (((2. * da(e - 1) + da(e - 2)) * q(e - 1) - da(e - 1) * q(e - 2)) / (da(e - 2) + da(e - 1)) +
+                         ((2. * da(e) + da(e + 1)) * q(e) - da(e) * q(e + 1)) / (da(e) + da(e + 1)));
+      xt = fmax(xt, fmin(fmin(q(e - 2), q(e - 1)), fmin(q(e), q(e + 1))));
+      return fmin(xt, fmax(fmax(q(e - 2), q(e - 1)), fmax(q(e), q(e + 1))));
+    };
+    if (i == 0) { bl = MONO_S14 * mono_dm(q, -1) + MONO_S11 * (q(-1) - q(0)); br = two_sided(1) - q(0); }
+    else if (i == 1) { bl = two_sided(1) - q(1); br = MONO_S15 * q(1) + MONO_S11 * q(2) - MONO_S14 * mono_dm(q, 2) - q(1); }
+    else if (i == 2) { bl = MONO_S15 * q(1) + MONO_S11 * q(2) - MONO_S14 * mono_dm(q, 2) - q(2); br = mono_al(q, 3) - q(2); }
+    else if (i == n1 - 2) { bl = mono_al(q, n1 - 2) - q(n1 - 2); br = MONO_S15 * q(n1 - 1) + MONO_S11 * q(n1 - 2) + MONO_S14 * mono_dm(q, n1 - 2) - q(n1 - 2); }
+    else if (i == n1 - 1) { bl = MONO_S15 * q(n1 - 1) + MONO_S11 * q(n1 - 2) + MONO_S14 * mono_dm(q, n1 - 2) - q(n1 - 1); br = two_sided(n1) - q(n1 - 1); }
+    else { bl = two_sided(n1) - q(n1); br = MONO_S11 * (q(n1 + 1) - q(n1)) - MONO_S14 * mono_dm(q, n1 + 1); }
+    mono_pert_ppm(bl, br);
+    return;
+  }
+  const double qi = q(i), al0 = mono_al(q, i), al1 = mono_al(q, i + 1);
+  if (iord == 8) {                             // Lin's fast monotone constraint (:643-678)
+    const double xt = 2. * mono_dm(q, i);
+    bl = -mono_sign(fmin(fabs(xt), fabs(al0 - qi)), xt);
+    br = mono_sign(fmin(fabs(xt), fabs(al1 - qi)), xt);
+    return;
+  }
+  bl = al0 - qi; br = al1 - qi;                // iord = 10: Huynh's second constraint (:716-823)
+  if (fabs(mono_dm(q, i - 1)) + fabs(mono_dm(q, i)) + fabs(mono_dm(q, i + 1)) < MONO_NEAR_ZERO) { bl = 0.; br = 0.; return; }
+  if (fabs(3. * (bl + br)) > fabs(bl - br)) {
+    const double pmp_2 = 2. * (q(i) - q(i - 1)), lac_2 = pmp_2 - 0.75 * (2. * (q(i - 1) - q(i - 2)));
+    br = fmin(fmax(0., fmax(pmp_2, lac_2)), fmax(br, fmin(0., fmin(pmp_2, lac_2))));
+    const double pmp_1 = -(2. * (q(i + 1) - q(i))), lac_1 = pmp_1 + 0.75 * (2. * (q(i + 2) - q(i + 1)));
+    bl = fmin(fmax(0., fmax(pmp_1, lac_1)), fmax(bl, fmin(0., fmin(pmp_1, lac_1))));
+  }
+}
+// flux at interface m with the trajectory scheme: the differentiable schemes through ppm_flux, 8 / 10 through the slopes above (:944-952)
+template <class Q, class D>
+HD double ppm_flux_traj(int iord, bool face, int m, int n1, const Q& q, const D& da, double cc) {
+  if (iord != 8 && iord != 10) return ppm_flux<double>(iord, face, m, n1, q, da, cc);
+  double bl, br;
+  if (cc > 0.) { mono_blbr(iord, face, m - 1, n1, q, da, bl, br); return q(m - 1) + (1. - cc) * (br - cc * (bl + br)); }
+  mono_blbr(iord, face, m, n1, q, da, bl, br);
+  return q(m) + (1. + cc) * (bl + cc * (bl + br));
+}
+
 // xtp_u / ytp_v flux at interface m (sw_core_tlm.F90:7272-7486, :7490-7759): cfl = c * rd(upwind cell).
 template <class T, class Q, class D>
 HD T tp_uv_flux(int iord, bool face, int m, int n1, bool row_edge, const Q& q, const D& dd, T cc, double rd_m, double rd_0) {
@@ -528,6 +593,10 @@ struct DswRa {   // sw_core_tlm.F90:2969-2978
 
 // ---- fv_tp_2d building blocks (tp_core_tlm.F90:83-236) ----
 enum HordSel { HORD_MT = 0, HORD_VT, HORD_TM, HORD_DP, HORD_TR, HORD_TM_G };
+// the trajectory scheme of the same transport (== hord_of unless the schemes are split)
+HD int hord_traj_of(const LevelParams& l, int sel) {
+  return sel == HORD_MT ? l.hord_mt : sel == HORD_VT ? l.hord_vt_t : sel == HORD_TM ? l.hord_tm_t : sel == HORD_DP ? l.hord_dp_t : sel == HORD_TM_G ? l.hord_tm_g_t : l.hord_tr_t;
+}
 HD int hord_of(const LevelParams& l, int sel) {
   return sel == HORD_MT ? l.hord_mt : sel == HORD_VT ? l.hord_vt : sel == HORD_TM ? l.hord_tm : sel == HORD_DP ? l.hord_dp : sel == HORD_TM_G ? l.hord_tm_g : l.hord_tr;
 }
@@ -610,11 +679,15 @@ HD T lap_corner(const A& a, const Ctx& c, int tile, int i, int j) {
   return (fxa - fxb + (fya - fyb)) * MET(rarea, i, j);
 }
 enum DampSel { DAMP_NONE = 0, DAMP_V = 1, DAMP_T = 2 };
-HD void damp_of(const LevelParams& l, int sel, int& nord, double& damp_c) {
-  if (sel == DAMP_V) { nord = l.nord_v; damp_c = l.damp_vt; }
-  else if (sel == DAMP_T) { nord = l.nord_t; damp_c = l.damp_t; }
-  else { nord = -1; damp_c = 0.; }
+// pert: the level's transport runs with split schemes and this is the perturbation chain: nord_v_pert / damp_vt_pert for the mass
+// (sw_core_tlm.F90:1672-1679) and, as nord_t_pert / damp_t_pert = the same pair (dyn_core_tlm.F90:856-859), for the heat transport
+HD void damp_of(const LevelParams& l, int sel, int& nord, double& damp_c, bool pert = false) {
+  if (sel != DAMP_V && sel != DAMP_T) { nord = -1; damp_c = 0.; }
+  else if (pert) { nord = l.nord_v_pert; damp_c = l.damp_vt_pert; }
+  else if (sel == DAMP_V) { nord = l.nord_v; damp_c = l.damp_vt; }
+  else { nord = l.nord_t; damp_c = l.damp_t; }
 }
+HD bool level_split(const LevelParams& l, int hsel) { return hord_traj_of(l, hsel) != hord_of(l, hsel); }
 struct TpD2D {
   static constexpr bool LDS_FW_OK = true;
   STAGE_BASE("TpD2", 1, 1)   // in: q   out: d2b  (is-1..ie+1, js-1..je+1); zero where the level does not use nord=1
@@ -624,11 +697,14 @@ struct TpD2D {
   HD static constexpr int alias_box(int M) { return M; }
   HD bool alias(const Ctx& c, int, int i, int j, int n, int& ai, int& aj) const { return corner_alias(c.g, n + 1, i, j, ai, aj); }
   int dsel; int use_mass;
+  int hsel = -1, traj = 0;      // the transport's scheme selector; traj: the Laplacian of the values-only trajectory pass of a split level
   HD static constexpr Box box(int) { return Box{-1, 1, -1, 1, 0, 0}; }
   template <bool EDGE, class T, class A>
   HD void eval_e(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    int nord; double dc; damp_of(c.lev[k - 1], dsel, nord, dc);
+    const bool split = hsel >= 0 && level_split(c.lev[k - 1], hsel);
+    int nord; double dc; damp_of(c.lev[k - 1], dsel, nord, dc, split && !traj);
     o[0] = T(0.);
+    if (traj && !split) return;
     if (nord != 1 || !(dc > 1.e-4)) return;
     const double damp = use_mass ? 1.0 : (dc * c.m.da_min) * (dc * c.m.da_min);
     o[0] = damp * lap_corner<EDGE, 0, T>(a, c, tile, i, j);
@@ -640,13 +716,13 @@ typedef Edged<TpD2D, true> TpD2E;
 struct TpFlux {
   STAGE_BASE("TpFlux", 9, 2)   // in: fx_o fx2 mx fy_o fy2 my q d2b mass   out: fx fy
   STAGE_NO_ALIAS
-  int dsel; int use_mass;
+  int dsel; int use_mass; int hsel = -1;
   HD static constexpr bool uses(int M, int di, int dj, int) { return M < 6 || !(di == -1 && dj == -1); }
   HD static constexpr unsigned wants(int M) { return M < 3 ? 0x1u : M < 6 ? 0x2u : 0x3u; }
   HD static constexpr Box box(int M) { return (M == 6 || M == 7 || M == 8) ? Box{-1, 0, -1, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    int nord; double dc; damp_of(c.lev[k - 1], dsel, nord, dc);
+    int nord; double dc; damp_of(c.lev[k - 1], dsel, nord, dc, hsel >= 0 && level_split(c.lev[k - 1], hsel));
     const bool dmp = (dsel != DAMP_NONE) && (dc > 1.e-4);
     double damp = 0.;
     if (dmp) { damp = dc * c.m.da_min; if (nord == 1) damp = damp * damp; }
@@ -682,13 +758,13 @@ struct TpFlux {
 struct TpDamp {
   STAGE_BASE("TpDamp", 3, 2)   // in: q d2b mass   out: fx fy (adjoints read; never run forward)
   STAGE_NO_ALIAS
-  int dsel; int use_mass;
+  int dsel; int use_mass; int hsel = -1;
   HD static constexpr bool uses(int, int di, int dj, int) { return !(di == -1 && dj == -1); }
   HD static constexpr unsigned wants(int) { return 0x3u; }
   HD static constexpr Box box(int) { return Box{-1, 0, -1, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    int nord; double dc; damp_of(c.lev[k - 1], dsel, nord, dc);
+    int nord; double dc; damp_of(c.lev[k - 1], dsel, nord, dc, hsel >= 0 && level_split(c.lev[k - 1], hsel));
     const bool dmp = (dsel != DAMP_NONE) && (dc > 1.e-4);
     o[0] = o[1] = T(0.);
     if (!dmp) return;

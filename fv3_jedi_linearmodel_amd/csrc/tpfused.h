@@ -18,6 +18,7 @@ namespace fv3 {
 struct TpFusedArgs {
   Fld q, crx, cry, xfx, yfx, rax, ray, mx, my;   // inputs
   Fld mass, d2b;                                 // damping inputs (t == nullptr when unused)
+  Fld d2b_t;                                     // the damping Laplacian of the trajectory pass of split levels (TpD2 with traj = 1)
   Fld fx, fy;                                    // outputs
   Fld fy2, q_i, fxo, fx2, q_j, fyo;              // trajectory intermediates (nonlinear mode stores them for the staged adjoint)
   int hsel, dsel, use_mass, nk;
@@ -76,9 +77,15 @@ struct TpfTile {
 
 // One block: cells I0..I1 x J0..J1 of level k of one tile.  tid / nth: this thread and the number of threads sharing the block
 // (host emulation: 0 / 1).
-template <class T, bool STORE, int NTH>
+// TRAJ: the values-only second pass of a level whose trajectory scheme differs from the scheme the tangent / adjoint is taken of
+// (split_hord, sw_core_tlm.F90:1664-1682): the whole chain again with the trajectory scheme (inner sweeps: 8 where it is 10,
+// tp_core_tlm.F90:135-136) and the trajectory damping, fx.t / fy.t overwritten; levels without a split return at once.
+template <class T, bool STORE, int NTH, bool TRAJ = false>
 DEV void tp_fused_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx, int by, double* lds, int tid, int nth) {
   typedef TpfIO<T> IO;
+  static_assert(!TRAJ || (std::is_same<T, double>::value && !STORE), "the trajectory pass computes values only");
+  const bool split = level_split(c.lev[k - 1], a.hsel);
+  if (TRAJ && !split) return;
   const Geom& g = c.g;
   const int nx = g.nx, ny = g.ny;
   const bool face = g.face != 0;
@@ -90,7 +97,16 @@ DEV void tp_fused_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int
   // constant row pitches (the full block's), whatever the block's own width: index arithmetic by compile-time constants
   const TpfTile<T> q{lds, I0 - 3, J0 - 3, TPF_QW}, fy2{lds + TPF_NQ, I0 - 3, J0, TPF_QW}, qi{lds + TPF_NQ + TPF_NFY2, I0 - 3, J0, TPF_QW},
       fx2{lds + TPF_NQ + TPF_NFY2 + TPF_NQI, I0, J0 - 3, TPF_W + 1}, qj{lds + TPF_NQ + TPF_NFY2 + TPF_NQI + TPF_NFX2, I0, J0 - 3, TPF_W};
-  const int iord = hord_of(c.lev[k - 1], a.hsel);
+  const int iord = TRAJ ? hord_traj_of(c.lev[k - 1], a.hsel) : hord_of(c.lev[k - 1], a.hsel), iord_in = (TRAJ && iord == 10) ? 8 : iord;
+  auto flux1d = [&](int io, int m, int n1, const auto& line, const auto& da, const T& cc) -> T {
+    if constexpr (TRAJ) return ppm_flux_traj(io, face, m, n1, line, da, cc); else return ppm_flux<T>(io, face, m, n1, line, da, cc);
+  };
+  // flux capacitors on a split level: the first pass adds the tangents, the trajectory pass the values
+  auto acc_flux = [&](const Fld& acc, size_t n, const T& f) {
+    if constexpr (TRAJ) acc.t[n] += f;
+    else if (!split) IO::st(acc, n, IO::ld(acc, n) + f);
+    else if constexpr (!std::is_same<T, double>::value) acc.p[n] += f.d;
+  };
   // ownership of the stored intermediates: every element of their full regions belongs to exactly one block
   auto own_i = [&](int i) { return (i >= I0 && i <= I1) || (firstx && i < I0) || (lastx && i > I1); };
   auto own_j = [&](int j) { return (j >= J0 && j <= J1) || (firsty && j < J0) || (lasty && j > J1); };
@@ -107,10 +123,10 @@ DEV void tp_fused_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int
       auto line = [&](int jj) -> T { int ii = i, j2 = jj; if (face) corner_map(g, 2, ii, j2); return q.get(ii, j2); };
       const MetY da{c.m.dya, c, tile, i};
       const T cc = IO::ld(a.cry, at(i, j));
-      const T f = ppm_flux<T>(iord, face, j, ny + 1, line, da, cc);
+      const T f = flux1d(iord_in, j, ny + 1, line, da, cc);
       fy2.set(i, j, f);
       if (STORE && own_i(i) && (j <= J1 || lasty)) a.fy2.t[at(i, j)] = val(f);
-      if (a.do_acc && own_i(i) && (j <= J1 || lasty)) IO::st(a.acy, at(i, j), IO::ld(a.acy, at(i, j)) + cc);
+      if (!TRAJ && a.do_acc && own_i(i) && (j <= J1 || lasty)) IO::st(a.acy, at(i, j), IO::ld(a.acy, at(i, j)) + cc);
     } }
   { constexpr int w = TPF_W + 1, n = w * TPF_QH;
     TPF_LOOP(e, n) {
@@ -119,10 +135,10 @@ DEV void tp_fused_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int
       auto line = [&](int ii) -> T { int i2 = ii, jj = j; if (face) corner_map(g, 1, i2, jj); return q.get(i2, jj); };
       const MetX da{c.m.dxa, c, tile, j};
       const T cc = IO::ld(a.crx, at(i, j));
-      const T f = ppm_flux<T>(iord, face, i, nx + 1, line, da, cc);
+      const T f = flux1d(iord_in, i, nx + 1, line, da, cc);
       fx2.set(i, j, f);
       if (STORE && own_j(j) && (i <= I1 || lastx)) a.fx2.t[at(i, j)] = val(f);
-      if (a.do_acc && own_j(j) && (i <= I1 || lastx)) IO::st(a.acx, at(i, j), IO::ld(a.acx, at(i, j)) + cc);
+      if (!TRAJ && a.do_acc && own_j(j) && (i <= I1 || lastx)) IO::st(a.acx, at(i, j), IO::ld(a.acx, at(i, j)) + cc);
     } }
   TPF_SYNC();
   // ---- q_i, q_j: the field advanced by the inner fluxes (tp_core_tlm.F90:149-159, :173-181)
@@ -146,10 +162,11 @@ DEV void tp_fused_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int
     } }
   TPF_SYNC();
   // ---- outer sweeps and flux assembly (tp_core_tlm.F90:187-234; deln_flux :1918-2043 as in stages.h TpFlux)
-  int nord; double dc; damp_of(c.lev[k - 1], a.dsel, nord, dc);
+  int nord; double dc; damp_of(c.lev[k - 1], a.dsel, nord, dc, split && !TRAJ);
   const bool dmp = (a.dsel != DAMP_NONE) && (dc > 1.e-4);
   double damp = 0.;
   if (dmp) { damp = dc * c.m.da_min; if (nord == 1) damp = damp * damp; }
+  const Fld& d2 = TRAJ ? a.d2b_t : a.d2b;
   { constexpr int w = TPF_W + 1, n = w * (TPF_H + 1);
     TPF_LOOP(e, n) {
       const int i = I0 + e % w, j = J0 + e / w;
@@ -157,34 +174,34 @@ DEV void tp_fused_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int
       if (j <= J1 && (i <= I1 || lastx)) {          // fx(i,j)
         auto line = [&](int ii) -> T { return qi.get(ii, j); };
         const MetX da{c.m.dxa, c, tile, j};
-        const T fo = ppm_flux<T>(iord, face, i, nx + 1, line, da, IO::ld(a.crx, at(i, j)));
+        const T fo = flux1d(iord, i, nx + 1, line, da, IO::ld(a.crx, at(i, j)));
         if (STORE) a.fxo.t[at(i, j)] = val(fo);
         T f = 0.5 * (fo + fx2.get(i, j)) * IO::ld(a.mx, at(i, j));
         if (dmp) {
           T f2;
           if (nord == 0) { f2 = MET(del6_v, i, j) * (q.get(i - 1, j) - q.get(i, j)); if (!a.use_mass) f2 = damp * f2; }
-          else f2 = MET(del6_v, i, j) * (IO::ld(a.d2b, at(i, j)) - IO::ld(a.d2b, at(i - 1, j)));
+          else f2 = MET(del6_v, i, j) * (IO::ld(d2, at(i, j)) - IO::ld(d2, at(i - 1, j)));
           if (a.use_mass) f = f + (0.5 * damp) * (IO::ld(a.mass, at(i - 1, j)) + IO::ld(a.mass, at(i, j))) * f2;
           else f = f + f2;
         }
         IO::st(a.fx, at(i, j), f);
-        if (a.do_acc) IO::st(a.amfx, at(i, j), IO::ld(a.amfx, at(i, j)) + f);
+        if (a.do_acc) acc_flux(a.amfx, at(i, j), f);
       }
       if (i <= I1 && (j <= J1 || lasty)) {          // fy(i,j)
         auto line = [&](int jj) -> T { return qj.get(i, jj); };
         const MetY da{c.m.dya, c, tile, i};
-        const T fo = ppm_flux<T>(iord, face, j, ny + 1, line, da, IO::ld(a.cry, at(i, j)));
+        const T fo = flux1d(iord, j, ny + 1, line, da, IO::ld(a.cry, at(i, j)));
         if (STORE) a.fyo.t[at(i, j)] = val(fo);
         T f = 0.5 * (fo + fy2.get(i, j)) * IO::ld(a.my, at(i, j));
         if (dmp) {
           T f2;
           if (nord == 0) { f2 = MET(del6_u, i, j) * (q.get(i, j - 1) - q.get(i, j)); if (!a.use_mass) f2 = damp * f2; }
-          else f2 = MET(del6_u, i, j) * (IO::ld(a.d2b, at(i, j)) - IO::ld(a.d2b, at(i, j - 1)));
+          else f2 = MET(del6_u, i, j) * (IO::ld(d2, at(i, j)) - IO::ld(d2, at(i, j - 1)));
           if (a.use_mass) f = f + (0.5 * damp) * (IO::ld(a.mass, at(i, j - 1)) + IO::ld(a.mass, at(i, j))) * f2;
           else f = f + f2;
         }
         IO::st(a.fy, at(i, j), f);
-        if (a.do_acc) IO::st(a.amfy, at(i, j), IO::ld(a.amfy, at(i, j)) + f);
+        if (a.do_acc) acc_flux(a.amfy, at(i, j), f);
       }
     } }
 }
@@ -198,32 +215,36 @@ inline double tpf_bytes(const TpFusedArgs& a, const Geom& g, int mode) {
 }
 
 #ifndef FV3LM_HOST_EMUL
-template <class T, bool STORE, int NTH>
+template <class T, bool STORE, int NTH, bool TRAJ = false>
 __global__ void __launch_bounds__(NTH) k_tp_fused(TpFusedArgs a, Ctx c) {
   extern __shared__ double tpf_lds[];
   int bx = blockIdx.x, by = blockIdx.y; xcd_block(gridDim.x, gridDim.y, bx, by);
-  tp_fused_block<T, STORE, NTH>(a, c, blockIdx.z / a.nk, 1 + blockIdx.z % a.nk, bx, by, tpf_lds, threadIdx.x, NTH);
+  tp_fused_block<T, STORE, NTH, TRAJ>(a, c, blockIdx.z / a.nk, 1 + blockIdx.z % a.nk, bx, by, tpf_lds, threadIdx.x, NTH);
 }
 #endif
 
-// nonlinear / tangent-linear launch (the adjoint runs the staged launches of build_tp)
-inline void run_tp_fused(Exec& ex, int mode, const TpFusedArgs& a0, const Ctx& c) {
+// nonlinear / tangent-linear launch (the adjoint runs the staged launches of build_tp); traj: the values-only trajectory pass of
+// the levels with split schemes, in the nonlinear and the tangent mode alike
+inline void run_tp_fused(Exec& ex, int mode, const TpFusedArgs& a0, const Ctx& c, bool traj = false) {
   TpFusedArgs a = a0;
-  for (Fld* f : {&a.q, &a.crx, &a.cry, &a.xfx, &a.yfx, &a.rax, &a.ray, &a.mx, &a.my, &a.mass, &a.d2b, &a.fx, &a.fy, &a.fy2, &a.q_i, &a.fxo, &a.fx2, &a.q_j, &a.fyo, &a.acx, &a.acy, &a.amfx, &a.amfy}) *f = ex.sh(*f);
+  for (Fld* f : {&a.q, &a.crx, &a.cry, &a.xfx, &a.yfx, &a.rax, &a.ray, &a.mx, &a.my, &a.mass, &a.d2b, &a.d2b_t, &a.fx, &a.fy, &a.fy2, &a.q_i, &a.fxo, &a.fx2, &a.q_j, &a.fyo, &a.acx, &a.acy, &a.amfx, &a.amfy}) *f = ex.sh(*f);
   a.do_acc = (a.acx.t && !ex.skip_accum) ? 1 : 0;
   int nbx, nby; tpf_grid(c.g, nbx, nby);
-  ex.mark_begin("TpFused", mode == MODE_TL ? ".tl" : ".nl", tpf_bytes(a, c.g, mode));
+  ex.mark_begin(traj ? "TpFusedTraj" : "TpFused", traj ? ".nl" : mode == MODE_TL ? ".tl" : ".nl", traj ? 0. : tpf_bytes(a, c.g, mode));
 #ifdef FV3LM_HOST_EMUL
   std::vector<double> lds((size_t)TPF_NT * 2);
   for (int z = 0; z < c.g.ntile * a.nk; ++z)
     for (int by = 0; by < nby; ++by)
       for (int bx = 0; bx < nbx; ++bx) {
-        if (mode == MODE_TL) tp_fused_block<Dual, false, 1>(a, c, z / a.nk, 1 + z % a.nk, bx, by, lds.data(), 0, 1);
+        if (traj) tp_fused_block<double, false, 1, true>(a, c, z / a.nk, 1 + z % a.nk, bx, by, lds.data(), 0, 1);
+        else if (mode == MODE_TL) tp_fused_block<Dual, false, 1>(a, c, z / a.nk, 1 + z % a.nk, bx, by, lds.data(), 0, 1);
         else tp_fused_block<double, true, 1>(a, c, z / a.nk, 1 + z % a.nk, bx, by, lds.data(), 0, 1);
       }
 #else
   const dim3 grid(nbx, nby, c.g.ntile * a.nk);
-  if (mode == MODE_TL) {
+  if (traj) {
+    hipLaunchKernelGGL((k_tp_fused<double, false, TPF_THREADS_NL, true>), grid, dim3(TPF_THREADS_NL), TPF_NT * 8, ex.stream, a, c);
+  } else if (mode == MODE_TL) {
     static bool attr = false;      // 2 x 53.5 KB of LDS per block: above the 64 KB default limit of a launch
     if (!attr) { if (hipFuncSetAttribute((const void*)k_tp_fused<Dual, false, TPF_THREADS_TL>, hipFuncAttributeMaxDynamicSharedMemorySize, TPF_NT * 16) != hipSuccess) set_sticky("hipFuncSetAttribute(k_tp_fused) failed"); attr = true; }
     hipLaunchKernelGGL((k_tp_fused<Dual, false, TPF_THREADS_TL>), grid, dim3(TPF_THREADS_TL), TPF_NT * 16, ex.stream, a, c);

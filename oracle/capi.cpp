@@ -328,7 +328,7 @@ void orc_tracer_2d(void* hv, int mode, int nq, double** in_t, double** in_p, dou
     using T = typename std::decay<decltype(x[0].p[0].d[0])>::type;
     std::vector<Arr3<T>> q(nq);
     for (int n = 0; n < nq; ++n) q[n] = x[5 + n];
-    tracer_2d(q, x[0], x[1], x[2], x[3], x[4], npz, h->o.hord_tr, h->g, h->bd);
+    tracer_2d(q, x[0], x[1], x[2], x[3], x[4], npz, Hord(h->o.hord_tr, h->o.hord_tr_pert), h->g, h->bd);
     for (int n = 0; n < nq; ++n) y[n] = q[n];
   });
 }
@@ -420,7 +420,7 @@ void orc_cube_tracer_2d(void* cv, int mode, int nq, double** in_t, double** in_p
       dp1[t] = x[0 * 6 + t]; S[t].mfx = x[1 * 6 + t]; S[t].mfy = x[2 * 6 + t]; S[t].cx = x[3 * 6 + t]; S[t].cy = x[4 * 6 + t];
       for (int n = 0; n < nq; ++n) S[t].q[n] = x[(5 + n) * 6 + t];
     }
-    tracer_2d_cube(S, dp1, npz, h->o.hord_tr, c->G, h->bd, c->X);
+    tracer_2d_cube(S, dp1, npz, Hord(h->o.hord_tr, h->o.hord_tr_pert), c->G, h->bd, c->X);
     for (int t = 0; t < 6; ++t) for (int n = 0; n < nq; ++n) y[n * 6 + t] = S[t].q[n];
   });
 }

@@ -90,7 +90,7 @@ void dyn_core_cube(std::vector<DynState<T>>& S, const std::vector<Arr2<double>>&
 // (mp_reduce_max, fv_tracer2d_tlm.F90:1306) and the tracer halos are exchanged between sub-steps (:1440-1444), so the
 // faces advance sub-step by sub-step together.
 template <class T>
-void tracer_2d_cube(std::vector<DynState<T>>& S, std::vector<Arr3<T>>& dp1, int npz, int hord, const std::vector<Grid>& G, const Bounds& bd,
+void tracer_2d_cube(std::vector<DynState<T>>& S, std::vector<Arr3<T>>& dp1, int npz, Hord hord, const std::vector<Grid>& G, const Bounds& bd,
                     const CubeTables& X) {
   const int nt = (int)S.size();
   std::vector<double> cmax(npz + 1, 0.), loc;
@@ -162,7 +162,7 @@ void fv_dynamics_cube(std::vector<DynState<T>>& S, const std::vector<Arr2<double
         std::vector<Arr3<T>*> qs; for (auto& s : S) qs.push_back(&s.q[n]);
         exchange(X.rows[X_CELL], qs, none);
       }
-      tracer_2d_cube(S, dp1, npz, o.hord_tr, G, bd, X);
+      tracer_2d_cube(S, dp1, npz, Hord(o.hord_tr, o.hord_tr_pert), G, bd, X);
     }
     if (npz > 4) for (int t = 0; t < nt; ++t) lagrangian_to_eulerian(n_map == k_split, S[t], npz, c.akap, c.zvir, ptop, ak, bk, bd);
   }

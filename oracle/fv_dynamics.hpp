@@ -100,7 +100,7 @@ void map_col(int km, const std::vector<T>& pe1, const std::vector<T>& q1, int kn
 // tracer_2d, fv_tracer2d_tlm.F90:1148-1446 (q_split = 0, nord_tr/trdm = 0).  dp1 = delp before dyn_core.
 template <class T>
 void tracer_2d(std::vector<Arr3<T>>& q, Arr3<T>& dp1, Arr3<T>& mfx, Arr3<T>& mfy, Arr3<T>& cx, Arr3<T>& cy, int npz,
-               int hord, const Grid& g, const Bounds& bd, int* nsplt_out = nullptr, const std::vector<double>* cmax_all = nullptr,
+               Hord hord, const Grid& g, const Bounds& bd, int* nsplt_out = nullptr, const std::vector<double>* cmax_all = nullptr,
                std::vector<double>* cmax_out = nullptr, const std::function<void(std::vector<Arr3<T>>&)>* halo = nullptr) {
   const int is = bd.is, ie = bd.ie, js = bd.js, je = bd.je, isd = bd.isd, ied = bd.ied, jsd = bd.jsd, jed = bd.jed;
   const int nq = (int)q.size();
@@ -157,8 +157,8 @@ void tracer_2d(std::vector<Arr3<T>>& q, Arr3<T>& dp1, Arr3<T>& mfx, Arr3<T>& mfy
       for (int j = js; j <= je; ++j)
         for (int i = isd; i <= ied; ++i) ra_y(i, j) = g.area(i, j) + (yfx(i, j, k) - yfx(i, j + 1, k));
       for (int iq = 0; iq < nq; ++iq) {
-        fv_tp_2d<T>(q[iq].plane(k), cx.plane(k), cy.plane(k), hord, fx, fy, xfx.plane(k), yfx.plane(k), g, bd, ra_x, ra_y,
-                    &mfx.plane(k), &mfy.plane(k), nullptr, -1, 0.0);
+        fv_tp_2d_split<T>(q[iq].plane(k), cx.plane(k), cy.plane(k), hord.traj, hord.pert, fx, fy, xfx.plane(k), yfx.plane(k), g, bd, ra_x, ra_y,
+                          &mfx.plane(k), &mfy.plane(k), nullptr, -1, 0.0, -1, 0.0);       // fv_tracer2d_tlm.F90:1047-1110
         for (int j = js; j <= je; ++j)
           for (int i = is; i <= ie; ++i)
             q[iq](i, j, k) = (q[iq](i, j, k) * dp1(i, j, k) + (fx(i, j) - fx(i + 1, j) + (fy(i, j) - fy(i, j + 1))) * g.rarea(i, j)) / dp2(i, j);
@@ -268,7 +268,7 @@ void fv_dynamics(DynState<T>& s, const Arr2<double>& phis, int npz, double bdt, 
     dyn_core(s, phis, npz, mdt, n_split, o, c, ptop, g, bd);
     if (nq > 0) {
       for (auto& qq : s.q) halo_periodic(qq, bd);     // dyn_core_tlm.F90:2452-2454 halo of q
-      tracer_2d(s.q, dp1, s.mfx, s.mfy, s.cx, s.cy, npz, o.hord_tr, g, bd);
+      tracer_2d(s.q, dp1, s.mfx, s.mfy, s.cx, s.cy, npz, Hord(o.hord_tr, o.hord_tr_pert), g, bd);
     }
     if (npz > 4) lagrangian_to_eulerian(last_step, s, npz, c.akap, c.zvir, ptop, ak, bk, bd);
   }

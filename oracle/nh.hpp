@@ -248,7 +248,7 @@ void update_dz_c(int km, double dt, const std::vector<double>& dp0, const Arr2<d
 // Courant numbers / area fluxes interpolated to the interfaces (EDGE_PROFILE), plus del-2/4 damping with the vorticity
 // damping coefficients of the layer above (ndif(km+1) = ndif(km)).
 template <class T>
-void update_dz_d(const std::vector<int>& ndif, const std::vector<double>& damp, int hord, int km, const std::vector<double>& dp0,
+void update_dz_d(const std::vector<int>& ndif, const std::vector<double>& damp, Hord hord, int km, const std::vector<double>& dp0,
                  const Arr2<double>& zs, Arr3<T>& zh, const Arr3<T>& crx, const Arr3<T>& cry, const Arr3<T>& xfx, const Arr3<T>& yfx, Arr2<T>& ws,
                  double rdt, const Grid& g, const Bounds& bd) {
   const int is = bd.is, ie = bd.ie, js = bd.js, je = bd.je, isd = bd.isd, ied = bd.ied, jsd = bd.jsd, jed = bd.jed;
@@ -275,8 +275,8 @@ void update_dz_d(const std::vector<int>& ndif, const std::vector<double>& damp, 
     for (int j = js; j <= je; ++j)
       for (int i = isd; i <= ied; ++i) ra_y(i, j) = g.area(i, j) + (yfx_adv(i, j, k) - yfx_adv(i, j + 1, k));
     Arr2<T> z2 = zh.plane(k);
-    fv_tp_2d<T>(z2, crx_adv.plane(k), cry_adv.plane(k), hord, fx, fy, xfx_adv.plane(k), yfx_adv.plane(k), g, bd, ra_x, ra_y, nullptr, nullptr,
-                nullptr, -1, 0.0);
+    fv_tp_2d_split<T>(z2, crx_adv.plane(k), cry_adv.plane(k), hord.traj, hord.pert, fx, fy, xfx_adv.plane(k), yfx_adv.plane(k), g, bd, ra_x, ra_y, nullptr, nullptr,
+                      nullptr, -1, 0.0, -1, 0.0);      // nh_utils_tlm.F90:496-560
     if (damp[kk] > 1.e-5) {
       del6_vt_flux(ndif[kk], damp[kk], z2, wk2, fx2, fy2, g, bd);
       for (int j = js; j <= je; ++j)
@@ -421,7 +421,7 @@ void dyn_core_nh(DynState<T>& s, NhState<T>& n, const Arr2<double>& phis, int np
            o.d4_bg, g, bd, &n.w.plane(k));
     }
     halo_periodic(s.delp, bd); halo_periodic(s.pt, bd);
-    update_dz_d(ndif, dampv, o.hord_tm, npz, dp_ref, zs, n.zh, crx, cry, xfx, yfx, ws, rdt, g, bd);
+    update_dz_d(ndif, dampv, Hord(o.hord_tm, o.hord_tm_pert), npz, dp_ref, zs, n.zh, crx, cry, xfx, yfx, ws, rdt, g, bd);
     riem_solver3(dt, npz, c.akap, ptop, zs, n.w, n.delz, s.pt, s.delp, n.zh, s.pe, pkc, pk3, s.pk, s.peln, ws, remap_step, c, nh, bd);
     halo_periodic(n.zh, bd); halo_periodic(pkc, bd);
     if (remap_step) pe_halo(npz, ptop, s.pe, s.delp, bd);
@@ -511,7 +511,7 @@ void fv_dynamics_nh(DynState<T>& s, NhState<T>& n, const Arr2<double>& phis, int
     dyn_core_nh(s, n, phis, npz, mdt, n_split, o, c, ptop, ak, bk, nh, g, bd, &ws);
     if (nq > 0) {
       for (auto& qq : s.q) halo_periodic(qq, bd);
-      tracer_2d(s.q, dp1, s.mfx, s.mfy, s.cx, s.cy, npz, o.hord_tr, g, bd);
+      tracer_2d(s.q, dp1, s.mfx, s.mfy, s.cx, s.cy, npz, Hord(o.hord_tr, o.hord_tr_pert), g, bd);
     }
     if (npz > 4) lagrangian_to_eulerian_nh(last_step, s, n, ws, npz, c, ptop, ak, bk, bd);
   }
@@ -576,7 +576,7 @@ void dyn_core_nh_cube(std::vector<DynState<T>>& S, std::vector<NhState<T>>& N, c
     exchange(X.rows[X_CELL], per_tile(S, [](DynState<T>& s) -> Arr3<T>& { return s.delp; }), none);
     exchange(X.rows[X_CELL], per_tile(S, [](DynState<T>& s) -> Arr3<T>& { return s.pt; }), none);
     for (int t = 0; t < nt; ++t) {
-      update_dz_d(ndif, dampv, o.hord_tm, npz, dp_ref, zs[t], N[t].zh, crx[t], cry[t], xfx[t], yfx[t], ws[t], rdt, G[t], bd);
+      update_dz_d(ndif, dampv, Hord(o.hord_tm, o.hord_tm_pert), npz, dp_ref, zs[t], N[t].zh, crx[t], cry[t], xfx[t], yfx[t], ws[t], rdt, G[t], bd);
       riem_solver3(dt, npz, c.akap, ptop, zs[t], N[t].w, N[t].delz, S[t].pt, S[t].delp, N[t].zh, S[t].pe, pkc[t], pk3[t], S[t].pk, S[t].peln, ws[t],
                    remap_step, c, nh, bd);
     }
@@ -626,7 +626,7 @@ void fv_dynamics_nh_cube(std::vector<DynState<T>>& S, std::vector<NhState<T>>& N
         std::vector<Arr3<T>*> qs; for (auto& s : S) qs.push_back(&s.q[n]);
         exchange(X.rows[X_CELL], qs, none);
       }
-      tracer_2d_cube(S, dp1, npz, o.hord_tr, G, bd, X);
+      tracer_2d_cube(S, dp1, npz, Hord(o.hord_tr, o.hord_tr_pert), G, bd, X);
     }
     if (npz > 4) for (int t = 0; t < nt; ++t) lagrangian_to_eulerian_nh(n_map == k_split, S[t], N[t], ws[t], npz, c, ptop, ak, bk, bd);
   }

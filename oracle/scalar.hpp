@@ -102,6 +102,11 @@ inline double combine(double a, double) { return a; }
 inline Dual combine(const Dual& a, const Dual& b) { return Dual(a.v, b.d); }
 inline Rev combine(const Rev& a, const Rev& b) { return mk(a.v, b.id, 1.0, -1, 0.0); }
 
+// the value replaced, the sensitivities kept (split schemes: the nonlinear routine's result over the _TLM routine's, tp_core.hpp fv_tp_2d_split)
+inline void set_val(double& a, double x) { a = x; }
+inline void set_val(Dual& a, double x) { a.v = x; }
+inline void set_val(Rev& a, double x) { a.v = x; }
+
 // value extraction used for every trajectory-dependent branch
 inline double val(double a) { return a; }
 inline double val(const Dual& a) { return a.v; }

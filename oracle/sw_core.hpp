@@ -768,8 +768,8 @@ void d_sw(Arr2<T>& delp, Arr2<T>& pt, Arr2<T>& u, Arr2<T>& v, Arr2<T>& uc, Arr2<
   for (int j = js; j <= je; ++j)
     for (int i = isd; i <= ied; ++i) ra_y(i, j) = g.area(i, j) + (yfx_adv(i, j) - yfx_adv(i, j + 1));
   // delp transport (:2979-2986): nord=nord_v, damp_c=damp_v, no mass
-  fv_tp_2d<T>(delp, crx_adv, cry_adv, lp.hord_dp, fx, fy, xfx_adv, yfx_adv, g, bd, ra_x, ra_y, nullptr, nullptr,
-              nullptr, lp.nord_v, lp.damp_vt);
+  fv_tp_2d_split<T>(delp, crx_adv, cry_adv, lp.hord_dp, lp.hord_dp_pert, fx, fy, xfx_adv, yfx_adv, g, bd, ra_x, ra_y, nullptr, nullptr,
+                    nullptr, lp.nord_v, lp.damp_vt, lp.nord_v_pert, lp.damp_vt_pert);
   for (int j = jsd; j <= jed; ++j)            // flux capacitors :2988-3006
     for (int i = is; i <= ie + 1; ++i) cx(i, j) = cx(i, j) + crx_adv(i, j);
   for (int j = js; j <= je; ++j)
@@ -787,13 +787,14 @@ void d_sw(Arr2<T>& delp, Arr2<T>& pt, Arr2<T>& u, Arr2<T>& v, Arr2<T>& uc, Arr2<
       for (int j = js; j <= je; ++j)
         for (int i = is; i <= ie; ++i) dw(i, j) = (fx2(i, j) - fx2(i + 1, j) + (fy2(i, j) - fy2(i, j + 1))) * g.rarea(i, j);
     }
-    fv_tp_2d<T>(*w, crx_adv, cry_adv, lp.hord_vt, gx, gy, xfx_adv, yfx_adv, g, bd, ra_x, ra_y, &fx, &fy, nullptr, -1, 0.0);
+    fv_tp_2d_split<T>(*w, crx_adv, cry_adv, lp.hord_vt, lp.hord_vt_pert, gx, gy, xfx_adv, yfx_adv, g, bd, ra_x, ra_y, &fx, &fy, nullptr, -1, 0.0, -1, 0.0);
     for (int j = js; j <= je; ++j)
       for (int i = is; i <= ie; ++i) (*w)(i, j) = delp(i, j) * (*w)(i, j) + (gx(i, j) - gx(i + 1, j) + (gy(i, j) - gy(i, j + 1))) * g.rarea(i, j);
   }
   // pt transport (:3064-3072): mass=delp, nord_t, damp_t
-  fv_tp_2d<T>(pt, crx_adv, cry_adv, lp.hord_tm, gx, gy, xfx_adv, yfx_adv, g, bd, ra_x, ra_y, &fx, &fy, &delp,
-              lp.nord_t, lp.damp_t);
+  // perturbation damping of the split call: nord_t_pert = nord_v_pert(k), damp_t_pert = damp_vt_pert(k) (dyn_core_tlm.F90:856-859)
+  fv_tp_2d_split<T>(pt, crx_adv, cry_adv, lp.hord_tm, lp.hord_tm_pert, gx, gy, xfx_adv, yfx_adv, g, bd, ra_x, ra_y, &fx, &fy, &delp,
+                    lp.nord_t, lp.damp_t, lp.nord_v_pert, lp.damp_vt_pert);
   for (int j = js; j <= je; ++j)              // :3107-3116
     for (int i = is; i <= ie; ++i) {
       pt(i, j) = pt(i, j) * delp(i, j) + (gx(i, j) - gx(i + 1, j) + (gy(i, j) - gy(i, j + 1))) * g.rarea(i, j);
@@ -854,8 +855,8 @@ void d_sw(Arr2<T>& delp, Arr2<T>& pt, Arr2<T>& u, Arr2<T>& v, Arr2<T>& uc, Arr2<
                              divg_d, wk, g, bd);
   for (int j = jsd; j <= jed; ++j)            // :3535-3540 hydrostatic
     for (int i = isd; i <= ied; ++i) vort(i, j) = wk(i, j) + g.f0(i, j);
-  fv_tp_2d<T>(vort, crx_adv, cry_adv, lp.hord_vt, fx, fy, xfx_adv, yfx_adv, g, bd, ra_x, ra_y, nullptr, nullptr,
-              nullptr, -1, 0.0);
+  fv_tp_2d_split<T>(vort, crx_adv, cry_adv, lp.hord_vt, lp.hord_vt_pert, fx, fy, xfx_adv, yfx_adv, g, bd, ra_x, ra_y, nullptr, nullptr,
+                    nullptr, -1, 0.0, -1, 0.0);
   for (int j = js; j <= je + 1; ++j)          // :3555-3564
     for (int i = is; i <= ie; ++i) u(i, j) = vt(i, j) + (ke(i, j) - ke(i + 1, j)) + fy(i, j);
   for (int j = js; j <= je; ++j)

@@ -2,14 +2,26 @@
 // Restatement of model_tlmadm/tp_core_tlm.F90: fv_tp_2d (:83-236 / _TLM :2123-2324), xppm
 // (_TLM :2328-2492), yppm (_TLM :2496-2669), deln_flux (:1918-2043 / _TLM :2673-2837),
 // copy_corners (:2046-2118).  Only the schemes the TL/AD code implements are restated:
-// iord/jord in {1, 2, 333} (tp_core_tlm.F90:2393,2431,2441,2467).
+// iord/jord in {1, 2, 333} (tp_core_tlm.F90:2393,2431,2441,2467); on double (the nonlinear routine) also the monotone
+// iord 8 / 10 of tp_mono.hpp, which fv_tp_2d_split below runs for the trajectory values when the schemes are split.
 #pragma once
 #include "arrays.hpp"
+#include "tp_mono.hpp"
 
 namespace orc {
 
 static const double ppm_p1 = 7. / 12., ppm_p2 = -1. / 12.;   // tp_core_tlm.F90:57-58 region (p1,p2)
 static const double ppm_c1 = -2. / 14., ppm_c2 = 11. / 14., ppm_c3 = 5. / 14.;
+
+// the monotone schemes exist for the nonlinear routine only (never differentiated by the reference)
+template <class T> struct Mono {
+  static bool x(Arr2<T>&, const Arr2<T>&, const Arr2<T>&, int, int, int, int, int, const Bounds&, const Grid&) { std::fprintf(stderr, "oracle: monotone xppm on a differentiated scalar\n"); std::abort(); }
+  static bool y(Arr2<T>&, const Arr2<T>&, const Arr2<T>&, int, int, int, int, int, const Bounds&, const Grid&) { std::fprintf(stderr, "oracle: monotone yppm on a differentiated scalar\n"); std::abort(); }
+};
+template <> struct Mono<double> {
+  static bool x(Arr2<double>& f, const Arr2<double>& q, const Arr2<double>& c, int iord, int is, int ie, int j0, int j1, const Bounds& bd, const Grid& g) { xppm_mono(f, q, c, iord, is, ie, j0, j1, bd, g); return true; }
+  static bool y(Arr2<double>& f, const Arr2<double>& q, const Arr2<double>& c, int jord, int i0, int i1, int js, int je, const Bounds& bd, const Grid& g) { yppm_mono(f, q, c, jord, i0, i1, js, je, bd, g); return true; }
+};
 
 // xppm: 1-D flux in x along rows jfirst..jlast.  c and flux live on is..ie+1.
 // tp_core_tlm.F90:2328-2492, with the one-sided edge values at cube-face edges (:2402-2429).
@@ -33,6 +45,7 @@ void copy_corners(Arr2<T>& q, int dir, const Bounds& bd) {
 template <class T>
 void xppm(Arr2<T>& flux, const Arr2<T>& q, const Arr2<T>& c, int iord, int is, int ie, int jfirst, int jlast,
           const Bounds& bd, const Grid& g) {
+  if (iord == 8 || iord == 10) { Mono<T>::x(flux, q, c, iord, is, ie, jfirst, jlast, bd, g); return; }
   assert(iord == 1 || iord == 2 || iord == 333);
   const int npx = bd.npx;
   int is1 = is - 1, ie3 = ie + 2;
@@ -87,6 +100,7 @@ void xppm(Arr2<T>& flux, const Arr2<T>& q, const Arr2<T>& c, int iord, int is, i
 template <class T>
 void yppm(Arr2<T>& flux, const Arr2<T>& q, const Arr2<T>& c, int jord, int ifirst, int ilast, int js, int je,
           const Bounds& bd, const Grid& g) {
+  if (jord == 8 || jord == 10) { Mono<T>::y(flux, q, c, jord, ifirst, ilast, js, je, bd, g); return; }
   assert(jord == 1 || jord == 2 || jord == 333);
   const int npy = bd.npy;
   int js1 = js - 1, je3 = je + 2;
@@ -230,6 +244,37 @@ void fv_tp_2d(const Arr2<T>& q_in, const Arr2<T>& crx, const Arr2<T>& cry, int h
       deln_flux<T>(nord, bd, damp, q, fx, fy, g, nullptr);
     }
   }
+}
+
+
+// Trajectory scheme != perturbation scheme (split_hord): the reference calls FV_TP_2D_TLM with the perturbation scheme and
+// damping and then the nonlinear fv_tp_2d with the trajectory scheme and damping, whose fluxes replace the VALUES
+// (sw_core_tlm.F90:1664-1682 delp, :1746-1763 w, :1787-1803 pt, :2407-2420 vorticity; fv_tracer2d_tlm.F90, nh_utils_tlm.F90 likewise).
+// The tangents stay those of the perturbation chain.  Equal schemes: one call with the trajectory damping, as before.
+// trajectory / perturbation scheme pair of a transport call (an int converts: both the same)
+struct Hord { int traj, pert; Hord(int t) : traj(t), pert(t) {} Hord(int t, int p) : traj(t), pert(p) {} };
+inline Arr2<double> values_of(const Arr2<double>& a) { return a; }
+template <class T> Arr2<double> values_of(const Arr2<T>& a) {
+  Arr2<double> r; r.isd = a.isd; r.jsd = a.jsd; r.pi = a.pi; r.pj = a.pj; r.d.resize(a.d.size());
+  for (size_t n = 0; n < a.d.size(); ++n) r.d[n] = val(a.d[n]);
+  return r;
+}
+template <class T>
+void fv_tp_2d_split(const Arr2<T>& q, const Arr2<T>& crx, const Arr2<T>& cry, int hord, int hord_pert, Arr2<T>& fx, Arr2<T>& fy,
+                    const Arr2<T>& xfx, const Arr2<T>& yfx, const Grid& g, const Bounds& bd, const Arr2<T>& ra_x, const Arr2<T>& ra_y,
+                    const Arr2<T>* mfx, const Arr2<T>* mfy, const Arr2<T>* mass, int nord, double damp_c, int nord_pert, double damp_c_pert) {
+  if (hord == hord_pert) { fv_tp_2d<T>(q, crx, cry, hord, fx, fy, xfx, yfx, g, bd, ra_x, ra_y, mfx, mfy, mass, nord, damp_c); return; }
+  fv_tp_2d<T>(q, crx, cry, hord_pert, fx, fy, xfx, yfx, g, bd, ra_x, ra_y, mfx, mfy, mass, nord_pert, damp_c_pert);
+  const Arr2<double> qd = values_of(q), cxd = values_of(crx), cyd = values_of(cry), xd = values_of(xfx), yd = values_of(yfx), rxd = values_of(ra_x), ryd = values_of(ra_y);
+  Arr2<double> mxd, myd, msd, fxd(bd), fyd(bd);
+  if (mfx) mxd = values_of(*mfx);
+  if (mfy) myd = values_of(*mfy);
+  if (mass) msd = values_of(*mass);
+  fv_tp_2d<double>(qd, cxd, cyd, hord, fxd, fyd, xd, yd, g, bd, rxd, ryd, mfx ? &mxd : nullptr, mfy ? &myd : nullptr, mass ? &msd : nullptr, nord, damp_c);
+  for (int j = bd.js; j <= bd.je; ++j)
+    for (int i = bd.is; i <= bd.ie + 1; ++i) set_val(fx(i, j), fxd(i, j));
+  for (int j = bd.js; j <= bd.je + 1; ++j)
+    for (int i = bd.is; i <= bd.ie; ++i) set_val(fy(i, j), fyd(i, j));
 }
 
 }  // namespace orc

@@ -1,0 +1,124 @@
+// TEST INFRASTRUCTURE — CPU oracle (see scalar.hpp).
+// The monotone 1-D PPM fluxes of the NONLINEAR xppm / yppm, iord = 8 and 10 (model_tlmadm/tp_core_tlm.F90:592-955 for
+// x, :1339-1723 for y; pert_ppm :1853-1915).  The tangent-linear and adjoint code never differentiates them: with a
+// trajectory scheme that differs from the perturbation scheme the reference runs the _TLM routine with the perturbation
+// scheme and then the nonlinear routine with the trajectory scheme for the values (sw_core_tlm.F90:1664-1682) — so
+// these are written on double only.  x and y share one line routine here (the two reference copies are the same
+// statements with the indices swapped; the cube-edge values use dxa along x, dya along y).
+#pragma once
+#include "arrays.hpp"
+#include <algorithm>
+
+namespace orc {
+
+static const double mono_r3 = 1. / 3., mono_near_zero = 1.e-25;
+static const double mono_s11 = 11. / 14., mono_s14 = 4. / 7., mono_s15 = 3. / 14.;   // tp_core_tlm.F90:57
+
+inline double f_sign(double a, double b) { return b >= 0. ? std::fabs(a) : -std::fabs(a); }   // Fortran SIGN(a, b)
+
+// pert_ppm with iv = 1 ("standard PPM constraint"), tp_core_tlm.F90:1893-1913; iv = 0 is only reached for iord 9 / 13
+inline void pert_ppm_std(int im, double* al, double* ar) {
+  for (int i = 0; i < im; ++i) {
+    if (al[i] * ar[i] < 0.) {
+      const double da1 = al[i] - ar[i], da2 = da1 * da1, a6da = 3. * (al[i] + ar[i]) * da1;
+      if (a6da < -da2) ar[i] = -(2. * al[i]);
+      else if (a6da > da2) al[i] = -(2. * ar[i]);
+    } else { al[i] = 0.; ar[i] = 0.; }
+  }
+}
+
+// One line.  Cells are numbered as in the reference (first..last = is..ie or js..je, three halo cells each side);
+// q(n), c(n) (n = first..last+1), da(n) = dxa or dya along the line; edge_lo: first == 1 on a cube edge,
+// edge_hi: last + 1 == np on a cube edge; any_edge: the tile is part of a cubed-sphere face (is1 / ie1 clipping, :314-330).
+template <class FQ, class FC, class FD, class FOut>
+void ppm_line_mono(int iord, int first, int last, int np, bool any_edge, bool edge_lo, bool edge_hi, const FQ& q, const FC& c, const FD& da,
+                   const FOut& flux) {
+  assert(iord == 8 || iord == 10);
+  int is1 = first - 1, ie1 = last + 1;
+  if (any_edge) { is1 = std::max(3, first - 1); ie1 = std::min(np - 3, last + 1); }
+  const int lo = first - 4, n = last - first + 10;
+  std::vector<double> dm_(n, 0.), al_(n, 0.), bl_(n, 0.), br_(n, 0.), dq_(n, 0.);
+  auto dm = [&](int i) -> double& { return dm_[i - lo]; };
+  auto al = [&](int i) -> double& { return al_[i - lo]; };
+  auto bl = [&](int i) -> double& { return bl_[i - lo]; };
+  auto br = [&](int i) -> double& { return br_[i - lo]; };
+  auto dq = [&](int i) -> double& { return dq_[i - lo]; };
+  for (int i = first - 2; i <= last + 2; ++i) {      // :596-640
+    const double xt = 0.25 * (q(i + 1) - q(i - 1));
+    const double hi = std::max(std::max(q(i - 1), q(i)), q(i + 1)) - q(i), lw = q(i) - std::min(std::min(q(i - 1), q(i)), q(i + 1));
+    dm(i) = f_sign(std::min(std::min(std::fabs(xt), hi), lw), xt);
+  }
+  for (int i = is1; i <= ie1 + 1; ++i) al(i) = 0.5 * (q(i - 1) + q(i)) + mono_r3 * (dm(i - 1) - dm(i));     // :641-642
+  if (iord == 8) {                                   // :643-678
+    for (int i = is1; i <= ie1; ++i) {
+      const double xt = 2. * dm(i);
+      bl(i) = -f_sign(std::min(std::fabs(xt), std::fabs(al(i) - q(i))), xt);
+      br(i) = f_sign(std::min(std::fabs(xt), std::fabs(al(i + 1) - q(i))), xt);
+    }
+  } else {                                           // iord = 10: Huynh's second constraint, :716-823
+    for (int i = is1 - 2; i <= ie1 + 1; ++i) dq(i) = 2. * (q(i + 1) - q(i));
+    for (int i = is1; i <= ie1; ++i) {
+      bl(i) = al(i) - q(i);
+      br(i) = al(i + 1) - q(i);
+      if (std::fabs(dm(i - 1)) + std::fabs(dm(i)) + std::fabs(dm(i + 1)) < mono_near_zero) { bl(i) = 0.; br(i) = 0.; }
+      else if (std::fabs(3. * (bl(i) + br(i))) > std::fabs(bl(i) - br(i))) {
+        const double pmp_2 = dq(i - 1), lac_2 = pmp_2 - 0.75 * dq(i - 2);
+        br(i) = std::min(std::max(0., std::max(pmp_2, lac_2)), std::max(br(i), std::min(0., std::min(pmp_2, lac_2))));
+        const double pmp_1 = -dq(i), lac_1 = pmp_1 + 0.75 * dq(i + 1);
+        bl(i) = std::min(std::max(0., std::max(pmp_1, lac_1)), std::max(bl(i), std::min(0., std::min(pmp_1, lac_1))));
+      }
+    }
+  }
+  auto two_sided = [&](int e) {     // the dxa-weighted value on a cube edge between cells e-1 and e (:833-835, :892-895)
+    return 0.5 * (((2. * da(e - 1) + da(e - 2)) * q(e - 1) - da(e - 1) * q(e - 2)) / (da(e - 2) + da(e - 1)) +
+                  ((2. * da(e) + da(e + 1)) * q(e) - da(e) * q(e + 1)) / (da(e) + da(e + 1)));
+  };
+  if (any_edge) {
+    if (edge_lo) {                  // :830-884
+      bl(0) = mono_s14 * dm(-1) + mono_s11 * (q(-1) - q(0));
+      double xt = two_sided(1);
+      xt = std::max(xt, std::min(std::min(q(-1), q(0)), std::min(q(1), q(2))));
+      xt = std::min(xt, std::max(std::max(q(-1), q(0)), std::max(q(1), q(2))));
+      br(0) = xt - q(0);
+      bl(1) = xt - q(1);
+      xt = mono_s15 * q(1) + mono_s11 * q(2) - mono_s14 * dm(2);
+      br(1) = xt - q(1);
+      bl(2) = xt - q(2);
+      br(2) = al(3) - q(2);
+      pert_ppm_std(3, &bl(0), &br(0));
+    }
+    if (edge_hi) {                  // :886-942
+      bl(np - 2) = al(np - 2) - q(np - 2);
+      double xt = mono_s15 * q(np - 1) + mono_s11 * q(np - 2) + mono_s14 * dm(np - 2);
+      br(np - 2) = xt - q(np - 2);
+      bl(np - 1) = xt - q(np - 1);
+      xt = two_sided(np);
+      xt = std::max(xt, std::min(std::min(q(np - 2), q(np - 1)), std::min(q(np), q(np + 1))));
+      xt = std::min(xt, std::max(std::max(q(np - 2), q(np - 1)), std::max(q(np), q(np + 1))));
+      br(np - 1) = xt - q(np - 1);
+      bl(np) = xt - q(np);
+      br(np) = mono_s11 * (q(np + 1) - q(np)) - mono_s14 * dm(np + 1);
+      pert_ppm_std(3, &bl(np - 2), &br(np - 2));
+    }
+  }
+  for (int i = first; i <= last + 1; ++i) {          // :944-952
+    const double cc = c(i);
+    if (cc > 0.) flux(i, q(i - 1) + (1. - cc) * (br(i - 1) - cc * (bl(i - 1) + br(i - 1))));
+    else flux(i, q(i) + (1. + cc) * (bl(i) + cc * (bl(i) + br(i))));
+  }
+}
+
+inline void xppm_mono(Arr2<double>& flux, const Arr2<double>& q, const Arr2<double>& c, int iord, int is, int ie, int jfirst, int jlast,
+                      const Bounds& bd, const Grid& g) {
+  for (int j = jfirst; j <= jlast; ++j)
+    ppm_line_mono(iord, is, ie, bd.npx, bd.any_edge(), bd.edge_w, bd.edge_e, [&](int i) { return q(i, j); }, [&](int i) { return c(i, j); },
+                  [&](int i) { return g.dxa(i, j); }, [&](int i, double f) { flux(i, j) = f; });
+}
+inline void yppm_mono(Arr2<double>& flux, const Arr2<double>& q, const Arr2<double>& c, int jord, int ifirst, int ilast, int js, int je,
+                      const Bounds& bd, const Grid& g) {
+  for (int i = ifirst; i <= ilast; ++i)
+    ppm_line_mono(jord, js, je, bd.npy, bd.any_edge(), bd.edge_s, bd.edge_n, [&](int j) { return q(i, j); }, [&](int j) { return c(i, j); },
+                  [&](int j) { return g.dya(i, j); }, [&](int j, double f) { flux(i, j) = f; });
+}
+
+}  // namespace orc

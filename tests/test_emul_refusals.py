@@ -6,13 +6,12 @@ from common import Case
 
 @pytest.mark.parametrize("kw, needle", [
     (dict(nord=2), "nord"),
-    (dict(hord_dp=10), "hord"),
-    (dict(hord_mt=2, hord_mt_pert=1), "split_hord"),
+    (dict(hord_dp=10, hord_dp_pert=10), "hord"),          # the tangent / adjoint exists for 1, 2, 333 only
+    (dict(hord_dp=5), "hord"),                            # trajectory schemes built: 1, 2, 333, 8, 10
+    (dict(hord_mt=2, hord_mt_pert=1), "split_hord"),      # xtp_u / ytp_v with two schemes: not built
     (dict(hydrostatic=0, a_imp=0.4), "a_imp"),
     (dict(kord_tm=-9), "kord"),
     (dict(kord_tr=8), "kord"),
-    (dict(nq=2, hord_tr=2, hord_tr_pert=1), "hord_tr"),
-    (dict(hydrostatic=0, hord_tm=2, hord_tm_pert=1, hord_tm_ks_traj=1, hord_tm_ks_pert=1), "hord_tm"),
 ])
 def test_unsupported_options_are_refused(kw, needle):
     with pytest.raises(Exception) as e:

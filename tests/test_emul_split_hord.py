@@ -1,0 +1,120 @@
+"""split_hord: a trajectory advection scheme that differs from the perturbation scheme -- incl. the monotone
+iord 8 / 10 of the nonlinear xppm / yppm (tp_core_tlm.F90:592-955) -- for the fv_tp_2d transports.  The reference runs the _TLM
+routine with the perturbation scheme, then the nonlinear routine with the trajectory scheme for the values
+(sw_core_tlm.F90:1664-1682); product (fused kernel + a values-only second pass) against the oracle (tp_core.hpp fv_tp_2d_split,
+tp_mono.hpp), on the host-emulation build.  The monotone schemes have no reference-held fixtures: parity unpinned, like the path."""
+import numpy as np
+import pytest
+from common import Case, CubeCase
+from groups import check_group, check_dyn_core, check_fv_dynamics, check_tracer, dot_product_step
+from oracle import TL, AD, NL
+
+SPLIT10 = dict(hord_vt=10, hord_tm=10, hord_dp=10, hord_tr=10)      # perturbation schemes stay at their default (2; 1 in the sponge)
+SPLIT8 = dict(hord_vt=8, hord_tm=8, hord_dp=8, hord_tr=8, hord_vt_pert=333, hord_tm_pert=333, hord_dp_pert=333, hord_tr_pert=333)
+
+
+@pytest.fixture(scope="module", params=["h10", "h8"])
+def case(request):
+    kw = SPLIT10 if request.param == "h10" else SPLIT8
+    return Case(nx=12, ny=10, npz=12, n_split=2, k_split=2, dt=1800.0, backend="emul", nq=2, **kw)      # 12 levels: sponge + regular
+
+
+@pytest.mark.parametrize("mode", [TL, AD])
+def test_d_sw_group(case, mode):
+    check_group(case, "d_sw", mode, 1e-12 if mode == TL else 1e-11)
+
+
+@pytest.mark.parametrize("mode", [TL, AD])
+def test_dyn_core(case, mode):
+    check_dyn_core(case, mode, 1e-10)
+
+
+@pytest.mark.parametrize("mode", [TL, AD])
+def test_tracer_2d(case, mode):
+    check_tracer(case, mode, 1e-11)
+
+
+@pytest.mark.parametrize("mode", [TL, AD])
+def test_fv_dynamics(case, mode):
+    check_fv_dynamics(case, mode, 1e-10)
+
+
+def test_dot_product(case):
+    lhs, rhs = dot_product_step(case)
+    assert abs(lhs - rhs) <= 1e-12 * abs(lhs), (lhs, rhs)
+
+
+def test_step_nl(case):
+    """f2: the nonlinear step runs the TRAJECTORY schemes (monotone here), as the reference's step_nl does"""
+    from groups import check_step_nl
+    check_step_nl(case, 1e-10)
+
+
+def test_trajectory_differs_from_the_unsplit_one():
+    """the second pass does something: the nonlinear step with hord 10 is not the one with hord 2"""
+    from groups import step_state
+    out = []
+    for kw in (SPLIT10, {}):
+        c = Case(nx=12, ny=10, npz=12, n_split=2, k_split=1, dt=1800.0, backend="emul", oracle=False, **kw)
+        T, _ = step_state(c)
+        for n in ("u", "v", "pt", "delp"):
+            c.dy.put(n, T[n][None], 0)
+        c.dy.step_nl()
+        out.append({n: c.dy.get(n, 0)[0].copy() for n in ("pt", "delp")})
+    a, b = out
+    assert max(np.max(np.abs(a[n] - b[n])) / np.max(np.abs(b[n])) for n in a) > 1e-7
+
+
+# ---- cube faces: the three cells each side of a cube edge have their own monotone slopes (tp_core_tlm.F90:828-942)
+@pytest.fixture(scope="module", params=["h10", "h8"])
+def fcase(request):
+    kw = SPLIT10 if request.param == "h10" else SPLIT8
+    return Case(nx=12, ny=12, npz=12, n_split=2, dt=1800.0, backend="emul", face=2, nq=2, **kw)
+
+
+@pytest.mark.parametrize("mode", [TL, AD])
+def test_face_d_sw_group(fcase, mode):
+    check_group(fcase, "d_sw", mode, 1e-12 if mode == TL else 1e-11)
+
+
+@pytest.mark.parametrize("mode", [TL, AD])
+def test_face_tracer(fcase, mode):
+    check_tracer(fcase, mode, 1e-11 if mode == TL else 1e-10)
+
+
+@pytest.fixture(scope="module")
+def ccase():
+    return CubeCase(n=8, npz=12, n_split=2, k_split=2, backend="emul", oracle=True, nq=2, **SPLIT10)
+
+
+@pytest.mark.parametrize("mode", [TL, AD])
+def test_cube_fv_dynamics(ccase, mode):
+    from groups import cube_check_fv_dynamics
+    cube_check_fv_dynamics(ccase, mode, 1e-10)
+
+
+def test_cube_step_dot_product(ccase):
+    from groups import cube_dot_product_step
+    lhs, rhs = cube_dot_product_step(ccase)
+    assert abs(lhs - rhs) <= 1e-12 * abs(lhs), (lhs, rhs)
+
+
+# ---- non-hydrostatic: w transport (hord_vt) and the height transport of update_dz_d (the global hord_tm, nh_utils_tlm.F90:496-560)
+@pytest.fixture(scope="module")
+def nhcase():
+    return Case(nx=10, ny=8, npz=12, n_split=2, k_split=2, dt=1200.0, nq=2, backend="emul", hydrostatic=0, **SPLIT10)
+
+
+def test_nh_fv_dynamics(nhcase):
+    import nh_checks as N
+    N.check_nh_fv_tangent(nhcase)
+    N.check_nh_fv_adjoint(nhcase)
+    N.check_nh_fv_dot_product(nhcase)
+
+
+def test_nh_cube():
+    import nh_checks as N
+    c = CubeCase(n=12, npz=11, n_split=2, k_split=1, dt=600.0, nq=1, backend="emul", oracle=True, hydrostatic=0, **SPLIT10)
+    N.cube_check_nh_fv(c, TL)
+    N.cube_check_nh_fv(c, AD)
+    N.cube_check_nh_dot_product(c)
