@@ -66,6 +66,9 @@ HD double val(const Dual& a) { return a.v; }
 // sw_core_tlm.F90:2436-2452)
 HD double combine(double a, double) { return a; }
 HD Dual combine(const Dual& a, const Dual& b) { return Dual(a.v, b.d); }
+// the value replaced, the tangents kept (split schemes: the nonlinear routine's result over the tangent routine's, sw_core_tlm.F90:1987-2002)
+HD void set_val(double& a, double x) { a = x; }
+HD void set_val(Dual& a, double x) { a.v = x; }
 
 // Forward-mode scalar with N tangent directions: the joint adjoint launcher (exec.h) seeds one direction per stage
 // input, so one evaluation of an output point yields its derivatives with respect to every input at once.  All loops
@@ -94,6 +97,7 @@ template <int N> HD DualV<N> dexp(const DualV<N>& a) { DualV<N> r; const double 
 template <int N> HD DualV<N> dsqrt(const DualV<N>& a) { DualV<N> r; const double sq = sqrt(a.v); r.v = sq; for (int n = 0; n < N; ++n) r.d[n] = a.v == 0.0 ? 0.0 : a.d[n] / (2.0 * sq); return r; }
 template <int N> HD double val(const DualV<N>& a) { return a.v; }
 template <int N> HD DualV<N> combine(const DualV<N>& a, const DualV<N>& b) { DualV<N> r = b; r.v = a.v; return r; }
+template <int N> HD void set_val(DualV<N>& a, double x) { a.v = x; }
 
 // ------------------------------------------------------------------ geometry
 // All 2-D planes share one padded index map: (isd:ied+1, jsd:jed+1), isd = 1-ng, ng = 3.
@@ -142,7 +146,7 @@ struct LevelParams {
   int hord_tm_g;            // flagstruct%hord_tm as passed to UPDATE_DZ_D for all npz+1 interfaces (dyn_core_tlm.F90:1091): no sponge override
   // trajectory schemes (split_hord): where one differs from the scheme above, that transport's VALUES come from a second, values-only
   // pass with this scheme and the trajectory damping (sw_core_tlm.F90:1664-1682); may be monotone (8, 10)
-  int hord_vt_t, hord_tm_t, hord_dp_t, hord_tr_t, hord_tm_g_t;
+  int hord_mt_t, hord_vt_t, hord_tm_t, hord_dp_t, hord_tr_t, hord_tm_g_t;
   int nord, nord_v, nord_w, nord_t, nord_v_pert;
   double d2_divg, damp_vt, damp_w, damp_t, d_con, damp_vt_pert;
   // tracer_2d sub-cycling of the current call (fv_tracer2d_tlm.F90:1306-1345): sub-steps this level takes and 1/that

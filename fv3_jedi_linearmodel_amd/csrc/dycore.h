@@ -68,8 +68,7 @@ struct Arena {
 
 typedef fv3lm_options Options;   // include/fv3lm.h
 
-// Per-level selection, dyn_core_tlm.F90:741-921.  Returns false on a trajectory/perturbation split of hord_mt at level k
-// (xtp_u / ytp_v with two schemes: not built); the fv_tp_2d transports carry both schemes.
+// Per-level selection, dyn_core_tlm.F90:741-921: both the schemes the tangent / adjoint is taken of and the trajectory's.
 inline bool resolve_level(const Options& o, int k, int npz, LevelParams& lp) {
   int hord_m = o.hord_mt, hord_t = o.hord_tm, hord_v = o.hord_vt, hord_p = o.hord_dp;
   int nord_k = o.nord, nord_v = (2 > o.nord) ? o.nord : 2;
@@ -119,11 +118,11 @@ inline bool resolve_level(const Options& o, int k, int npz, LevelParams& lp) {
   }
   lp.hord_mt = hmp; lp.hord_vt = hvp; lp.hord_tm = htp; lp.hord_dp = hpp; lp.hord_tr = o.hord_tr_pert;
   lp.hord_tm_g = o.hord_tm_pert;
-  lp.hord_vt_t = hord_v; lp.hord_tm_t = hord_t; lp.hord_dp_t = hord_p; lp.hord_tr_t = o.hord_tr; lp.hord_tm_g_t = o.hord_tm;
+  lp.hord_mt_t = hord_m; lp.hord_vt_t = hord_v; lp.hord_tm_t = hord_t; lp.hord_dp_t = hord_p; lp.hord_tr_t = o.hord_tr; lp.hord_tm_g_t = o.hord_tm;
   lp.nord = nord_k; lp.nord_v = nord_v; lp.nord_w = nord_w; lp.nord_t = nord_t; lp.nord_v_pert = nord_v_pert;
   lp.d2_divg = d2_divg; lp.damp_vt = damp_vt; lp.damp_w = damp_w; lp.damp_t = damp_t; lp.d_con = d_con_k;
   lp.damp_vt_pert = damp_vt_pert;
-  return hord_m == hmp;
+  return true;
 }
 
 struct Op {
@@ -584,17 +583,17 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
   //   tracer advection: the perturbation runs with the trajectory scheme (no split_hord recompute); hord_tr_ks_* are read by the
   //   reference's namelist but used nowhere on the path (fv_control_tlmadm.F90:166-172), so they are accepted and ignored here too
   //   advection schemes: the tangent / adjoint exists for 1, 2, 333 (tp_core_tlm.F90:2393-2487); a trajectory scheme that differs
-  //   (split_hord) gives the values in a second pass and may also be the monotone 8 or 10 -- for the fv_tp_2d transports; the
-  //   momentum fluxes xtp_u / ytp_v (hord_mt) with two schemes are not built
+  //   (split_hord) gives the values -- a second pass of fv_tp_2d, a second evaluation inside the xtp_u / ytp_v stage -- and may
+  //   also be the monotone 8 or 10
   lev_host.resize(npz + 1);
   for (int k = 1; k <= npz; ++k) {
-    if (!resolve_level(o, k, npz, lev_host[k - 1])) { err = "trajectory/perturbation hord split (split_hord) of hord_mt (xtp_u / ytp_v) not supported"; return false; }
+    resolve_level(o, k, npz, lev_host[k - 1]);
     const LevelParams& l = lev_host[k - 1];
     for (int h : {l.hord_mt, l.hord_vt, l.hord_tm, l.hord_dp, l.hord_tr, l.hord_tm_g})
       if (h != 1 && h != 2 && h != 333) { err = "perturbation hord must be 1, 2 or 333 (the schemes the TL/AD reference implements)"; return false; }
-    for (int h : {l.hord_vt_t, l.hord_tm_t, l.hord_dp_t, l.hord_tr_t, l.hord_tm_g_t})
+    for (int h : {l.hord_mt_t, l.hord_vt_t, l.hord_tm_t, l.hord_dp_t, l.hord_tr_t, l.hord_tm_g_t})
       if (h != 1 && h != 2 && h != 333 && h != 8 && h != 10) { err = "trajectory hord must be 1, 2, 333 (differentiated) or, with a different perturbation scheme, 8 or 10"; return false; }
-    const int pairs[5][2] = {{l.hord_vt_t, l.hord_vt}, {l.hord_tm_t, l.hord_tm}, {l.hord_dp_t, l.hord_dp}, {l.hord_tr_t, l.hord_tr}, {l.hord_tm_g_t, l.hord_tm_g}};
+    const int pairs[6][2] = {{l.hord_mt_t, l.hord_mt}, {l.hord_vt_t, l.hord_vt}, {l.hord_tm_t, l.hord_tm}, {l.hord_dp_t, l.hord_dp}, {l.hord_tr_t, l.hord_tr}, {l.hord_tm_g_t, l.hord_tm_g}};
     for (auto& pr : pairs) if (pr[0] == pr[1] && pr[0] != 1 && pr[0] != 2 && pr[0] != 333) { err = "hord must be 1, 2 or 333 where trajectory and perturbation share the scheme"; return false; }
   }
 #ifndef FV3LM_HOST_EMUL

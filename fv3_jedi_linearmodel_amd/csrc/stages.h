@@ -198,6 +198,52 @@ HD T tp_uv_flux(int iord, bool face, int m, int n1, bool row_edge, const Q& q, c
   return q(m) + (1. + cfl) * (bl + cfl * (bl + br));
 }
 
+// The monotone slopes of the NONLINEAR xtp_u / ytp_v, iord 8 / 10 (sw_core_tlm.F90:4620-5041, :5361-5865): as mono_blbr with the
+// momentum fluxes' own edge treatment (D-grid metric, two-sided edge value unclamped, zero slopes next to a face corner, pert_ppm
+// on cells 2 and n1-2 only) and their own 2-delta-x test.  Values only (split_hord, :1987-2002).
+template <class Q, class D>
+HD void uv_mono_blbr(int iord, bool face, int i, int n1, bool row_edge, const Q& q, const D& dd, double& bl, double& br) {
+  if (face && (i <= 2 || i >= n1 - 2)) {
+    auto two_sided = [&](int e) {
+      return 0.5 * ((2. * dd(e - 1) + dd(e - 2)) * q(e - 1) - dd(e - 1) * q(e - 2)) / (dd(e - 1) + dd(e - 2)) +
+             0.5 * ((2. * dd(e) + dd(e + 1)) * q(e) - dd(e) * q(e + 1)) / (dd(e) + dd(e + 1));
+    };
+    if (row_edge && (i <= 1 || i >= n1 - 1)) { bl = 0.; br = 0.; return; }
+    if (i == 0) { bl = MONO_S14 * mono_dm(q, -1) - MONO_S11 * (q(0) - q(-1)); br = two_sided(1) - q(0); }
+    else if (i == 1) { bl = two_sided(1) - q(1); br = MONO_S15 * q(1) + MONO_S11 * q(2) - MONO_S14 * mono_dm(q, 2) - q(1); }
+    else if (i == 2) { bl = MONO_S15 * q(1) + MONO_S11 * q(2) - MONO_S14 * mono_dm(q, 2) - q(2); br = mono_al(q, 3) - q(2); mono_pert_ppm(bl, br); }
+    else if (i == n1 - 2) { bl = mono_al(q, n1 - 2) - q(n1 - 2); br = MONO_S15 * q(n1 - 1) + MONO_S11 * q(n1 - 2) + MONO_S14 * mono_dm(q, n1 - 2) - q(n1 - 2); mono_pert_ppm(bl, br); }
+    else if (i == n1 - 1) { bl = MONO_S15 * q(n1 - 1) + MONO_S11 * q(n1 - 2) + MONO_S14 * mono_dm(q, n1 - 2) - q(n1 - 1); br = two_sided(n1) - q(n1 - 1); }
+    else { bl = two_sided(n1) - q(n1); br = MONO_S11 * (q(n1 + 1) - q(n1)) - MONO_S14 * mono_dm(q, n1 + 1); }
+    return;
+  }
+  const double qi = q(i), al0 = mono_al(q, i), al1 = mono_al(q, i + 1);
+  if (iord == 8) {
+    const double xt = 2. * mono_dm(q, i);
+    bl = -mono_sign(fmin(fabs(xt), fabs(al0 - qi)), xt);
+    br = mono_sign(fmin(fabs(xt), fabs(al1 - qi)), xt);
+    return;
+  }
+  bl = al0 - qi; br = al1 - qi;
+  if (fabs(mono_dm(q, i)) < MONO_NEAR_ZERO) {
+    if (fabs(mono_dm(q, i - 1)) + fabs(mono_dm(q, i + 1)) < MONO_NEAR_ZERO) { bl = 0.; br = 0.; }
+  } else if (fabs(3. * (bl + br)) > fabs(bl - br)) {
+    const double pmp_1 = -(2. * (q(i + 1) - q(i))), lac_1 = pmp_1 + 1.5 * (q(i + 2) - q(i + 1));
+    bl = fmin(fmax(0., fmax(pmp_1, lac_1)), fmax(bl, fmin(0., fmin(pmp_1, lac_1))));
+    const double pmp_2 = 2. * (q(i) - q(i - 1)), lac_2 = pmp_2 - 1.5 * (q(i - 1) - q(i - 2));
+    br = fmin(fmax(0., fmax(pmp_2, lac_2)), fmax(br, fmin(0., fmin(pmp_2, lac_2))));
+  }
+}
+template <class Q, class D>
+HD double tp_uv_flux_traj(int iord, bool face, int m, int n1, bool row_edge, const Q& q, const D& dd, double cc, double rd_m, double rd_0) {
+  if (iord != 8 && iord != 10) return tp_uv_flux<double>(iord, face, m, n1, row_edge, q, dd, cc, rd_m, rd_0);
+  double bl, br;
+  if (cc > 0.) { uv_mono_blbr(iord, face, m - 1, n1, row_edge, q, dd, bl, br); const double cfl = cc * rd_m; return q(m - 1) + (1. - cfl) * (br - cfl * (bl + br)); }
+  uv_mono_blbr(iord, face, m, n1, row_edge, q, dd, bl, br);
+  const double cfl = cc * rd_0;
+  return q(m) + (1. + cfl) * (bl + cfl * (bl + br));
+}
+
 // ===================================================================== c_sw
 // d2a2c_vect A: D-grid winds -> A-grid (sw_core_tlm.F90:6505-6611); within 3 cells of a face edge the
 // 4-point Lagrange interpolation gives way to 2-point averages (:6548-6602, npt = 4).
@@ -595,7 +641,7 @@ struct DswRa {   // sw_core_tlm.F90:2969-2978
 enum HordSel { HORD_MT = 0, HORD_VT, HORD_TM, HORD_DP, HORD_TR, HORD_TM_G };
 // the trajectory scheme of the same transport (== hord_of unless the schemes are split)
 HD int hord_traj_of(const LevelParams& l, int sel) {
-  return sel == HORD_MT ? l.hord_mt : sel == HORD_VT ? l.hord_vt_t : sel == HORD_TM ? l.hord_tm_t : sel == HORD_DP ? l.hord_dp_t : sel == HORD_TM_G ? l.hord_tm_g_t : l.hord_tr_t;
+  return sel == HORD_MT ? l.hord_mt_t : sel == HORD_VT ? l.hord_vt_t : sel == HORD_TM ? l.hord_tm_t : sel == HORD_DP ? l.hord_dp_t : sel == HORD_TM_G ? l.hord_tm_g_t : l.hord_tr_t;
 }
 HD int hord_of(const LevelParams& l, int sel) {
   return sel == HORD_MT ? l.hord_mt : sel == HORD_VT ? l.hord_vt : sel == HORD_TM ? l.hord_tm : sel == HORD_DP ? l.hord_dp : sel == HORD_TM_G ? l.hord_tm_g : l.hord_tr;
@@ -854,6 +900,13 @@ struct DswKeD {
     T fv = tp_uv_flux<T>(iord, F, j, npy, i == 1 || i == npx, qv, ddy, vb, MET(rdy, i, j - 1), MET(rdy, i, j));
     LineX<A, 2> qu{a, c.g, j, 0}; MetX ddx{c.m.dx, c, tile, j};
     T fu = tp_uv_flux<T>(iord, F, i, npx, j == 1 || j == npy, qu, ddx, ub, MET(rdx, i - 1, j), MET(rdx, i, j));
+    const int iord_t = c.lev[k - 1].hord_mt_t;
+    if (iord_t != iord) {      // split_hord: the nonlinear fluxes of the trajectory scheme for the values (sw_core_tlm.F90:1987-2002, :2059-2072)
+      auto qvd = [&](int jj) { return val(qv(jj)); };
+      auto qud = [&](int ii) { return val(qu(ii)); };
+      set_val(fv, tp_uv_flux_traj(iord_t, F, j, npy, i == 1 || i == npx, qvd, ddy, val(vb), MET(rdy, i, j - 1), MET(rdy, i, j)));
+      set_val(fu, tp_uv_flux_traj(iord_t, F, i, npx, j == 1 || j == npy, qud, ddx, val(ub), MET(rdx, i - 1, j), MET(rdx, i, j)));
+    }
     o[0] = 0.5 * (vb * fv + ub * fu);
   }
 };

@@ -108,7 +108,7 @@ struct LevelParams {
   // (nord_v, damp_vt), perturbation with the *_pert pair (sw_core_tlm.F90:2436-2452, :2502-2530).
   int nord_v_pert; double damp_vt_pert;
   // perturbation advection schemes where they differ from the trajectory's (split_hord): fv_tp_2d runs twice then (tp_core.hpp fv_tp_2d_split)
-  int hord_vt_pert, hord_tm_pert, hord_dp_pert;
+  int hord_mt_pert, hord_vt_pert, hord_tm_pert, hord_dp_pert;
 };
 
 struct Flags {

@@ -84,8 +84,8 @@ inline bool level_params(const DampOpts& o, int k, int npz, LevelParams& lp) {
   lp.nord = nord_k; lp.nord_v = nord_v; lp.nord_w = nord_w; lp.nord_t = nord_t;
   lp.d2_divg = d2_divg; lp.damp_vt = damp_vt; lp.damp_w = damp_w; lp.damp_t = damp_t; lp.d_con = d_con_k;
   lp.nord_v_pert = nord_v_pert; lp.damp_vt_pert = damp_vt_pert;
-  lp.hord_vt_pert = hord_v_pert; lp.hord_tm_pert = hord_t_pert; lp.hord_dp_pert = hord_p_pert;
-  return hord_m == hord_m_pert;      // xtp_u / ytp_v with split schemes: not restated
+  lp.hord_mt_pert = hord_m_pert; lp.hord_vt_pert = hord_v_pert; lp.hord_tm_pert = hord_t_pert; lp.hord_dp_pert = hord_p_pert;
+  return true;
 }
 
 // Doubly-periodic wrap of every point of the padded plane that is outside 1..nx × 1..ny.

@@ -636,6 +636,39 @@ void compute_divergence_damping(int nord, double d2_bg, double d4_bg, double ddd
   }
 }
 
+// split_hord for the momentum fluxes (sw_core_tlm.F90:1987-2002 ytp_v, :2059-2072 xtp_u): the _TLM routine with the perturbation scheme,
+// then the nonlinear routine with the trajectory scheme -- which may be the monotone 8 / 10 (tp_mono.hpp uv_line_mono) -- for the values.
+inline void xtp_u_traj(const Arr2<double>& c, const Arr2<double>& u, Arr2<double>& flux, int iord, const Grid& g, const Bounds& bd) {
+  if (iord != 8 && iord != 10) { xtp_u<double>(c, u, flux, iord, g, bd); return; }
+  for (int j = bd.js; j <= bd.je + 1; ++j)
+    uv_line_mono(iord, bd.is, bd.ie, bd.npx, bd.any_edge(), bd.edge_w, bd.edge_e, bd.any_edge() && (j == 1 || j == bd.npy), [&](int i) { return u(i, j); },
+                 [&](int i) { return c(i, j); }, [&](int i) { return g.dx(i, j); }, [&](int i) { return g.rdx(i, j); }, [&](int i, double f) { flux(i, j) = f; });
+}
+inline void ytp_v_traj(const Arr2<double>& c, const Arr2<double>& v, Arr2<double>& flux, int jord, const Grid& g, const Bounds& bd) {
+  if (jord != 8 && jord != 10) { ytp_v<double>(c, v, flux, jord, g, bd); return; }
+  for (int i = bd.is; i <= bd.ie + 1; ++i)
+    uv_line_mono(jord, bd.js, bd.je, bd.npy, bd.any_edge(), bd.edge_s, bd.edge_n, bd.any_edge() && (i == 1 || i == bd.npx), [&](int j) { return v(i, j); },
+                 [&](int j) { return c(i, j); }, [&](int j) { return g.dy(i, j); }, [&](int j) { return g.rdy(i, j); }, [&](int j, double f) { flux(i, j) = f; });
+}
+template <class T>
+void xtp_u_split(const Arr2<T>& c, const Arr2<T>& u, Arr2<T>& flux, int iord, int iord_pert, const Grid& g, const Bounds& bd) {
+  if (iord == iord_pert) { xtp_u(c, u, flux, iord, g, bd); return; }
+  xtp_u(c, u, flux, iord_pert, g, bd);
+  const Arr2<double> cd = values_of(c), ud = values_of(u);
+  Arr2<double> fd(bd);
+  xtp_u_traj(cd, ud, fd, iord, g, bd);
+  for (int j = bd.js; j <= bd.je + 1; ++j) for (int i = bd.is; i <= bd.ie + 1; ++i) set_val(flux(i, j), fd(i, j));
+}
+template <class T>
+void ytp_v_split(const Arr2<T>& c, const Arr2<T>& v, Arr2<T>& flux, int jord, int jord_pert, const Grid& g, const Bounds& bd) {
+  if (jord == jord_pert) { ytp_v(c, v, flux, jord, g, bd); return; }
+  ytp_v(c, v, flux, jord_pert, g, bd);
+  const Arr2<double> cd = values_of(c), vd = values_of(v);
+  Arr2<double> fd(bd);
+  ytp_v_traj(cd, vd, fd, jord, g, bd);
+  for (int j = bd.js; j <= bd.je + 1; ++j) for (int i = bd.is; i <= bd.ie + 1; ++i) set_val(flux(i, j), fd(i, j));
+}
+
 // d_sw, hydrostatic, inline_q=.false., d_con<=1e-5, grid_type<3.
 // sw_core_tlm.F90:2533-3617 (_TLM :1047-2531).  In/out: delp, pt, u, v (updated on the compute
 // domain), xflux,yflux,cx,cy accumulators; in: uc, vc, ua, va, divg_d; out: crx_adv.. yfx_adv.
@@ -813,7 +846,7 @@ void d_sw(Arr2<T>& delp, Arr2<T>& pt, Arr2<T>& u, Arr2<T>& v, Arr2<T>& uc, Arr2<
     if (bd.edge_e) vb(npx, j) = dt4 * (-vt(npx - 2, j) + 3. * (vt(npx - 1, j) + vt(npx, j)) - vt(npx + 1, j));
   }
   if (bd.edge_n) for (int i = is; i <= ie + 1; ++i) vb(i, npy) = dt5 * (vt(i - 1, npy) + vt(i, npy));
-  ytp_v(vb, v, ub, lp.hord_mt, g, bd);
+  ytp_v_split(vb, v, ub, lp.hord_mt, lp.hord_mt_pert, g, bd);
   for (int j = js; j <= je + 1; ++j)
     for (int i = is; i <= ie + 1; ++i) ke(i, j) = vb(i, j) * ub(i, j);
   if (bd.edge_w) for (int j = js; j <= je + 1; ++j) ub(1, j) = dt5 * (ut(1, j - 1) + ut(1, j));
@@ -826,7 +859,7 @@ void d_sw(Arr2<T>& delp, Arr2<T>& pt, Arr2<T>& u, Arr2<T>& v, Arr2<T>& uc, Arr2<
     }
   }
   if (bd.edge_e) for (int j = js; j <= je + 1; ++j) ub(npx, j) = dt5 * (ut(npx, j - 1) + ut(npx, j));
-  xtp_u(ub, u, vb, lp.hord_mt, g, bd);
+  xtp_u_split(ub, u, vb, lp.hord_mt, lp.hord_mt_pert, g, bd);
   for (int j = js; j <= je + 1; ++j)
     for (int i = is; i <= ie + 1; ++i) ke(i, j) = 0.5 * (ke(i, j) + ub(i, j) * vb(i, j));
   {   // KE at the 4 corners of the face (:3258-3273)

@@ -121,4 +121,86 @@ inline void yppm_mono(Arr2<double>& flux, const Arr2<double>& q, const Arr2<doub
                   [&](int j) { return g.dya(i, j); }, [&](int j, double f) { flux(i, j) = f; });
 }
 
+// ---- xtp_u / ytp_v, iord = 8 and 10 of the NONLINEAR routines (sw_core_tlm.F90:4620-5041 for x, :5361-5865 for y): the same
+// monotone slopes with their own edge treatment (no clamping of the two-sided edge value, zero slopes next to a corner of the
+// face, pert_ppm on cells 2 and np-2 only) and their own form of the 2-delta-x test of iord 10.  One line routine for both
+// directions; dd = dx or dy, rd = rdx or rdy along the line, c = the displacement (not a Courant number: cfl = c * rd(upwind)).
+template <class FQ, class FC, class FD, class FR, class FOut>
+void uv_line_mono(int iord, int first, int last, int np, bool any_edge, bool edge_lo, bool edge_hi, bool row_edge, const FQ& q, const FC& c,
+                  const FD& dd, const FR& rd, const FOut& flux) {
+  assert(iord == 8 || iord == 10);
+  int is3 = first - 1, ie3 = last + 1;
+  if (any_edge) { is3 = std::max(3, first - 1); ie3 = std::min(np - 3, last + 1); }
+  const int lo = first - 4, n = last - first + 10;
+  std::vector<double> dm_(n, 0.), al_(n, 0.), bl_(n, 0.), br_(n, 0.), dq_(n, 0.);
+  auto dm = [&](int i) -> double& { return dm_[i - lo]; };
+  auto al = [&](int i) -> double& { return al_[i - lo]; };
+  auto bl = [&](int i) -> double& { return bl_[i - lo]; };
+  auto br = [&](int i) -> double& { return br_[i - lo]; };
+  auto dq = [&](int i) -> double& { return dq_[i - lo]; };
+  for (int i = first - 2; i <= last + 2; ++i) {      // :4622-4666
+    const double xt = 0.25 * (q(i + 1) - q(i - 1));
+    const double hi = std::max(std::max(q(i - 1), q(i)), q(i + 1)) - q(i), lw = q(i) - std::min(std::min(q(i - 1), q(i)), q(i + 1));
+    dm(i) = f_sign(std::min(std::min(std::fabs(xt), hi), lw), xt);
+  }
+  for (int i = first - 3; i <= last + 2; ++i) dq(i) = q(i + 1) - q(i);
+  for (int i = is3; i <= ie3 + 1; ++i) al(i) = 0.5 * (q(i - 1) + q(i)) + mono_r3 * (dm(i - 1) - dm(i));
+  if (iord == 8) {                                   // :4674-4709
+    for (int i = is3; i <= ie3; ++i) {
+      const double xt = 2. * dm(i);
+      bl(i) = -f_sign(std::min(std::fabs(xt), std::fabs(al(i) - q(i))), xt);
+      br(i) = f_sign(std::min(std::fabs(xt), std::fabs(al(i + 1) - q(i))), xt);
+    }
+  } else {                                           // :4781-4890
+    for (int i = is3; i <= ie3; ++i) {
+      bl(i) = al(i) - q(i);
+      br(i) = al(i + 1) - q(i);
+      if (std::fabs(dm(i)) < mono_near_zero) {
+        if (std::fabs(dm(i - 1)) + std::fabs(dm(i + 1)) < mono_near_zero) { bl(i) = 0.; br(i) = 0.; }
+      } else if (std::fabs(3. * (bl(i) + br(i))) > std::fabs(bl(i) - br(i))) {
+        const double pmp_1 = -(2. * dq(i)), lac_1 = pmp_1 + 1.5 * dq(i + 1);
+        bl(i) = std::min(std::max(0., std::max(pmp_1, lac_1)), std::max(bl(i), std::min(0., std::min(pmp_1, lac_1))));
+        const double pmp_2 = 2. * dq(i - 1), lac_2 = pmp_2 - 1.5 * dq(i - 2);
+        br(i) = std::min(std::max(0., std::max(pmp_2, lac_2)), std::max(br(i), std::min(0., std::min(pmp_2, lac_2))));
+      }
+    }
+  }
+  auto two_sided = [&](int e) {     // x0l + x0r between cells e-1 and e (:4907-4912)
+    return 0.5 * ((2. * dd(e - 1) + dd(e - 2)) * q(e - 1) - dd(e - 1) * q(e - 2)) / (dd(e - 1) + dd(e - 2)) +
+           0.5 * ((2. * dd(e) + dd(e + 1)) * q(e) - dd(e) * q(e + 1)) / (dd(e) + dd(e + 1));
+  };
+  if (any_edge && edge_lo) {        // :4893-4917
+    br(2) = al(3) - q(2);
+    double xt = mono_s15 * q(1) + mono_s11 * q(2) - mono_s14 * dm(2);
+    bl(2) = xt - q(2);
+    br(1) = xt - q(1);
+    if (row_edge) { bl(0) = 0.; br(0) = 0.; bl(1) = 0.; br(1) = 0.; }
+    else {
+      bl(0) = mono_s14 * dm(-1) - mono_s11 * dq(-1);
+      xt = two_sided(1);
+      br(0) = xt - q(0);
+      bl(1) = xt - q(1);
+    }
+    pert_ppm_std(1, &bl(2), &br(2));
+  }
+  if (any_edge && edge_hi) {        // :4918-4946
+    bl(np - 2) = al(np - 2) - q(np - 2);
+    double xt = mono_s15 * q(np - 1) + mono_s11 * q(np - 2) + mono_s14 * dm(np - 2);
+    br(np - 2) = xt - q(np - 2);
+    bl(np - 1) = xt - q(np - 1);
+    if (row_edge) { bl(np - 1) = 0.; br(np - 1) = 0.; bl(np) = 0.; br(np) = 0.; }
+    else {
+      br(np) = mono_s11 * dq(np) - mono_s14 * dm(np + 1);
+      xt = two_sided(np);
+      br(np - 1) = xt - q(np - 1);
+      bl(np) = xt - q(np);
+    }
+    pert_ppm_std(1, &bl(np - 2), &br(np - 2));
+  }
+  for (int i = first; i <= last + 1; ++i) {          // :5028-5038
+    if (c(i) > 0.) { const double cfl = c(i) * rd(i - 1); flux(i, q(i - 1) + (1. - cfl) * (br(i - 1) - cfl * (bl(i - 1) + br(i - 1)))); }
+    else { const double cfl = c(i) * rd(i); flux(i, q(i) + (1. + cfl) * (bl(i) + cfl * (bl(i) + br(i)))); }
+  }
+}
+
 }  // namespace orc

@@ -8,7 +8,7 @@ from common import Case
     (dict(nord=2), "nord"),
     (dict(hord_dp=10, hord_dp_pert=10), "hord"),          # the tangent / adjoint exists for 1, 2, 333 only
     (dict(hord_dp=5), "hord"),                            # trajectory schemes built: 1, 2, 333, 8, 10
-    (dict(hord_mt=2, hord_mt_pert=1), "split_hord"),      # xtp_u / ytp_v with two schemes: not built
+    (dict(hord_mt=6, hord_mt_pert=2), "hord"),
     (dict(hydrostatic=0, a_imp=0.4), "a_imp"),
     (dict(kord_tm=-9), "kord"),
     (dict(kord_tr=8), "kord"),

@@ -9,8 +9,8 @@ from common import Case, CubeCase
 from groups import check_group, check_dyn_core, check_fv_dynamics, check_tracer, dot_product_step
 from oracle import TL, AD, NL
 
-SPLIT10 = dict(hord_vt=10, hord_tm=10, hord_dp=10, hord_tr=10)      # perturbation schemes stay at their default (2; 1 in the sponge)
-SPLIT8 = dict(hord_vt=8, hord_tm=8, hord_dp=8, hord_tr=8, hord_vt_pert=333, hord_tm_pert=333, hord_dp_pert=333, hord_tr_pert=333)
+SPLIT10 = dict(hord_mt=10, hord_vt=10, hord_tm=10, hord_dp=10, hord_tr=10)      # perturbation schemes stay at their default (2; 1 in the sponge)
+SPLIT8 = dict(hord_mt=8, hord_vt=8, hord_tm=8, hord_dp=8, hord_tr=8, hord_mt_pert=333, hord_vt_pert=333, hord_tm_pert=333, hord_dp_pert=333, hord_tr_pert=333)
 
 
 @pytest.fixture(scope="module", params=["h10", "h8"])

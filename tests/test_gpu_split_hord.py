@@ -6,8 +6,8 @@ from oracle import TL, AD
 
 pytestmark = pytest.mark.gpu
 
-SPLIT10 = dict(hord_vt=10, hord_tm=10, hord_dp=10, hord_tr=10)
-SPLIT8 = dict(hord_vt=8, hord_tm=8, hord_dp=8, hord_tr=8, hord_vt_pert=333, hord_tm_pert=333, hord_dp_pert=333, hord_tr_pert=333)
+SPLIT10 = dict(hord_mt=10, hord_vt=10, hord_tm=10, hord_dp=10, hord_tr=10)
+SPLIT8 = dict(hord_mt=8, hord_vt=8, hord_tm=8, hord_dp=8, hord_tr=8, hord_mt_pert=333, hord_vt_pert=333, hord_tm_pert=333, hord_dp_pert=333, hord_tr_pert=333)
 
 
 @pytest.mark.parametrize("kw", [SPLIT10, SPLIT8], ids=["h10", "h8"])
