@@ -102,7 +102,9 @@ def cpu_baseline(args, opt):
 def scheme_string(o, nh):
     """the scheme flags actually in force (fv3lm_options of the instance that was timed)"""
     sponge = ("%d/%d/%d/%d below level %d" % (o.hord_mt_ks_pert, o.hord_vt_ks_pert, o.hord_tm_ks_pert, o.hord_dp_ks_pert, o.n_sponge_pert)) if o.hord_ks_pert else "off"
-    s = "hord mt/vt/tm/dp/tr=%d/%d/%d/%d/%d (sponge: %s), kord=%d, nord=%d" % (o.hord_mt, o.hord_vt, o.hord_tm, o.hord_dp, o.hord_tr, sponge, abs(o.kord_tm), o.nord)
+    s = "hord mt/vt/tm/dp/tr=%d/%d/%d/%d/%d (sponge: %s), kord=%d, nord=%d" % (o.hord_mt_pert, o.hord_vt_pert, o.hord_tm_pert, o.hord_dp_pert, o.hord_tr_pert, sponge, abs(o.kord_tm), o.nord)
+    if (o.hord_mt, o.hord_vt, o.hord_tm, o.hord_dp, o.hord_tr) != (o.hord_mt_pert, o.hord_vt_pert, o.hord_tm_pert, o.hord_dp_pert, o.hord_tr_pert):
+        s += ", split_hord: trajectory %d/%d/%d/%d/%d" % (o.hord_mt, o.hord_vt, o.hord_tm, o.hord_dp, o.hord_tr)
     if nh:
         s += ", a_imp=%g (%s)" % (o.a_imp, "SIM1" if o.a_imp > 0.999 else "SIM")
     return s
@@ -122,6 +124,8 @@ def main():
     ap.add_argument("--tiles", choices=["cube", "periodic"], default="cube")
     ap.add_argument("--nonhydrostatic", action="store_true",
                     help="BASELINE config 3: w, delz prognostic, nh_core active (hydrostatic = 0); not the headline workload")
+    ap.add_argument("--hord-traj", type=int, default=0,
+                    help="trajectory advection scheme (8 or 10) with the perturbation schemes left at their defaults: split_hord (not the headline configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-host-transport", action="store_true",
                     help="multi-rank rehearsal on ONE GPU (RCCL refuses two ranks per device): gloo process group, halo messages staged "
@@ -197,6 +201,8 @@ def main():
         active = len(cube.faces_of(rank, world)) > 0
         if active:
             nhkw = dict(hydrostatic=0) if args.nonhydrostatic else {}
+            if args.hord_traj:
+                nhkw.update(hord_mt=args.hord_traj, hord_vt=args.hord_traj, hord_tm=args.hord_traj, hord_dp=args.hord_traj, hord_tr=args.hord_traj)
             c = CubeCase(n=args.nx, npz=args.npz, n_split=args.n_split, k_split=args.k_split, dt=args.dt, backend="hip", nq=args.nq,
                          rank=rank, world=world, **nhkw)
             T, P = cube_step_state(c)

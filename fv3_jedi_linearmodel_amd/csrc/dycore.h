@@ -928,7 +928,10 @@ inline void Dycore::build_acoustic() {
   Fld vb = W("vb", npz), ub = W("ub", npz), ke = W("ke", npz);
   { DswKeWindsD s; s.in[0] = uc; s.in[1] = vc; s.in[2] = g.face ? ut : none; s.in[3] = g.face ? vt : none; s.out[0] = vb; s.out[1] = ub; s.orect[0] = s.orect[1] = R(is, ie + 1, js, je + 1); s.dt = dt;
     s.k1 = npz; add_face(P, "d_sw", s, 1); }
-  { DswKeD s; s.in[0] = vb; s.in[1] = ub; s.in[2] = u; s.in[3] = v; s.in[4] = g.face ? ut : none; s.in[5] = g.face ? vt : none; s.dt = dt; s.out[0] = ke; s.orect[0] = R(is, ie + 1, js, je + 1); s.k1 = npz; add_face(P, "d_sw", s, 3); }
+  { bool split_mt = false;
+    for (int k = 0; k < npz; ++k) split_mt = split_mt || level_split(lev_host[k], HORD_MT);
+    auto ke_stage = [&](auto s) { s.in[0] = vb; s.in[1] = ub; s.in[2] = u; s.in[3] = v; s.in[4] = g.face ? ut : none; s.in[5] = g.face ? vt : none; s.dt = dt; s.out[0] = ke; s.orect[0] = R(is, ie + 1, js, je + 1); s.k1 = npz; add_face(P, "d_sw", s, 3); };
+    if (split_mt) ke_stage(DswKeSD{}); else ke_stage(DswKeD{}); }
   Fld wk = W("wk", npz), vorta = W("vort_abs", npz);
   { DswVort s; s.in[0] = u; s.in[1] = v; s.out[0] = wk; s.out[1] = vorta; s.orect[0] = s.orect[1] = R(isd, ied, jsd, jed); s.k1 = npz; add(P, "d_sw", s); }
   Fld da = W("dd_a", npz), db = W("dd_b", npz), dc = W("dd_c", npz), vortb = W("vort_b", npz), ke2 = W("ke2", npz);

@@ -117,14 +117,11 @@ HD double ppm_dq(int iord, bool face, int m, int n1, int k, const D& da, double 
 // the cells within three of it, so the flux at interface m reads q(m-3 .. m+2), inside the three-cell halo like the reference.
 constexpr double MONO_R3 = 1. / 3., MONO_S11 = 11. / 14., MONO_S14 = 4. / 7., MONO_S15 = 3. / 14., MONO_NEAR_ZERO = 1.e-25;
 HD double mono_sign(double a, double b) { return b >= 0. ? fabs(a) : -fabs(a); }     // Fortran SIGN(a, b)
-template <class Q>
-HD double mono_dm(const Q& q, int i) {                                                // :596-640
-  const double a = q(i - 1), b = q(i), c_ = q(i + 1), xt = 0.25 * (c_ - a);
+HD double mono_dm3(double a, double b, double c_) {                                   // dm of the middle cell (:596-640)
+  const double xt = 0.25 * (c_ - a);
   const double hi = fmax(fmax(a, b), c_) - b, lo = b - fmin(fmin(a, b), c_);
   return mono_sign(fmin(fmin(fabs(xt), hi), lo), xt);
 }
-template <class Q>
-HD double mono_al(const Q& q, int i) { return 0.5 * (q(i - 1) + q(i)) + MONO_R3 * (mono_dm(q, i - 1) - mono_dm(q, i)); }   // :641-642
 HD void mono_pert_ppm(double& al, double& ar) {                                       // pert_ppm, iv = 1 (:1893-1913)
   if (al * ar < 0.) {
     const double da1 = al - ar, da2 = da1 * da1, a6da = 3. * (al + ar) * da1;
@@ -132,48 +129,53 @@ HD void mono_pert_ppm(double& al, double& ar) {                                 
     else if (a6da > da2) al = -(2. * ar);
   } else { al = 0.; ar = 0.; }
 }
-template <class Q, class D>
-HD void mono_blbr(int iord, bool face, int i, int n1, const Q& q, const D& da, double& bl, double& br) {
+// the two-sided value on a cube edge between cells e-1 and e: w = q(e-2 .. e+1), metric by absolute index (:833-835)
+template <class D>
+HD double mono_two_sided(const D& da, int e, double w0, double w1, double w2, double w3) {
+  return 0.5 * (((2. * da(e - 1) + da(e - 2)) * w1 - da(e - 1) * w0) / (da(e - 2) + da(e - 1)) + ((2. * da(e) + da(e + 1)) * w2 - da(e) * w3) / (da(e) + da(e + 1)));
+}
+// Slopes of cell i from its five-cell window v[0..4] = q(i-2 .. i+2) (registers; all indices static).
+template <class D>
+HD void mono_blbr(int iord, bool face, int i, int n1, const double* v, const D& da, double& bl, double& br) {
+  const double dm_m = mono_dm3(v[0], v[1], v[2]), dm_0 = mono_dm3(v[1], v[2], v[3]), dm_p = mono_dm3(v[2], v[3], v[4]);
   if (face && (i <= 2 || i >= n1 - 2)) {       // the three cells each side of a cube edge (:828-942)
-    auto two_sided = [&](int e) {
-      double xt = 0.5 * (((2. * da(e - 1) + da(e - 2)) * q(e - 1) - da(e - 1) * q(e - 2)) / (da(e - 2) + da(e - 1)) +
-                         ((2. * da(e) + da(e + 1)) * q(e) - da(e) * q(e + 1)) / (da(e) + da(e + 1)));
-      xt = fmax(xt, fmin(fmin(q(e - 2), q(e - 1)), fmin(q(e), q(e + 1))));
-      return fmin(xt, fmax(fmax(q(e - 2), q(e - 1)), fmax(q(e), q(e + 1))));
-    };
-    if (i == 0) { bl = MONO_S14 * mono_dm(q, -1) + MONO_S11 * (q(-1) - q(0)); br = two_sided(1) - q(0); }
-    else if (i == 1) { bl = two_sided(1) - q(1); br = MONO_S15 * q(1) + MONO_S11 * q(2) - MONO_S14 * mono_dm(q, 2) - q(1); }
-    else if (i == 2) { bl = MONO_S15 * q(1) + MONO_S11 * q(2) - MONO_S14 * mono_dm(q, 2) - q(2); br = mono_al(q, 3) - q(2); }
-    else if (i == n1 - 2) { bl = mono_al(q, n1 - 2) - q(n1 - 2); br = MONO_S15 * q(n1 - 1) + MONO_S11 * q(n1 - 2) + MONO_S14 * mono_dm(q, n1 - 2) - q(n1 - 2); }
-    else if (i == n1 - 1) { bl = MONO_S15 * q(n1 - 1) + MONO_S11 * q(n1 - 2) + MONO_S14 * mono_dm(q, n1 - 2) - q(n1 - 1); br = two_sided(n1) - q(n1 - 1); }
-    else { bl = two_sided(n1) - q(n1); br = MONO_S11 * (q(n1 + 1) - q(n1)) - MONO_S14 * mono_dm(q, n1 + 1); }
+    auto clamp4 = [](double xt, double a, double b, double c_, double d) { xt = fmax(xt, fmin(fmin(a, b), fmin(c_, d))); return fmin(xt, fmax(fmax(a, b), fmax(c_, d))); };
+    if (i == 0) { bl = MONO_S14 * dm_m + MONO_S11 * (v[1] - v[2]); br = clamp4(mono_two_sided(da, 1, v[1], v[2], v[3], v[4]), v[1], v[2], v[3], v[4]) - v[2]; }
+    else if (i == 1) { bl = clamp4(mono_two_sided(da, 1, v[0], v[1], v[2], v[3]), v[0], v[1], v[2], v[3]) - v[2]; br = MONO_S15 * v[2] + MONO_S11 * v[3] - MONO_S14 * dm_p - v[2]; }
+    else if (i == 2) { bl = MONO_S15 * v[1] + MONO_S11 * v[2] - MONO_S14 * dm_0 - v[2]; br = 0.5 * (v[2] + v[3]) + MONO_R3 * (dm_0 - dm_p) - v[2]; }
+    else if (i == n1 - 2) { bl = 0.5 * (v[1] + v[2]) + MONO_R3 * (dm_m - dm_0) - v[2]; br = MONO_S15 * v[3] + MONO_S11 * v[2] + MONO_S14 * dm_0 - v[2]; }
+    else if (i == n1 - 1) { bl = MONO_S15 * v[2] + MONO_S11 * v[1] + MONO_S14 * dm_m - v[2]; br = clamp4(mono_two_sided(da, n1, v[1], v[2], v[3], v[4]), v[1], v[2], v[3], v[4]) - v[2]; }
+    else { bl = clamp4(mono_two_sided(da, n1, v[0], v[1], v[2], v[3]), v[0], v[1], v[2], v[3]) - v[2]; br = MONO_S11 * (v[3] - v[2]) - MONO_S14 * dm_p; }
     mono_pert_ppm(bl, br);
     return;
   }
-  const double qi = q(i), al0 = mono_al(q, i), al1 = mono_al(q, i + 1);
+  const double qi = v[2], al0 = 0.5 * (v[1] + v[2]) + MONO_R3 * (dm_m - dm_0), al1 = 0.5 * (v[2] + v[3]) + MONO_R3 * (dm_0 - dm_p);   // :641-642
   if (iord == 8) {                             // Lin's fast monotone constraint (:643-678)
-    const double xt = 2. * mono_dm(q, i);
+    const double xt = 2. * dm_0;
     bl = -mono_sign(fmin(fabs(xt), fabs(al0 - qi)), xt);
     br = mono_sign(fmin(fabs(xt), fabs(al1 - qi)), xt);
     return;
   }
   bl = al0 - qi; br = al1 - qi;                // iord = 10: Huynh's second constraint (:716-823)
-  if (fabs(mono_dm(q, i - 1)) + fabs(mono_dm(q, i)) + fabs(mono_dm(q, i + 1)) < MONO_NEAR_ZERO) { bl = 0.; br = 0.; return; }
+  if (fabs(dm_m) + fabs(dm_0) + fabs(dm_p) < MONO_NEAR_ZERO) { bl = 0.; br = 0.; return; }
   if (fabs(3. * (bl + br)) > fabs(bl - br)) {
-    const double pmp_2 = 2. * (q(i) - q(i - 1)), lac_2 = pmp_2 - 0.75 * (2. * (q(i - 1) - q(i - 2)));
+    const double pmp_2 = 2. * (v[2] - v[1]), lac_2 = pmp_2 - 0.75 * (2. * (v[1] - v[0]));
     br = fmin(fmax(0., fmax(pmp_2, lac_2)), fmax(br, fmin(0., fmin(pmp_2, lac_2))));
-    const double pmp_1 = -(2. * (q(i + 1) - q(i))), lac_1 = pmp_1 + 0.75 * (2. * (q(i + 2) - q(i + 1)));
+    const double pmp_1 = -(2. * (v[3] - v[2])), lac_1 = pmp_1 + 0.75 * (2. * (v[4] - v[3]));
     bl = fmin(fmax(0., fmax(pmp_1, lac_1)), fmax(bl, fmin(0., fmin(pmp_1, lac_1))));
   }
 }
-// flux at interface m with the trajectory scheme: the differentiable schemes through ppm_flux, 8 / 10 through the slopes above (:944-952)
+// flux at interface m with the trajectory scheme: the differentiable schemes through ppm_flux, 8 / 10 through the slopes of the upwind
+// cell (:944-952).  The six cells q(m-3 .. m+2) are read once; the upwind cell's window is picked by selects, never by a dynamic index.
 template <class Q, class D>
 HD double ppm_flux_traj(int iord, bool face, int m, int n1, const Q& q, const D& da, double cc) {
   if (iord != 8 && iord != 10) return ppm_flux<double>(iord, face, m, n1, q, da, cc);
+  const double w0 = q(m - 3), w1 = q(m - 2), w2 = q(m - 1), w3 = q(m), w4 = q(m + 1), w5 = q(m + 2);
+  const bool up = cc > 0.;
+  const double v[5] = {up ? w0 : w1, up ? w1 : w2, up ? w2 : w3, up ? w3 : w4, up ? w4 : w5};
   double bl, br;
-  if (cc > 0.) { mono_blbr(iord, face, m - 1, n1, q, da, bl, br); return q(m - 1) + (1. - cc) * (br - cc * (bl + br)); }
-  mono_blbr(iord, face, m, n1, q, da, bl, br);
-  return q(m) + (1. + cc) * (bl + cc * (bl + br));
+  mono_blbr(iord, face, up ? m - 1 : m, n1, v, da, bl, br);
+  return up ? v[2] + (1. - cc) * (br - cc * (bl + br)) : v[2] + (1. + cc) * (bl + cc * (bl + br));
 }
 
 // xtp_u / ytp_v flux at interface m (sw_core_tlm.F90:7272-7486, :7490-7759): cfl = c * rd(upwind cell).
@@ -201,47 +203,49 @@ HD T tp_uv_flux(int iord, bool face, int m, int n1, bool row_edge, const Q& q, c
 // The monotone slopes of the NONLINEAR xtp_u / ytp_v, iord 8 / 10 (sw_core_tlm.F90:4620-5041, :5361-5865): as mono_blbr with the
 // momentum fluxes' own edge treatment (D-grid metric, two-sided edge value unclamped, zero slopes next to a face corner, pert_ppm
 // on cells 2 and n1-2 only) and their own 2-delta-x test.  Values only (split_hord, :1987-2002).
-template <class Q, class D>
-HD void uv_mono_blbr(int iord, bool face, int i, int n1, bool row_edge, const Q& q, const D& dd, double& bl, double& br) {
+template <class D>
+HD void uv_mono_blbr(int iord, bool face, int i, int n1, bool row_edge, const double* v, const D& dd, double& bl, double& br) {
+  const double dm_m = mono_dm3(v[0], v[1], v[2]), dm_0 = mono_dm3(v[1], v[2], v[3]), dm_p = mono_dm3(v[2], v[3], v[4]);
   if (face && (i <= 2 || i >= n1 - 2)) {
-    auto two_sided = [&](int e) {
-      return 0.5 * ((2. * dd(e - 1) + dd(e - 2)) * q(e - 1) - dd(e - 1) * q(e - 2)) / (dd(e - 1) + dd(e - 2)) +
-             0.5 * ((2. * dd(e) + dd(e + 1)) * q(e) - dd(e) * q(e + 1)) / (dd(e) + dd(e + 1));
+    auto two_sided = [&](int e, double w0, double w1, double w2, double w3) {    // x0l + x0r (:4907-4912)
+      return 0.5 * ((2. * dd(e - 1) + dd(e - 2)) * w1 - dd(e - 1) * w0) / (dd(e - 1) + dd(e - 2)) + 0.5 * ((2. * dd(e) + dd(e + 1)) * w2 - dd(e) * w3) / (dd(e) + dd(e + 1));
     };
     if (row_edge && (i <= 1 || i >= n1 - 1)) { bl = 0.; br = 0.; return; }
-    if (i == 0) { bl = MONO_S14 * mono_dm(q, -1) - MONO_S11 * (q(0) - q(-1)); br = two_sided(1) - q(0); }
-    else if (i == 1) { bl = two_sided(1) - q(1); br = MONO_S15 * q(1) + MONO_S11 * q(2) - MONO_S14 * mono_dm(q, 2) - q(1); }
-    else if (i == 2) { bl = MONO_S15 * q(1) + MONO_S11 * q(2) - MONO_S14 * mono_dm(q, 2) - q(2); br = mono_al(q, 3) - q(2); mono_pert_ppm(bl, br); }
-    else if (i == n1 - 2) { bl = mono_al(q, n1 - 2) - q(n1 - 2); br = MONO_S15 * q(n1 - 1) + MONO_S11 * q(n1 - 2) + MONO_S14 * mono_dm(q, n1 - 2) - q(n1 - 2); mono_pert_ppm(bl, br); }
-    else if (i == n1 - 1) { bl = MONO_S15 * q(n1 - 1) + MONO_S11 * q(n1 - 2) + MONO_S14 * mono_dm(q, n1 - 2) - q(n1 - 1); br = two_sided(n1) - q(n1 - 1); }
-    else { bl = two_sided(n1) - q(n1); br = MONO_S11 * (q(n1 + 1) - q(n1)) - MONO_S14 * mono_dm(q, n1 + 1); }
+    if (i == 0) { bl = MONO_S14 * dm_m - MONO_S11 * (v[2] - v[1]); br = two_sided(1, v[1], v[2], v[3], v[4]) - v[2]; }
+    else if (i == 1) { bl = two_sided(1, v[0], v[1], v[2], v[3]) - v[2]; br = MONO_S15 * v[2] + MONO_S11 * v[3] - MONO_S14 * dm_p - v[2]; }
+    else if (i == 2) { bl = MONO_S15 * v[1] + MONO_S11 * v[2] - MONO_S14 * dm_0 - v[2]; br = 0.5 * (v[2] + v[3]) + MONO_R3 * (dm_0 - dm_p) - v[2]; mono_pert_ppm(bl, br); }
+    else if (i == n1 - 2) { bl = 0.5 * (v[1] + v[2]) + MONO_R3 * (dm_m - dm_0) - v[2]; br = MONO_S15 * v[3] + MONO_S11 * v[2] + MONO_S14 * dm_0 - v[2]; mono_pert_ppm(bl, br); }
+    else if (i == n1 - 1) { bl = MONO_S15 * v[2] + MONO_S11 * v[1] + MONO_S14 * dm_m - v[2]; br = two_sided(n1, v[1], v[2], v[3], v[4]) - v[2]; }
+    else { bl = two_sided(n1, v[0], v[1], v[2], v[3]) - v[2]; br = MONO_S11 * (v[3] - v[2]) - MONO_S14 * dm_p; }
     return;
   }
-  const double qi = q(i), al0 = mono_al(q, i), al1 = mono_al(q, i + 1);
+  const double qi = v[2], al0 = 0.5 * (v[1] + v[2]) + MONO_R3 * (dm_m - dm_0), al1 = 0.5 * (v[2] + v[3]) + MONO_R3 * (dm_0 - dm_p);
   if (iord == 8) {
-    const double xt = 2. * mono_dm(q, i);
+    const double xt = 2. * dm_0;
     bl = -mono_sign(fmin(fabs(xt), fabs(al0 - qi)), xt);
     br = mono_sign(fmin(fabs(xt), fabs(al1 - qi)), xt);
     return;
   }
   bl = al0 - qi; br = al1 - qi;
-  if (fabs(mono_dm(q, i)) < MONO_NEAR_ZERO) {
-    if (fabs(mono_dm(q, i - 1)) + fabs(mono_dm(q, i + 1)) < MONO_NEAR_ZERO) { bl = 0.; br = 0.; }
+  if (fabs(dm_0) < MONO_NEAR_ZERO) {
+    if (fabs(dm_m) + fabs(dm_p) < MONO_NEAR_ZERO) { bl = 0.; br = 0.; }
   } else if (fabs(3. * (bl + br)) > fabs(bl - br)) {
-    const double pmp_1 = -(2. * (q(i + 1) - q(i))), lac_1 = pmp_1 + 1.5 * (q(i + 2) - q(i + 1));
+    const double pmp_1 = -(2. * (v[3] - v[2])), lac_1 = pmp_1 + 1.5 * (v[4] - v[3]);
     bl = fmin(fmax(0., fmax(pmp_1, lac_1)), fmax(bl, fmin(0., fmin(pmp_1, lac_1))));
-    const double pmp_2 = 2. * (q(i) - q(i - 1)), lac_2 = pmp_2 - 1.5 * (q(i - 1) - q(i - 2));
+    const double pmp_2 = 2. * (v[2] - v[1]), lac_2 = pmp_2 - 1.5 * (v[1] - v[0]);
     br = fmin(fmax(0., fmax(pmp_2, lac_2)), fmax(br, fmin(0., fmin(pmp_2, lac_2))));
   }
 }
 template <class Q, class D>
 HD double tp_uv_flux_traj(int iord, bool face, int m, int n1, bool row_edge, const Q& q, const D& dd, double cc, double rd_m, double rd_0) {
   if (iord != 8 && iord != 10) return tp_uv_flux<double>(iord, face, m, n1, row_edge, q, dd, cc, rd_m, rd_0);
+  const double w0 = q(m - 3), w1 = q(m - 2), w2 = q(m - 1), w3 = q(m), w4 = q(m + 1), w5 = q(m + 2);
+  const bool up = cc > 0.;
+  const double v[5] = {up ? w0 : w1, up ? w1 : w2, up ? w2 : w3, up ? w3 : w4, up ? w4 : w5};
   double bl, br;
-  if (cc > 0.) { uv_mono_blbr(iord, face, m - 1, n1, row_edge, q, dd, bl, br); const double cfl = cc * rd_m; return q(m - 1) + (1. - cfl) * (br - cfl * (bl + br)); }
-  uv_mono_blbr(iord, face, m, n1, row_edge, q, dd, bl, br);
-  const double cfl = cc * rd_0;
-  return q(m) + (1. + cfl) * (bl + cfl * (bl + br));
+  uv_mono_blbr(iord, face, up ? m - 1 : m, n1, row_edge, v, dd, bl, br);
+  const double cfl = cc * (up ? rd_m : rd_0);
+  return up ? v[2] + (1. - cfl) * (br - cfl * (bl + br)) : v[2] + (1. + cfl) * (bl + cfl * (bl + br));
 }
 
 // ===================================================================== c_sw
@@ -872,10 +876,13 @@ struct DswKeWindsD {
 typedef Edged<DswKeWindsD, false> DswKeWinds;
 typedef Edged<DswKeWindsD, true> DswKeWindsE;
 // KE = 0.5*(vb*ytp_v + ub*xtp_u), face corners from the edge-normal winds (sw_core_tlm.F90:3197-3273)
-struct DswKeD {
-  static constexpr bool MERGE_AD_OK = true;
+// SPLIT: the build with a trajectory hord_mt that differs from the perturbation's on some level (split_hord) -- a stage type of its
+// own, so that the kernels of the unsplit configuration carry none of the monotone code
+template <bool SPLIT>
+struct DswKeT {
+  static constexpr bool MERGE_AD_OK = !SPLIT;
   static constexpr bool LDS_FW_OK = true;
-  STAGE_COMMON("DswKe", 6, 1)   // in: vb ub u v ut vt   out: ke
+  STAGE_COMMON(SPLIT ? "DswKeS" : "DswKe", 6, 1)   // in: vb ub u v ut vt   out: ke
   double dt;
   HD static constexpr Box box(int M) { return M < 2 ? Box{0, 0, 0, 0, 0, 0} : M == 2 ? Box{-3, 2, 0, 0, 0, 0} : M == 3 ? Box{0, 0, -3, 2, 0, 0} : M == 4 ? Box{0, 0, -1, 0, 0, 0} : Box{-1, 0, 0, 0, 0, 0}; }
   template <bool EDGE, class T, class A>
@@ -900,8 +907,8 @@ struct DswKeD {
     T fv = tp_uv_flux<T>(iord, F, j, npy, i == 1 || i == npx, qv, ddy, vb, MET(rdy, i, j - 1), MET(rdy, i, j));
     LineX<A, 2> qu{a, c.g, j, 0}; MetX ddx{c.m.dx, c, tile, j};
     T fu = tp_uv_flux<T>(iord, F, i, npx, j == 1 || j == npy, qu, ddx, ub, MET(rdx, i - 1, j), MET(rdx, i, j));
-    const int iord_t = c.lev[k - 1].hord_mt_t;
-    if (iord_t != iord) {      // split_hord: the nonlinear fluxes of the trajectory scheme for the values (sw_core_tlm.F90:1987-2002, :2059-2072)
+    const int iord_t = SPLIT ? c.lev[k - 1].hord_mt_t : iord;
+    if (SPLIT && iord_t != iord) {      // split_hord: the nonlinear fluxes of the trajectory scheme for the values (sw_core_tlm.F90:1987-2002, :2059-2072)
       auto qvd = [&](int jj) { return val(qv(jj)); };
       auto qud = [&](int ii) { return val(qu(ii)); };
       set_val(fv, tp_uv_flux_traj(iord_t, F, j, npy, i == 1 || i == npx, qvd, ddy, val(vb), MET(rdy, i, j - 1), MET(rdy, i, j)));
@@ -910,6 +917,8 @@ struct DswKeD {
     o[0] = 0.5 * (vb * fv + ub * fu);
   }
 };
+typedef DswKeT<false> DswKeD;
+typedef DswKeT<true> DswKeSD;
 typedef Edged<DswKeD, false> DswKe;
 typedef Edged<DswKeD, true> DswKeE;
 // relative and absolute vorticity (sw_core_tlm.F90:3275-3293, :3535-3540)
@@ -1437,6 +1446,7 @@ template <class D> constexpr unsigned edge_only_inputs(const D*) { return 0u; }
 constexpr unsigned edge_only_inputs(const CswKeVortD*) { return 0x30u; }
 constexpr unsigned edge_only_inputs(const DswKeWindsD*) { return 0xCu; }
 constexpr unsigned edge_only_inputs(const DswKeD*) { return 0x30u; }
+constexpr unsigned edge_only_inputs(const DswKeSD*) { return 0x30u; }
 constexpr unsigned edge_only_inputs(const DdAD*) { return 0x60u; }
 constexpr unsigned edge_only_inputs(const DswWindsCD*) { return 0xCu; }
 
