@@ -578,8 +578,15 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
   if (nh && !(o.a_imp > 0.5)) { err = "non-hydrostatic: a_imp must be > 0.5 (semi-implicit solver; the reference's a_imp <= 0.5 Riemann-invariant solver is not built)"; return false; }
   // options whose other values are not built are refused, never silently replaced by what is built:
   //   remap profiles: only the linear one, |kord| > 16 (fv_mapz_tlm.F90:8653-8666; the limited profiles are the split_kord work of DESIGN.md §8)
-  for (int kd : {o.kord_tm, o.kord_mt, o.kord_wz, o.kord_tr})
-    if ((kd < 0 ? -kd : kd) <= 16) { err = "kord_tm/kord_mt/kord_wz/kord_tr: only |kord| > 16 (the linear profile of the TL/AD reference) is built"; return false; }
+  //   a trajectory kord in {9, 10, 11} with a linear perturbation kord (split_kord): the limited profile gives the values (remap.h)
+  for (int kd : {o.kord_tm_pert, o.kord_mt_pert, o.kord_wz_pert, o.kord_tr_pert})
+    if ((kd < 0 ? -kd : kd) <= 16) { err = "kord_*_pert: only |kord| > 16 (the linear profile, the one the TL/AD reference differentiates) is built"; return false; }
+  for (int kd : {o.kord_tm, o.kord_mt, o.kord_wz, o.kord_tr}) {
+    const int ak = kd < 0 ? -kd : kd;
+    if (ak <= 16 && !(ak >= 9 && ak <= 11)) { err = "kord_tm/kord_mt/kord_wz/kord_tr: the linear profile (|kord| > 16) or, for the trajectory, the limited profiles 9, 10, 11"; return false; }
+    if (ak <= 16 && !o.hydrostatic) { err = "kord: limited trajectory profiles (split_kord) are built for the hydrostatic remap only"; return false; }
+    if (ak <= 16 && npz < 6) { err = "kord: limited trajectory profiles need npz >= 6"; return false; }
+  }
   //   tracer advection: the perturbation runs with the trajectory scheme (no split_hord recompute); hord_tr_ks_* are read by the
   //   reference's namelist but used nowhere on the path (fv_control_tlmadm.F90:166-172), so they are accepted and ignored here too
   //   advection schemes: the tangent / adjoint exists for 1, 2, 333 (tp_core_tlm.F90:2393-2487); a trajectory scheme that differs

@@ -347,6 +347,7 @@ inline RemapArgs Dynamics::remap_args(bool last_step) {
   a.u = f("u"); a.v = f("v"); a.pe2 = pe2; a.nq = nq;
   for (int n = 0; n < nq; ++n) a.q[n] = q[n];
   a.ak = ak_dev; a.bk = bk_dev; a.akap = opt.akap; a.zvir = opt.zvir; a.ptop = opt.ptop; a.last_step = last_step;
+  a.kord_tm = opt.kord_tm; a.kord_mt = opt.kord_mt; a.kord_tr = opt.kord_tr;
   a.ws = remap_ws; a.ws_stride = (size_t)g.ntile * g.plane; a.pu_ad = pu_ad; a.pv_ad = pv_ad;
   return a;
 }

@@ -100,6 +100,156 @@ HD void map_col(int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const FOu
   }
 }
 
+// ---------------------------------------------------------------- limited profiles of the nonlinear remap (split_kord)
+// cs_profile / scalar_profile with |kord| in {9, 10, 11} (fv_mapz_tlm.F90:5566-6433, :3240-4228; readable form
+// model/fv_mapz_nlm.F90:2113-2464, :1730-2110) and cs_limiters (:6434-6519).  Values only: the reference differentiates the linear
+// profile alone (:8653-8666) and, when the trajectory's kord differs from the perturbation's, runs the nonlinear map for the values
+// (:494-523, :596-637, :780-827).  Written per LAYER: after the tridiagonal solve every constraint is local in k, so the mapping loop
+// asks for (a2, a3, a4) of the one or two source layers a target touches instead of a pass that stores three more vectors.
+// a1(k): layer means, qe(k): the unlimited edge values (k = 1..km+1).  iv: -1 winds, 0 positive definite, 1 others.
+HD void cs_limiters(bool extm, double a1, double& a2, double& a3, double& a4, int iv) {
+  if (iv == 0) {
+    if (a1 <= 0.) { a2 = a1; a3 = a1; a4 = 0.; }
+    else if (fabs(a3 - a2) < -a4) {
+      if (a1 + 0.25 * (a3 - a2) * (a3 - a2) / a4 + a4 * (1. / 12.) < 0.) {
+        if (a1 < a3 && a1 < a2) { a3 = a1; a2 = a1; a4 = 0.; }
+        else if (a3 > a2) { a4 = 3. * (a2 - a1); a3 = a2 - a4; }
+        else { a4 = 3. * (a3 - a1); a2 = a3 - a4; }
+      }
+    }
+    return;
+  }
+  const bool flat = (iv == 1) ? ((a1 - a2) * (a1 - a3) >= 0.) : extm;
+  if (flat) { a2 = a1; a3 = a1; a4 = 0.; return; }
+  const double da1 = a3 - a2, da2 = da1 * da1, a6da = a4 * da1;
+  if (a6da < -da2) { a4 = 3. * (a2 - a1); a3 = a2 - a4; }
+  else if (a6da > da2) { a4 = 3. * (a3 - a1); a2 = a3 - a4; }
+}
+struct LimProfile { int kord, iv; bool scalar; double qmin; };     // scalar: scalar_profile's q < qmin tests (map_scalar, map1_q2)
+template <class FA, class FE>
+HD void lim_layer(const LimProfile& P, int k, int km, const FA& a1, const FE& qe, double& a2, double& a3, double& a4) {
+  const int ak = P.kord < 0 ? -P.kord : P.kord, iv = P.iv;
+  // the edge value at interface j after the large-scale constraints (:2207-2245 of the nlm file)
+  auto qlim = [&](int j) -> double {
+    double q = qe(j);
+    if (j <= 1 || j >= km + 1) return q;
+    const double lo = fmin(a1(j - 1), a1(j)), hi = fmax(a1(j - 1), a1(j));
+    if (j == 2 || j == km) return fmax(fmin(q, hi), lo);
+    const double g1 = a1(j - 1) - a1(j - 2), g2 = a1(j + 1) - a1(j);
+    if (g1 * g2 > 0.) return fmax(fmin(q, hi), lo);
+    if (g1 > 0.) return fmax(q, lo);
+    q = fmin(q, hi);
+    return iv == 0 ? fmax(0., q) : q;
+  };
+  auto gam = [&](int j) { return a1(j) - a1(j - 1); };          // j = 2..km
+  auto extm = [&](int j) -> bool {                               // interior layers only (2..km-1)
+    return gam(j) * gam(j + 1) < 0.;
+  };
+  const double a = a1(k);
+  a2 = qlim(k); a3 = qlim(k + 1);
+  if (k == 1 || k == km) {
+    const bool ex = (a2 - a) * (a3 - a) > 0.;
+    if (k == 1) {
+      if (iv == 0) a2 = fmax(0., a2);
+      else if (iv == -1) { if (a2 * a <= 0.) a2 = 0.; }
+    } else {
+      if (iv == 0) a3 = fmax(0., a3);
+      else if (iv == -1) { if (a3 * a <= 0.) a3 = 0.; }
+    }
+    a4 = 3. * (2. * a - (a2 + a3));
+    cs_limiters(ex, a, a2, a3, a4, 1);
+    return;
+  }
+  if (k == 2 || k == km - 1) { a4 = 3. * (2. * a - (a2 + a3)); cs_limiters(extm(k), a, a2, a3, a4, 2); return; }
+  const bool ex = extm(k), small = P.scalar && a < P.qmin;
+  auto huynh = [&]() {
+    const double pmp_1 = a - 2. * gam(k + 1), lac_1 = pmp_1 + 1.5 * gam(k + 2);
+    a2 = fmin(fmax(a2, fmin(a, fmin(pmp_1, lac_1))), fmax(a, fmax(pmp_1, lac_1)));
+    const double pmp_2 = a + 2. * gam(k), lac_2 = pmp_2 - 1.5 * gam(k - 1);
+    a3 = fmin(fmax(a3, fmin(a, fmin(pmp_2, lac_2))), fmax(a, fmax(pmp_2, lac_2)));
+  };
+  // extm(k-1), extm(k+1): k-1 >= 2 and k+1 <= km-1 here, interior form
+  if (ak == 9) {
+    if (ex && (extm(k - 1) || extm(k + 1) || small)) { a2 = a; a3 = a; a4 = 0.; }
+    else {
+      a4 = 3. * (2. * a - (a2 + a3));
+      if (fabs(a4) > fabs(a2 - a3)) { huynh(); a4 = 3. * (2. * a - (a2 + a3)); }
+    }
+  } else if (ak == 10) {
+    if (ex) {
+      if (small || extm(k - 1) || extm(k + 1)) { a2 = a; a3 = a; a4 = 0.; }
+      else a4 = 6. * a - 3. * (a2 + a3);
+    } else {
+      a4 = 6. * a - 3. * (a2 + a3);
+      if (fabs(a4) > fabs(a2 - a3)) { huynh(); a4 = 6. * a - 3. * (a2 + a3); }
+    }
+  } else {      // 11
+    if (ex && (extm(k - 1) || extm(k + 1) || small)) { a2 = a; a3 = a; a4 = 0.; }
+    else a4 = 3. * (2. * a - (a2 + a3));
+  }
+  if (iv == 0) cs_limiters(ex, a, a2, a3, a4, 0);
+}
+// map_col on double with the limited profile: the same tridiagonal solve (edge values into slot SE), then the mapping loop with
+// lim_layer's (a2, a3, a4).  Slots SG, SE in units of double.
+template <class FP1, class FQ1, class FP2, class FOut>
+HD void map_col_lim(const LimProfile& P, int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const FOut& out, const ColWs& ws, int SG, int SE) {
+  {
+    double dpa = pe1(2) - pe1(1), dpb = pe1(3) - pe1(2);
+    double grat = dpb / dpa, bet = grat * (grat + 0.5);
+    double qf = ((grat + grat) * (grat + 1.) * q1(1) + q1(2)) / bet, gam = (1. + grat * (grat + 1.5)) / bet;
+    ws.at(SE, 1) = qf; ws.at(SG, 1) = gam;
+    double d4 = grat, a_prev = q1(1), dp_prev = dpa;
+    for (int k = 2; k <= km; ++k) {
+      const double dpk = pe1(k + 1) - pe1(k), ak_ = q1(k);
+      d4 = dp_prev / dpk;
+      bet = 2. + d4 + d4 - gam;
+      qf = (3. * (a_prev + d4 * ak_) - qf) / bet;
+      gam = d4 / bet;
+      ws.at(SE, k) = qf; ws.at(SG, k) = gam;
+      a_prev = ak_; dp_prev = dpk;
+    }
+    const double a_bot = 1. + d4 * (d4 + 1.5);
+    double qe = (2. * d4 * (d4 + 1.) * q1(km) + q1(km - 1) - a_bot * qf) / (d4 * (d4 + 0.5) - a_bot * gam);
+    ws.at(SE, km + 1) = qe;
+    for (int k = km; k >= 1; --k) { qe = ws.at(SE, k) - ws.at(SG, k) * qe; ws.at(SE, k) = qe; }
+  }
+  auto qe = [&](int k) { return ws.at(SE, k); };
+  int k0 = 1;
+  double qsum = 0.;
+  for (int k = 1; k <= km; ++k) {
+    const double p2t = pe2(k), p2b = pe2(k + 1);
+    int l; bool found = false;
+    for (l = k0; l <= km; ++l)
+      if (p2t >= pe1(l) && p2t <= pe1(l + 1)) { found = true; break; }
+    if (found) {
+      const double p1l = pe1(l), p1r = pe1(l + 1), dpl = p1r - p1l;
+      double a2, a3, a4; lim_layer(P, l, km, q1, qe, a2, a3, a4);
+      const double pl = (p2t - p1l) / dpl;
+      if (p2b <= p1r) {
+        const double pr = (p2b - p1l) / dpl;
+        out(k, a2 + 0.5 * (a4 + a3 - a2) * (pr + pl) - a4 * R3 * (pr * (pr + pl) + pl * pl));
+        k0 = l;
+        continue;
+      }
+      qsum = (p1r - p2t) * (a2 + 0.5 * (a4 + a3 - a2) * (1. + pl) - a4 * (R3 * (1. + pl * (1. + pl))));
+      int m; bool bottom = false;
+      for (m = l + 1; m <= km; ++m) {
+        if (p2b > pe1(m + 1)) qsum = qsum + (pe1(m + 1) - pe1(m)) * q1(m);
+        else { bottom = true; break; }
+      }
+      if (bottom) {
+        const double p1m = pe1(m), dpm = pe1(m + 1) - p1m;
+        double b2, b3, b4; lim_layer(P, m, km, q1, qe, b2, b3, b4);
+        const double dp = p2b - p1m, esl = dp / dpm;
+        qsum = qsum + dp * (b2 + 0.5 * esl * (b3 - b2 + b4 * (1. - R23 * esl)));
+        k0 = m;
+      }
+    }
+    out(k, qsum / (p2b - p2t));
+  }
+}
+HD bool kord_limited(int kord) { return (kord < 0 ? -kord : kord) <= 16; }
+
 // ---------------------------------------------------------------- adjoint column map
 // Trajectory functors pe1, q1, pe2 (double); q2_ad(k) functor; accumulates into workspace slots
 // SP1 (pe1_ad), SQ1 (q1_ad), SP2 (pe2_ad), which the caller has zeroed or pre-loaded.  Scratch
@@ -421,6 +571,7 @@ struct RemapArgs {
   Fld q[8]; int nq;
   const double *ak, *bk;                   // device [npz+1]
   double akap, zvir, ptop; int last_step;
+  int kord_tm = -17, kord_mt = 17, kord_tr = 17;      // trajectory profiles; |kord| <= 16: the limited profile gives the values (split_kord)
   double* ws; size_t ws_stride;            // column workspace
   Fld pu_ad, pv_ad;                        // adjoint hand-over of the u/v maps to pe (npz+1 levels + ps slot)
 };
@@ -429,7 +580,8 @@ HD size_t fidx(const Geom& g, const Fld& f, int tile, int i, int j, int k) { ret
 // scalars: T (log p), tracers, delp, pk, peln, pkz, final pt (fv_mapz_tlm.F90:1586-1835, :2203-2250).
 // Two launches: (1) one thread per (column, field) — field 0 maps T_v in log p, field n tracer n in p — each with its own
 // workspace slots; (2) one thread per column for the new pressures and the final temperature conversion.
-template <class T>
+// LIM: the build of the kernels for a trajectory with limited profiles (split_kord); the default kernels carry none of that code
+template <class T, bool LIM = false>
 HD void remap_field_col(const RemapArgs& a, int field, int i, int j, int tile, size_t col) {
   const Geom& g = a.g; const int km = g.npz;
   const ColWs ws{a.ws + col, a.ws_stride, km + 2};
@@ -444,12 +596,27 @@ HD void remap_field_col(const RemapArgs& a, int field, int i, int j, int tile, s
   if (field == 0) {
     auto pn2 = [&](int k) -> T { return (k == 1 || k == km + 1) ? pn1(k) : dlog(pe2(k)); };
     auto tv = [&](int k) -> T { return IO::ld(a.pt, fidx(g, a.pt, tile, i, j, k)) * (pk1(k + 1) - pk1(k)) / (a.akap * (pn1(k + 1) - pn1(k))); };
-    map_col<T>(km, pn1, tv, pn2, outw, ws, SG, SE);
+    if (!(LIM && kord_limited(a.kord_tm) && W::W == 1)) map_col<T>(km, pn1, tv, pn2, outw, ws, SG, SE);
+    if constexpr (LIM) if (kord_limited(a.kord_tm)) {      // the values by the trajectory's limited profile (map_scalar, iv = 1, t_min = 184: fv_mapz_tlm.F90:494-509)
+      auto pn1d = [&](int k) { return a.peln.t[fidx(g, a.peln, tile, i, j, k)]; };
+      auto pk1d = [&](int k) { return a.pk.t[fidx(g, a.pk, tile, i, j, k)]; };
+      const double psd = a.pe.t[fidx(g, a.pe, tile, i, j, km + 1)];
+      auto pn2d = [&](int k) -> double { return (k == 1 || k == km + 1) ? pn1d(k) : log(k == 1 ? a.ptop : a.ak[k - 1] + a.bk[k - 1] * psd); };
+      auto tvd = [&](int k) -> double { return a.pt.t[fidx(g, a.pt, tile, i, j, k)] * (pk1d(k + 1) - pk1d(k)) / (a.akap * (pn1d(k + 1) - pn1d(k))); };
+      map_col_lim(LimProfile{a.kord_tm, 1, true, 184.}, km, pn1d, tvd, pn2d, [&](int k, double x) { ws.at(W::W * SO, k) = x; }, ws, W::W * SG, W::W * SE);
+    }
     for (int k = 1; k <= km; ++k) IO::st(a.pt, fidx(g, a.pt, tile, i, j, k), W::get(ws, SO, k));   // T_v on the new levels
   } else {
     const Fld& qf = a.q[field - 1];
     auto q1 = [&](int k) { return IO::ld(qf, fidx(g, qf, tile, i, j, k)); };
-    map_col<T>(km, pe1, q1, pe2, outw, ws, SG, SE);
+    if (!(LIM && kord_limited(a.kord_tr) && W::W == 1)) map_col<T>(km, pe1, q1, pe2, outw, ws, SG, SE);
+    if constexpr (LIM) if (kord_limited(a.kord_tr)) {      // map1_q2: scalar_profile, iv = 0, q_min = 0 (fv_mapz_tlm.F90:596-612)
+      auto pe1d = [&](int k) { return a.pe.t[fidx(g, a.pe, tile, i, j, k)]; };
+      const double psd = pe1d(km + 1);
+      auto pe2d = [&](int k) -> double { return k == 1 ? a.ptop : (k == km + 1 ? psd : a.ak[k - 1] + a.bk[k - 1] * psd); };
+      auto q1d = [&](int k) { return qf.t[fidx(g, qf, tile, i, j, k)]; };
+      map_col_lim(LimProfile{a.kord_tr, 0, true, 0.}, km, pe1d, q1d, pe2d, [&](int k, double x) { ws.at(W::W * SO, k) = x; }, ws, W::W * SG, W::W * SE);
+    }
     for (int k = 1; k <= km; ++k) IO::st(qf, fidx(g, qf, tile, i, j, k), W::get(ws, SO, k));
   }
 }
@@ -485,7 +652,7 @@ HD void remap_press_col(const RemapArgs& a, int i, int j, int tile) {
 
 // u (dir=0, points i=1..nx, j=1..ny+1) and v (dir=1, i=1..nx+1, j=1..ny) on pressures averaged across the
 // edge (fv_mapz_tlm.F90:1884-1934)
-template <class T>
+template <class T, bool LIM = false>
 HD void remap_wind_col(const RemapArgs& a, int dir, int i, int j, int tile, size_t col) {
   const Geom& g = a.g; const int km = g.npz;
   const ColWs ws{a.ws + col, a.ws_stride, km + 2};
@@ -501,7 +668,17 @@ HD void remap_wind_col(const RemapArgs& a, int dir, int i, int j, int tile, size
   auto pe3 = [&](int k) -> T { return (dir == 1 && k == 1) ? T(a.ak[0]) : a.ak[k - 1] + (0.5 * a.bk[k - 1]) * pss; };
   auto q1 = [&](int k) { return IO::ld(wf, fidx(g, wf, tile, i, j, k)); };
   auto outw = [&](int k, const T& x) { W::set(ws, SO, k, x); };
-  map_col<T>(km, pe0, q1, pe3, outw, ws, SG, SE);
+  if (!(LIM && kord_limited(a.kord_mt) && W::W == 1)) map_col<T>(km, pe0, q1, pe3, outw, ws, SG, SE);
+  if constexpr (LIM) if (kord_limited(a.kord_mt)) {        // map1_ppm: cs_profile, iv = -1 (fv_mapz_tlm.F90:780-795, :817-830)
+    auto pe0d = [&](int k) -> double {
+      if (k == 1) return a.pe.t[fidx(g, a.pe, tile, i, j, 1)];
+      return 0.5 * (a.pe.t[fidx(g, a.pe, tile, im, jm, k)] + a.pe.t[fidx(g, a.pe, tile, i, j, k)]);
+    };
+    const double pssd = a.pe.t[fidx(g, a.pe, tile, im, jm, km + 1)] + a.pe.t[fidx(g, a.pe, tile, i, j, km + 1)];
+    auto pe3d = [&](int k) -> double { return (dir == 1 && k == 1) ? a.ak[0] : a.ak[k - 1] + (0.5 * a.bk[k - 1]) * pssd; };
+    auto q1d = [&](int k) { return wf.t[fidx(g, wf, tile, i, j, k)]; };
+    map_col_lim(LimProfile{a.kord_mt, -1, false, 0.}, km, pe0d, q1d, pe3d, [&](int k, double x) { ws.at(W::W * SO, k) = x; }, ws, W::W * SG, W::W * SE);
+  }
   for (int k = 1; k <= km; ++k) IO::st(wf, fidx(g, wf, tile, i, j, k), W::get(ws, SO, k));
 }
 
@@ -572,6 +749,7 @@ struct RemapAdSlots { static constexpr int SPE1 = 13, SPN1 = 14, SPK1 = 15, SPE2
 struct FieldAdSlots { int SP1, SQ1, SP2; MapAdWs w; };
 HD FieldAdSlots remap_field_slots(int f) { const int b = RemapAdSlots::FBASE + RemapAdSlots::FN * f; return FieldAdSlots{b, b + 1, b + 2, MapAdWs{b + 3, b + 4, b + 5, b + 6, b + 7, b + 1, b}}; }
 
+template <bool LIM = false>
 HD void remap_ad_k1(const RemapArgs& a, int i, int j, int tile, size_t col) {
   const Geom& g = a.g; const int km = g.npz;
   const ColWs ws{a.ws + col, a.ws_stride, km + 2};
@@ -590,11 +768,15 @@ HD void remap_ad_k1(const RemapArgs& a, int i, int j, int tile, size_t col) {
   // trajectory of the remapped T_v and q_v (needed by the final conversion)
   {
     auto outT = [&](int k, double x) { ws.at(R_::ST2, k) = x; };
-    map_col<double>(km, pn1, tv, pn2, outT, ws, 0, 1);
+    bool done = false;
+    if constexpr (LIM) if (kord_limited(a.kord_tm)) { map_col_lim(LimProfile{a.kord_tm, 1, true, 184.}, km, pn1, tv, pn2, outT, ws, 0, 1); done = true; }
+    if (!done) map_col<double>(km, pn1, tv, pn2, outT, ws, 0, 1);
     if (a.nq > 0 && a.last_step) {
       auto q1 = [&](int k) { return a.q[0].t[fidx(g, a.q[0], tile, i, j, k)]; };
       auto outQ = [&](int k, double x) { ws.at(R_::SQ2, k) = x; };
-      map_col<double>(km, pe1, q1, pe2, outQ, ws, 0, 1);
+      bool doneq = false;
+      if constexpr (LIM) if (kord_limited(a.kord_tr)) { map_col_lim(LimProfile{a.kord_tr, 0, true, 0.}, km, pe1, q1, pe2, outQ, ws, 0, 1); doneq = true; }
+      if (!doneq) map_col<double>(km, pe1, q1, pe2, outQ, ws, 0, 1);
     }
   }
   // final conversion, pkz, pk/peln outputs, delp
@@ -697,42 +879,46 @@ HD void remap_ad_k3(const RemapArgs& a, int i, int j, int tile, size_t col) {
 }
 
 // one kernel per mode (separate register allocations)
-template <int MODE>
+template <int MODE, bool LIM = false>
 struct RemapFieldFn {      // z = tile * nf + field
   RemapArgs a; int nf;
   HD void operator()(int i, int j, int z) const {
     const int tile = z / nf, field = z % nf;
     const size_t col = (size_t)tile * a.g.plane + a.g.idx(i, j);
-    if (MODE == MODE_NL) remap_field_col<double>(a, field, i, j, tile, col);
-    else if (MODE == MODE_TL) remap_field_col<Dual>(a, field, i, j, tile, col);
+    if (MODE == MODE_NL) remap_field_col<double, LIM>(a, field, i, j, tile, col);
+    else if (MODE == MODE_TL) remap_field_col<Dual, LIM>(a, field, i, j, tile, col);
     else remap_ad_k2(a, field, i, j, tile, col);
   }
 };
-template <int MODE>        // MODE_AD: stage 1 of the adjoint; 3: stage 3
+template <int MODE, bool LIM = false>        // MODE_AD: stage 1 of the adjoint; 3: stage 3
 struct RemapPressFn {
   RemapArgs a;
   HD void operator()(int i, int j, int z) const {
     const size_t col = (size_t)z * a.g.plane + a.g.idx(i, j);
     if (MODE == MODE_NL) remap_press_col<double>(a, i, j, z);
     else if (MODE == MODE_TL) remap_press_col<Dual>(a, i, j, z);
-    else if (MODE == MODE_AD) remap_ad_k1(a, i, j, z, col);
+    else if (MODE == MODE_AD) remap_ad_k1<LIM>(a, i, j, z, col);
     else remap_ad_k3(a, i, j, z, col);
   }
 };
-template <int MODE>
+template <int MODE, bool LIM = false>
 struct RemapWindFn {
   RemapArgs a; int dir;
   HD void operator()(int i, int j, int z) const {
     const size_t col = (size_t)z * a.g.plane + a.g.idx(i, j);
-    if (MODE == MODE_NL) remap_wind_col<double>(a, dir, i, j, z, col);
-    else if (MODE == MODE_TL) remap_wind_col<Dual>(a, dir, i, j, z, col);
+    if (MODE == MODE_NL) remap_wind_col<double, LIM>(a, dir, i, j, z, col);
+    else if (MODE == MODE_TL) remap_wind_col<Dual, LIM>(a, dir, i, j, z, col);
     else remap_wind_col_ad(a, dir, i, j, z, col);
   }
 };
 inline void run_remap_winds(Exec& ex, int mode, const RemapArgs& a, double bytes = 0.) {
   const Geom& g = a.g;
   const Rect U{1, g.nx, 1, g.ny + 1}, V{1, g.nx + 1, 1, g.ny};
-  if (mode == MODE_NL) { for_points(ex, U, g.ntile, RemapWindFn<MODE_NL>{a, 0}, "remap_wind.nl", bytes); for_points(ex, V, g.ntile, RemapWindFn<MODE_NL>{a, 1}, "remap_wind.nl", bytes); }
+  if (kord_limited(a.kord_mt) && mode != MODE_AD) {      // split_kord: the kernels that also run the trajectory's limited profile
+    if (mode == MODE_NL) { for_points(ex, U, g.ntile, RemapWindFn<MODE_NL, true>{a, 0}, "remap_wind_lim.nl", bytes); for_points(ex, V, g.ntile, RemapWindFn<MODE_NL, true>{a, 1}, "remap_wind_lim.nl", bytes); }
+    else { for_points(ex, U, g.ntile, RemapWindFn<MODE_TL, true>{a, 0}, "remap_wind_lim.tl", bytes); for_points(ex, V, g.ntile, RemapWindFn<MODE_TL, true>{a, 1}, "remap_wind_lim.tl", bytes); }
+  }
+  else if (mode == MODE_NL) { for_points(ex, U, g.ntile, RemapWindFn<MODE_NL>{a, 0}, "remap_wind.nl", bytes); for_points(ex, V, g.ntile, RemapWindFn<MODE_NL>{a, 1}, "remap_wind.nl", bytes); }
   else if (mode == MODE_TL) { for_points(ex, U, g.ntile, RemapWindFn<MODE_TL>{a, 0}, "remap_wind.tl", bytes); for_points(ex, V, g.ntile, RemapWindFn<MODE_TL>{a, 1}, "remap_wind.tl", bytes); }
   else { for_points(ex, V, g.ntile, RemapWindFn<MODE_AD>{a, 1}, "remap_wind.ad", bytes); for_points(ex, U, g.ntile, RemapWindFn<MODE_AD>{a, 0}, "remap_wind.ad", bytes); }
 }
@@ -761,7 +947,14 @@ inline void run_remap(Exec& ex, int mode, const RemapArgs& a) {
     const double cells = double(g.nx) * g.ny * g.ntile * g.npz, w = mode == MODE_TL ? 2. : 1.;
     // algorithmic bytes: scalars read pe,peln,pk,pt,q[nq]; write pt,q[nq],delp,pk,peln,pkz,pe2; winds read pe x2, u|v; write u|v
     const int nf = 1 + a.nq;
-    if (mode == MODE_TL) {
+    const bool lim = kord_limited(a.kord_tm) || kord_limited(a.kord_tr);
+    if (lim && mode == MODE_TL) {
+      for_points(ex, A, g.ntile * nf, RemapFieldFn<MODE_TL, true>{a, nf}, "remap_fields_lim.tl", 8. * w * (5. + 2. * a.nq) * cells);
+      for_points(ex, A, g.ntile, RemapPressFn<MODE_TL>{a}, "remap_press.tl", 8. * w * (5. + 7.) * cells);
+    } else if (lim) {
+      for_points(ex, A, g.ntile * nf, RemapFieldFn<MODE_NL, true>{a, nf}, "remap_fields_lim.nl", 8. * w * (5. + 2. * a.nq) * cells);
+      for_points(ex, A, g.ntile, RemapPressFn<MODE_NL>{a}, "remap_press.nl", 8. * w * (5. + 7.) * cells);
+    } else if (mode == MODE_TL) {
       for_points(ex, A, g.ntile * nf, RemapFieldFn<MODE_TL>{a, nf}, "remap_fields.tl", 8. * w * (5. + 2. * a.nq) * cells);
       for_points(ex, A, g.ntile, RemapPressFn<MODE_TL>{a}, "remap_press.tl", 8. * w * (5. + 7.) * cells);
     } else {
@@ -775,7 +968,8 @@ inline void run_remap(Exec& ex, int mode, const RemapArgs& a) {
     run_remap_winds(ex, MODE_AD, a, 8. * 7. * cells);
     for_points(ex, H, g.ntile, RemapGatherFn{a}, "remap_gather.ad", 8. * 4. * cells);
     const int nf = 1 + a.nq;
-    for_points(ex, A, g.ntile, RemapPressFn<MODE_AD>{a}, "remap_scalars1.ad", 8. * 12. * cells);
+    if (kord_limited(a.kord_tm) || kord_limited(a.kord_tr)) for_points(ex, A, g.ntile, RemapPressFn<MODE_AD, true>{a}, "remap_scalars1_lim.ad", 8. * 12. * cells);
+    else for_points(ex, A, g.ntile, RemapPressFn<MODE_AD>{a}, "remap_scalars1.ad", 8. * 12. * cells);
     for_points(ex, A, g.ntile * nf, RemapFieldFn<MODE_AD>{a, nf}, "remap_fields.ad", 8. * (4. + 3. * a.nq) * cells);
     for_points(ex, A, g.ntile, RemapPressFn<3>{a}, "remap_scalars3.ad", 8. * 8. * cells);
   }

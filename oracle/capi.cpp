@@ -110,7 +110,7 @@ const char* orc_metric_names() { return METRIC_NAMES; }
 
 // iopt: hord_mt,hord_vt,hord_tm,hord_dp,hord_tr, nord, do_vort_damp, n_sponge,
 //       hord_*_pert(5), nord_pert, do_vort_damp_pert, n_sponge_pert, hord_ks_traj, hord_ks_pert,
-//       hord_*_ks_traj(5), hord_*_ks_pert(5), kord_tm, kord_mt, kord_wz, kord_tr        (34 ints)
+//       hord_*_ks_traj(5), hord_*_ks_pert(5), kord_tm, kord_mt, kord_wz, kord_tr, kord_*_pert(4)        (36 ints)
 // ropt: dddmp,d2_bg,d4_bg,vtdm4,d2_bg_k1,d2_bg_k2,d_con,ke_bg, dddmp_pert,d2_bg_pert,d4_bg_pert,vtdm4_pert,
 //       d2_bg_k1_pert,d2_bg_k2_pert,d2_bg_ks_pert, akap,cp,zvir,grav_jedi, cp_air,rdgas,rvgas,grav,radius,omega,hlv,
 //       ptop, da_min, da_min_c                                                            (29 doubles)
@@ -137,6 +137,7 @@ void* orc_create(int nx, int ny, int npz, int nq, const double* const* metrics, 
   o.hord_mt_ks_traj = *p++; o.hord_vt_ks_traj = *p++; o.hord_tm_ks_traj = *p++; o.hord_dp_ks_traj = *p++; o.hord_tr_ks_traj = *p++;
   o.hord_mt_ks_pert = *p++; o.hord_vt_ks_pert = *p++; o.hord_tm_ks_pert = *p++; o.hord_dp_ks_pert = *p++; o.hord_tr_ks_pert = *p++;
   h->ro.kord_tm = *p++; h->ro.kord_mt = *p++; h->ro.kord_wz = *p++; h->ro.kord_tr = *p++;
+  h->ro.kord_tm_pert = *p++; h->ro.kord_mt_pert = *p++; h->ro.kord_wz_pert = *p++; h->ro.kord_tr_pert = *p++;
   const double* r = ropt;
   o.dddmp = *r++; o.d2_bg = *r++; o.d4_bg = *r++; o.vtdm4 = *r++; o.d2_bg_k1 = *r++; o.d2_bg_k2 = *r++; o.d_con = *r++; o.ke_bg = *r++;
   o.dddmp_pert = *r++; o.d2_bg_pert = *r++; o.d4_bg_pert = *r++; o.vtdm4_pert = *r++; o.d2_bg_k1_pert = *r++;
@@ -155,7 +156,7 @@ void orc_destroy(void* h) { delete (OrcHandle*)h; }
 // Switch the tile to "whole cube face" mode (is=1, ie=npx-1, all edges and corners) and load the a2b_ord4
 // edge weights (edge[4][pj]: w, e, s, n, indexed by padded-plane position) and extrap_corner coefficients.
 void orc_set_face(void* hv, const double* edge, const double* ecorner) {
-  OrcHandle* h = (OrcHandle*)hv;
+  OrcHandle* h = (OrcHandle*)hv; remap_opts() = h->ro;
   const int n = h->bd.nx, pj = h->bd.pj();
   h->bd.set_face(n);
   std::vector<double>* dst[4] = {&h->g.edge_w, &h->g.edge_e, &h->g.edge_s, &h->g.edge_n};
@@ -168,7 +169,7 @@ void orc_set_face(void* hv, const double* edge, const double* ecorner) {
 
 // Per-level parameters as the reference would hand them to d_sw; returns 0 if traj/pert hord split.
 int orc_level_params(void* hv, int k, int* ip, double* rp) {
-  OrcHandle* h = (OrcHandle*)hv; LevelParams lp;
+  OrcHandle* h = (OrcHandle*)hv; remap_opts() = h->ro; LevelParams lp;
   bool ok = level_params(h->o, k, h->npz, lp);
   ip[0] = lp.hord_mt; ip[1] = lp.hord_vt; ip[2] = lp.hord_tm; ip[3] = lp.hord_dp; ip[4] = lp.hord_tr;
   ip[5] = lp.nord; ip[6] = lp.nord_v; ip[7] = lp.nord_w; ip[8] = lp.nord_t; ip[9] = lp.nord_v_pert;
@@ -179,7 +180,7 @@ int orc_level_params(void* hv, int k, int* ip, double* rp) {
 // in: q, crx, cry, xfx, yfx, ra_x, ra_y, [mfx, mfy, mass]   out: fx, fy   (single planes)
 void orc_fv_tp_2d(void* hv, int mode, int hord, int nord, double damp_c, int use_mf, int use_mass, double** in_t,
                   double** in_p, double** out_t, double** out_p) {
-  OrcHandle* h = (OrcHandle*)hv;
+  OrcHandle* h = (OrcHandle*)hv; remap_opts() = h->ro;
   int nin = 7 + (use_mf ? 2 : 0) + (use_mass ? 1 : 0);
   std::vector<int> nk(nin, 1), nko(2, 1);
   auto in = mkio(nin, in_t, in_p, nk.data()); auto out = mkio(2, out_t, out_p, nko.data());
@@ -194,7 +195,7 @@ void orc_fv_tp_2d(void* hv, int mode, int hord, int nord, double damp_c, int use
 
 // c_sw on all levels.  in: delp, pt, u, v   out: delpc, ptc, uc, vc, ua, va, ut, vt, divgd
 void orc_c_sw(void* hv, int mode, double dt2, double** in_t, double** in_p, double** out_t, double** out_p) {
-  OrcHandle* h = (OrcHandle*)hv; int npz = h->npz;
+  OrcHandle* h = (OrcHandle*)hv; remap_opts() = h->ro; int npz = h->npz;
   std::vector<int> nk(4, npz), nko(9, npz);
   auto in = mkio(4, in_t, in_p, nk.data()); auto out = mkio(9, out_t, out_p, nko.data());
   drive(mode, h->bd, in, out, [&](auto& x, auto& y) {
@@ -208,7 +209,7 @@ void orc_c_sw(void* hv, int mode, double dt2, double** in_t, double** in_p, doub
 // d_sw on all levels.  in: delp, pt, u, v, uc, vc, ua, va, divgd, mfx, mfy, cx, cy
 //                      out: delp, pt, u, v, mfx, mfy, cx, cy, crx, cry, xfx, yfx
 void orc_d_sw(void* hv, int mode, double dt, double** in_t, double** in_p, double** out_t, double** out_p) {
-  OrcHandle* h = (OrcHandle*)hv; int npz = h->npz;
+  OrcHandle* h = (OrcHandle*)hv; remap_opts() = h->ro; int npz = h->npz;
   std::vector<int> nk(13, npz), nko(12, npz);
   auto in = mkio(13, in_t, in_p, nk.data()); auto out = mkio(12, out_t, out_p, nko.data());
   drive(mode, h->bd, in, out, [&](auto& x, auto& y) {
@@ -225,7 +226,7 @@ void orc_d_sw(void* hv, int mode, double dt, double** in_t, double** in_p, doubl
 
 // geopk.  in: delp, pt (npz)   out: pe, peln, pk, gz (npz+1), pkz (npz)
 void orc_geopk(void* hv, int mode, int cg, double** in_t, double** in_p, double** out_t, double** out_p) {
-  OrcHandle* h = (OrcHandle*)hv; int npz = h->npz;
+  OrcHandle* h = (OrcHandle*)hv; remap_opts() = h->ro; int npz = h->npz;
   int nk[2] = {npz, npz}, nko[5] = {npz + 1, npz + 1, npz + 1, npz + 1, npz};
   auto in = mkio(2, in_t, in_p, nk); auto out = mkio(5, out_t, out_p, nko);
   drive(mode, h->bd, in, out, [&](auto& x, auto& y) {
@@ -235,7 +236,7 @@ void orc_geopk(void* hv, int mode, int cg, double** in_t, double** in_p, double*
 
 // p_grad_c.  in: pkc, gz (npz+1), uc, vc (npz)   out: uc, vc
 void orc_p_grad_c(void* hv, int mode, double dt2, double** in_t, double** in_p, double** out_t, double** out_p) {
-  OrcHandle* h = (OrcHandle*)hv; int npz = h->npz;
+  OrcHandle* h = (OrcHandle*)hv; remap_opts() = h->ro; int npz = h->npz;
   int nk[4] = {npz + 1, npz + 1, npz, npz}, nko[2] = {npz, npz};
   auto in = mkio(4, in_t, in_p, nk); auto out = mkio(2, out_t, out_p, nko);
   drive(mode, h->bd, in, out, [&](auto& x, auto& y) {
@@ -246,7 +247,7 @@ void orc_p_grad_c(void* hv, int mode, double dt2, double** in_t, double** in_p, 
 
 // one_grad_p.  in: u, v (npz), pk, gz (npz+1)   out: u, v
 void orc_one_grad_p(void* hv, int mode, double dt, double** in_t, double** in_p, double** out_t, double** out_p) {
-  OrcHandle* h = (OrcHandle*)hv; int npz = h->npz;
+  OrcHandle* h = (OrcHandle*)hv; remap_opts() = h->ro; int npz = h->npz;
   int nk[4] = {npz, npz, npz + 1, npz + 1}, nko[2] = {npz, npz};
   auto in = mkio(4, in_t, in_p, nk); auto out = mkio(2, out_t, out_p, nko);
   drive(mode, h->bd, in, out, [&](auto& x, auto& y) {
@@ -259,7 +260,7 @@ void orc_one_grad_p(void* hv, int mode, double dt, double** in_t, double** in_p,
 // in: delp (npz)   out: pe (npz+1), pk (npz+1), pkz (npz), peln (npz+1)
 void orc_fv_pressures(void* hv, int mode, double kappa, double ptop, double** in_t, double** in_p, double** out_t,
                       double** out_p) {
-  OrcHandle* h = (OrcHandle*)hv; int npz = h->npz;
+  OrcHandle* h = (OrcHandle*)hv; remap_opts() = h->ro; int npz = h->npz;
   int nk[1] = {npz}, nko[4] = {npz + 1, npz + 1, npz, npz + 1};
   auto in = mkio(1, in_t, in_p, nk); auto out = mkio(4, out_t, out_p, nko);
   drive(mode, h->bd, in, out, [&](auto& x, auto& y) {
@@ -270,7 +271,7 @@ void orc_fv_pressures(void* hv, int mode, double kappa, double ptop, double** in
 // dyn_core (n_split acoustic steps).  in: u, v, pt, delp   out: u, v, pt, delp, mfx, mfy, cx, cy, pe, peln, pk, pkz
 void orc_dyn_core(void* hv, int mode, double bdt, int n_split, double** in_t, double** in_p, double** out_t,
                   double** out_p) {
-  OrcHandle* h = (OrcHandle*)hv; int npz = h->npz;
+  OrcHandle* h = (OrcHandle*)hv; remap_opts() = h->ro; int npz = h->npz;
   std::vector<int> nk(4, npz); int nko[12] = {npz, npz, npz, npz, npz, npz, npz, npz, npz + 1, npz + 1, npz + 1, npz};
   auto in = mkio(4, in_t, in_p, nk.data()); auto out = mkio(12, out_t, out_p, nko);
   drive(mode, h->bd, in, out, [&](auto& x, auto& y) {
@@ -286,7 +287,7 @@ void orc_dyn_core(void* hv, int mode, double bdt, int n_split, double** in_t, do
 // non-hydrostatic dyn_core (n_split acoustic steps).  in: u, v, pt, delp, w, delz   out: u, v, pt, delp, w, delz (npz), pe, peln, pk, zh (npz+1)
 void orc_dyn_core_nh(void* hv, int mode, double bdt, int n_split, double a_imp, double p_fac, double scale_z, double** in_t, double** in_p,
                      double** out_t, double** out_p) {
-  OrcHandle* h = (OrcHandle*)hv; int npz = h->npz;
+  OrcHandle* h = (OrcHandle*)hv; remap_opts() = h->ro; int npz = h->npz;
   std::vector<int> nk(6, npz); int nko[10] = {npz, npz, npz, npz, npz, npz, npz + 1, npz + 1, npz + 1, npz + 1};
   auto in = mkio(6, in_t, in_p, nk.data()); auto out = mkio(10, out_t, out_p, nko);
   NhOpts nh; nh.a_imp = a_imp; nh.p_fac = p_fac; nh.scale_z = scale_z;
@@ -303,7 +304,7 @@ void orc_dyn_core_nh(void* hv, int mode, double bdt, int n_split, double a_imp, 
 // fv_dynamics, non-hydrostatic.  in: u, v, pt (temperature), delp, w, delz, q[nq]   out: the same
 void orc_fv_dynamics_nh(void* hv, int mode, int nq, double bdt, int n_split, int k_split, double a_imp, double p_fac, double scale_z, double** in_t,
                         double** in_p, double** out_t, double** out_p) {
-  OrcHandle* h = (OrcHandle*)hv; int npz = h->npz;
+  OrcHandle* h = (OrcHandle*)hv; remap_opts() = h->ro; int npz = h->npz;
   std::vector<int> nk(6 + nq, npz);
   auto in = mkio(6 + nq, in_t, in_p, nk.data()); auto out = mkio(6 + nq, out_t, out_p, nk.data());
   NhOpts nh; nh.a_imp = a_imp; nh.p_fac = p_fac; nh.scale_z = scale_z;
@@ -321,7 +322,7 @@ void orc_fv_dynamics_nh(void* hv, int mode, int nq, double bdt, int n_split, int
 
 // tracer_2d.  in: dp1, mfx, mfy, cx, cy, q[nq]   out: q[nq]
 void orc_tracer_2d(void* hv, int mode, int nq, double** in_t, double** in_p, double** out_t, double** out_p) {
-  OrcHandle* h = (OrcHandle*)hv; int npz = h->npz;
+  OrcHandle* h = (OrcHandle*)hv; remap_opts() = h->ro; int npz = h->npz;
   std::vector<int> nk(5 + nq, npz), nko(nq, npz);
   auto in = mkio(5 + nq, in_t, in_p, nk.data()); auto out = mkio(nq, out_t, out_p, nko.data());
   drive(mode, h->bd, in, out, [&](auto& x, auto& y) {
@@ -336,7 +337,7 @@ void orc_tracer_2d(void* hv, int mode, int nq, double** in_t, double** in_p, dou
 // Lagrangian_to_Eulerian.  in: pe, peln, pk (npz+1), pt, delp, u, v, q[nq]
 //                          out: pe, peln, pk (npz+1), pkz, pt, delp, u, v, q[nq]
 void orc_remap(void* hv, int mode, int nq, int last_step, double** in_t, double** in_p, double** out_t, double** out_p) {
-  OrcHandle* h = (OrcHandle*)hv; int npz = h->npz;
+  OrcHandle* h = (OrcHandle*)hv; remap_opts() = h->ro; int npz = h->npz;
   std::vector<int> nk(7 + nq, npz), nko(8 + nq, npz);
   nk[0] = nk[1] = nk[2] = npz + 1; nko[0] = nko[1] = nko[2] = npz + 1;
   auto in = mkio(7 + nq, in_t, in_p, nk.data()); auto out = mkio(8 + nq, out_t, out_p, nko.data());
@@ -355,7 +356,7 @@ void orc_remap(void* hv, int mode, int nq, int last_step, double** in_t, double*
 //                                                       out: u, v, pt(=T), delp, q[nq]
 void orc_fv_dynamics(void* hv, int mode, int nq, double bdt, int n_split, int k_split, double** in_t, double** in_p,
                      double** out_t, double** out_p) {
-  OrcHandle* h = (OrcHandle*)hv; int npz = h->npz;
+  OrcHandle* h = (OrcHandle*)hv; remap_opts() = h->ro; int npz = h->npz;
   std::vector<int> nk(8 + nq, npz), nko(4 + nq, npz);
   nk[4] = nk[5] = nk[6] = npz + 1;
   auto in = mkio(8 + nq, in_t, in_p, nk.data()); auto out = mkio(4 + nq, out_t, out_p, nko.data());
@@ -391,7 +392,7 @@ static std::vector<IO> mkio6(int n, double** traj, double** pert, const int* nk,
 }
 // dyn_core on the cube.  in: u, v, pt, delp   out: u, v, pt, delp, mfx, mfy, cx, cy, pe, peln, pk, pkz
 void orc_cube_dyn_core(void* cv, int mode, double bdt, int n_split, double** in_t, double** in_p, double** out_t, double** out_p) {
-  OrcCube* c = (OrcCube*)cv; OrcHandle* h = c->f[0]; const int npz = h->npz;
+  OrcCube* c = (OrcCube*)cv; OrcHandle* h = c->f[0]; remap_opts() = h->ro; const int npz = h->npz;
   const size_t np = (size_t)h->bd.pi() * h->bd.pj();
   std::vector<int> nk(4, npz); int nko[12] = {npz, npz, npz, npz, npz, npz, npz, npz, npz + 1, npz + 1, npz + 1, npz};
   auto in = mkio6(4, in_t, in_p, nk.data(), np); auto out = mkio6(12, out_t, out_p, nko, np);
@@ -408,7 +409,7 @@ void orc_cube_dyn_core(void* cv, int mode, double bdt, int n_split, double** in_
 }
 // tracer_2d on the cube (global sub-cycling count, halo exchange between sub-steps).  in: dp1, mfx, mfy, cx, cy, q[nq]   out: q[nq]
 void orc_cube_tracer_2d(void* cv, int mode, int nq, double** in_t, double** in_p, double** out_t, double** out_p) {
-  OrcCube* c = (OrcCube*)cv; OrcHandle* h = c->f[0]; const int npz = h->npz;
+  OrcCube* c = (OrcCube*)cv; OrcHandle* h = c->f[0]; remap_opts() = h->ro; const int npz = h->npz;
   const size_t np = (size_t)h->bd.pi() * h->bd.pj();
   std::vector<int> nk(5 + nq, npz), nko(nq, npz);
   auto in = mkio6(5 + nq, in_t, in_p, nk.data(), np); auto out = mkio6(nq, out_t, out_p, nko.data(), np);
@@ -428,7 +429,7 @@ void orc_cube_tracer_2d(void* cv, int mode, int nq, double** in_t, double** in_p
 // fv_dynamics on the cube.  in: u, v, pt(=T), delp, pe, peln, pk (npz+1), pkz, q[nq]   out: u, v, pt(=T), delp, q[nq]
 void orc_cube_fv_dynamics(void* cv, int mode, int nq, double bdt, int n_split, int k_split, double** in_t, double** in_p,
                           double** out_t, double** out_p) {
-  OrcCube* c = (OrcCube*)cv; OrcHandle* h = c->f[0]; const int npz = h->npz;
+  OrcCube* c = (OrcCube*)cv; OrcHandle* h = c->f[0]; remap_opts() = h->ro; const int npz = h->npz;
   const size_t np = (size_t)h->bd.pi() * h->bd.pj();
   std::vector<int> nk(8 + nq, npz), nko(4 + nq, npz);
   nk[4] = nk[5] = nk[6] = npz + 1;
@@ -453,7 +454,7 @@ void orc_cube_fv_dynamics(void* cv, int mode, int nq, double bdt, int n_split, i
 // six faces, non-hydrostatic.  in / out: u, v, pt (temperature), delp, w, delz, q[nq]
 void orc_cube_fv_dynamics_nh(void* cv, int mode, int nq, double bdt, int n_split, int k_split, double a_imp, double p_fac, double scale_z,
                              double** in_t, double** in_p, double** out_t, double** out_p) {
-  OrcCube* c = (OrcCube*)cv; OrcHandle* h = c->f[0]; const int npz = h->npz;
+  OrcCube* c = (OrcCube*)cv; OrcHandle* h = c->f[0]; remap_opts() = h->ro; const int npz = h->npz;
   const size_t np = (size_t)h->bd.pi() * h->bd.pj();
   std::vector<int> nk(6 + nq, npz);
   auto in = mkio6(6 + nq, in_t, in_p, nk.data(), np); auto out = mkio6(6 + nq, out_t, out_p, nk.data(), np);

@@ -13,7 +13,12 @@
 #include "dyn_core.hpp"
 
 namespace orc {
-struct RemapOpts { int kord_tm = -17, kord_mt = 17, kord_wz = 17, kord_tr = 17; };
+struct RemapOpts { int kord_tm = -17, kord_mt = 17, kord_wz = 17, kord_tr = 17, kord_tm_pert = -17, kord_mt_pert = 17, kord_wz_pert = 17, kord_tr_pert = 17; };
+// trajectory / perturbation profile of one map (split_kord): equal -> one map; else the _TLM map with the perturbation profile on a copy
+// and the nonlinear map with the trajectory profile for the values (fv_mapz_tlm.F90:494-523, :596-637, :780-827)
+// the options of the instance a C-ABI call runs on (set at every entry point of capi.cpp)
+inline RemapOpts& remap_opts() { static thread_local RemapOpts r; return r; }
+struct Kord { int traj = 17, pert = 17; double qmin = 0.; bool scalar = false; Kord() {} Kord(int t, int p, bool sc = false, double qm = 0.) : traj(t), pert(p), qmin(qm), scalar(sc) {} };
 
 // scalar_profile / cs_profile, iv != -2, |kord| > 16 (fv_mapz_tlm.F90:8424-8509 == :8592-8666)
 template <class T>
@@ -57,15 +62,110 @@ void cs_profile_linear(std::vector<T>& a1, std::vector<T>& a2, std::vector<T>& a
   }
 }
 
+// cs_limiters, fv_mapz_tlm.F90:6434-6519 (model/fv_mapz_nlm.F90:2467-2542): one layer
+inline void cs_limiters(bool extm, double a1, double& a2, double& a3, double& a4, int iv) {
+  const double r12 = 1. / 12.;
+  if (iv == 0) {          // positive definite constraint
+    if (a1 <= 0.) { a2 = a1; a3 = a1; a4 = 0.; }
+    else if (std::fabs(a3 - a2) < -a4) {
+      if (a1 + 0.25 * (a3 - a2) * (a3 - a2) / a4 + a4 * r12 < 0.) {
+        if (a1 < a3 && a1 < a2) { a3 = a1; a2 = a1; a4 = 0.; }
+        else if (a3 > a2) { a4 = 3. * (a2 - a1); a3 = a2 - a4; }
+        else { a4 = 3. * (a3 - a1); a2 = a3 - a4; }
+      }
+    }
+  } else {
+    const bool flat = (iv == 1) ? ((a1 - a2) * (a1 - a3) >= 0.) : extm;
+    if (flat) { a2 = a1; a3 = a1; a4 = 0.; }
+    else {
+      const double da1 = a3 - a2, da2 = da1 * da1, a6da = a4 * da1;
+      if (a6da < -da2) { a4 = 3. * (a2 - a1); a3 = a2 - a4; }
+      else if (a6da > da2) { a4 = 3. * (a3 - a1); a2 = a3 - a4; }
+    }
+  }
+}
+// The limited profiles of the NONLINEAR remap, |kord| in {9, 10, 11}: cs_profile (fv_mapz_tlm.F90:5566-6433) and scalar_profile
+// (:3240-4228; = cs_profile + the q < qmin tests), model/fv_mapz_nlm.F90:2113-2464 / :1730-2110.  Values only: the reference
+// differentiates the linear profile alone (:8653-8666).  a2, a3 enter as the unlimited edge values of the tridiagonal solve.
+inline void cs_profile_limited(const std::vector<double>& a1, std::vector<double>& a2, std::vector<double>& a3, std::vector<double>& a4, int km, int iv,
+                               int kord, bool scalar, double qmin) {
+  const int ak = std::abs(kord);
+  assert(ak == 9 || ak == 10 || ak == 11);
+  std::vector<double> q(km + 2), gam(km + 3, 0.);
+  std::vector<char> extm(km + 2, 0);
+  for (int k = 1; k <= km; ++k) q[k] = a2[k];
+  q[km + 1] = a3[km];
+  auto mx = [](double a, double b) { return a > b ? a : b; };
+  auto mn = [](double a, double b) { return a < b ? a : b; };
+  q[2] = mn(q[2], mx(a1[1], a1[2])); q[2] = mx(q[2], mn(a1[1], a1[2]));       // large-scale constraints
+  for (int k = 2; k <= km; ++k) gam[k] = a1[k] - a1[k - 1];
+  for (int k = 3; k <= km - 1; ++k) {
+    if (gam[k - 1] * gam[k + 1] > 0.) { q[k] = mn(q[k], mx(a1[k - 1], a1[k])); q[k] = mx(q[k], mn(a1[k - 1], a1[k])); }
+    else if (gam[k - 1] > 0.) q[k] = mx(q[k], mn(a1[k - 1], a1[k]));
+    else { q[k] = mn(q[k], mx(a1[k - 1], a1[k])); if (iv == 0) q[k] = mx(0., q[k]); }
+  }
+  q[km] = mn(q[km], mx(a1[km - 1], a1[km])); q[km] = mx(q[km], mn(a1[km - 1], a1[km]));
+  for (int k = 1; k <= km; ++k) { a2[k] = q[k]; a3[k] = q[k + 1]; }
+  for (int k = 1; k <= km; ++k)
+    extm[k] = (k == 1 || k == km) ? ((a2[k] - a1[k]) * (a3[k] - a1[k]) > 0.) : (gam[k] * gam[k + 1] < 0.);
+  // top two layers
+  if (iv == 0) a2[1] = mx(0., a2[1]);
+  else if (iv == -1) { if (a2[1] * a1[1] <= 0.) a2[1] = 0.; }
+  else if (iv == 2) { a2[1] = a1[1]; a3[1] = a1[1]; a4[1] = 0.; }
+  if (iv != 2) { a4[1] = 3. * (2. * a1[1] - (a2[1] + a3[1])); cs_limiters(extm[1], a1[1], a2[1], a3[1], a4[1], 1); }
+  a4[2] = 3. * (2. * a1[2] - (a2[2] + a3[2]));
+  cs_limiters(extm[2], a1[2], a2[2], a3[2], a4[2], 2);
+  auto huynh = [&](int k) {
+    const double pmp_1 = a1[k] - 2. * gam[k + 1], lac_1 = pmp_1 + 1.5 * gam[k + 2];
+    a2[k] = mn(mx(a2[k], mn(a1[k], mn(pmp_1, lac_1))), mx(a1[k], mx(pmp_1, lac_1)));
+    const double pmp_2 = a1[k] + 2. * gam[k], lac_2 = pmp_2 - 1.5 * gam[k - 1];
+    a3[k] = mn(mx(a3[k], mn(a1[k], mn(pmp_2, lac_2))), mx(a1[k], mx(pmp_2, lac_2)));
+  };
+  for (int k = 3; k <= km - 2; ++k) {      // Huynh's second constraint in the interior
+    const bool small = scalar && a1[k] < qmin;
+    auto flat = [&]() { a2[k] = a1[k]; a3[k] = a1[k]; a4[k] = 0.; };
+    if (ak == 9) {
+      if (extm[k] && (extm[k - 1] || extm[k + 1] || small)) flat();
+      else {
+        a4[k] = 3. * (2. * a1[k] - (a2[k] + a3[k]));
+        if (std::fabs(a4[k]) > std::fabs(a2[k] - a3[k])) { huynh(k); a4[k] = 3. * (2. * a1[k] - (a2[k] + a3[k])); }
+      }
+    } else if (ak == 10) {
+      if (extm[k]) {
+        if (small || extm[k - 1] || extm[k + 1]) flat();
+        else a4[k] = 6. * a1[k] - 3. * (a2[k] + a3[k]);
+      } else {
+        a4[k] = 6. * a1[k] - 3. * (a2[k] + a3[k]);
+        if (std::fabs(a4[k]) > std::fabs(a2[k] - a3[k])) { huynh(k); a4[k] = 6. * a1[k] - 3. * (a2[k] + a3[k]); }
+      }
+    } else {                               // 11
+      if (extm[k] && (extm[k - 1] || extm[k + 1] || small)) flat();
+      else a4[k] = 3. * (2. * a1[k] - (a2[k] + a3[k]));
+    }
+    if (iv == 0) cs_limiters(extm[k], a1[k], a2[k], a3[k], a4[k], 0);
+  }
+  // bottom two layers
+  if (iv == 0) a3[km] = mx(0., a3[km]);
+  else if (iv == -1) { if (a3[km] * a1[km] <= 0.) a3[km] = 0.; }
+  for (int k = km - 1; k <= km; ++k) {
+    a4[k] = 3. * (2. * a1[k] - (a2[k] + a3[k]));
+    cs_limiters(extm[k], a1[k], a2[k], a3[k], a4[k], k == km - 1 ? 2 : 1);
+  }
+}
+
 // One column of map_scalar / map1_ppm / map1_q2 (fv_mapz_tlm.F90:7812-7905): q1 on pe1 (km layers)
 // -> q2 on pe2 (kn layers).  1-based vectors.
 template <class T>
 void map_col(int km, const std::vector<T>& pe1, const std::vector<T>& q1, int kn, const std::vector<T>& pe2,
-             std::vector<T>& q2, int iv = 1, T qs = T(0.)) {
+             std::vector<T>& q2, int iv = 1, T qs = T(0.), int kord = 17, bool scalar = false, double qmin = 0.) {
   const double r3 = 1. / 3., r23 = 2. / 3.;
   std::vector<T> dp1(km + 1), a1(km + 1), a2(km + 1), a3(km + 1), a4(km + 1);
   for (int k = 1; k <= km; ++k) { dp1[k] = pe1[k + 1] - pe1[k]; a1[k] = q1[k]; }
   cs_profile_linear(a1, a2, a3, a4, dp1, km, iv, qs);
+  if (std::abs(kord) <= 16) {      // the limited profiles: nonlinear routine only
+    if constexpr (std::is_same<T, double>::value) cs_profile_limited(a1, a2, a3, a4, km, iv, kord, scalar, qmin);
+    else { std::fprintf(stderr, "oracle: limited remap profile on a differentiated scalar\n"); std::abort(); }
+  }
   int k0 = 1;
   T qsum = T(0.);
   for (int k = 1; k <= kn; ++k) {
@@ -95,6 +195,18 @@ void map_col(int km, const std::vector<T>& pe1, const std::vector<T>& q1, int kn
     }
     q2[k] = qsum / (pe2[k + 1] - pe2[k]);
   }
+}
+
+template <class T>
+void map_col_split(int km, const std::vector<T>& pe1, const std::vector<T>& q1, int kn, const std::vector<T>& pe2, std::vector<T>& q2, int iv, T qs, const Kord& kd) {
+  if (std::abs(kd.traj) == std::abs(kd.pert)) { map_col(km, pe1, q1, kn, pe2, q2, iv, qs, kd.traj, kd.scalar, kd.qmin); return; }
+  map_col(km, pe1, q1, kn, pe2, q2, iv, qs, kd.pert, kd.scalar, kd.qmin);
+  std::vector<double> p1(pe1.size()), p2(pe2.size()), qd(q1.size()), od(q2.size());
+  for (size_t n = 0; n < pe1.size(); ++n) p1[n] = val(pe1[n]);
+  for (size_t n = 0; n < pe2.size(); ++n) p2[n] = val(pe2[n]);
+  for (size_t n = 0; n < q1.size(); ++n) qd[n] = val(q1[n]);
+  map_col<double>(km, p1, qd, kn, p2, od, iv, val(qs), kd.traj, kd.scalar, kd.qmin);
+  for (int k = 1; k <= kn; ++k) set_val(q2[k], od[k]);
 }
 
 // tracer_2d, fv_tracer2d_tlm.F90:1148-1446 (q_split = 0, nord_tr/trdm = 0).  dp1 = delp before dyn_core.
@@ -184,7 +296,7 @@ void l2e_winds(DynState<T>& s, int km, const std::vector<double>& ak, const std:
       for (int k = 2; k <= km + 1; ++k) pe0[k] = 0.5 * (s.pe(i, j - 1, k) + s.pe(i, j, k));
       for (int k = 1; k <= km + 1; ++k) pe3[k] = ak[k - 1] + (0.5 * bk[k - 1]) * (s.pe(i, j - 1, km + 1) + s.pe(i, j, km + 1));
       for (int k = 1; k <= km; ++k) q1[k] = s.u(i, j, k);
-      map_col(km, pe0, q1, km, pe3, q2);
+      map_col_split(km, pe0, q1, km, pe3, q2, -1, T(0.), Kord(remap_opts().kord_mt, remap_opts().kord_mt_pert));
       for (int k = 1; k <= km; ++k) s.u(i, j, k) = q2[k];
     }
     if (j < je + 1)     // map v (:1913-1934)
@@ -196,7 +308,7 @@ void l2e_winds(DynState<T>& s, int km, const std::vector<double>& ak, const std:
           pe3[k] = ak[k - 1] + (0.5 * bk[k - 1]) * (s.pe(i - 1, j, km + 1) + s.pe(i, j, km + 1));
         }
         for (int k = 1; k <= km; ++k) q1[k] = s.v(i, j, k);
-        map_col(km, pe0, q1, km, pe3, q2);
+        map_col_split(km, pe0, q1, km, pe3, q2, -1, T(0.), Kord(remap_opts().kord_mt, remap_opts().kord_mt_pert));
         for (int k = 1; k <= km; ++k) s.v(i, j, k) = q2[k];
       }
   }
@@ -223,11 +335,11 @@ void lagrangian_to_eulerian(bool last_step, DynState<T>& s, int km, double akap,
         pn2[1] = pn1[1]; pn2[km + 1] = pn1[km + 1]; pk2[1] = s.pk(i, j, 1); pk2[km + 1] = s.pk(i, j, km + 1);
         for (int k = 2; k <= km; ++k) { pn2[k] = log(pe2[k]); pk2[k] = exp(akap * pn2[k]); }
         for (int k = 1; k <= km; ++k) q1[k] = s.pt(i, j, k);
-        map_col(km, pn1, q1, km, pn2, q2);       // map_scalar in log p (:1676-1688)
+        map_col_split(km, pn1, q1, km, pn2, q2, 1, T(0.), Kord(remap_opts().kord_tm, remap_opts().kord_tm_pert, true, 184.));       // map_scalar in log p (:1676-1688), t_min = 184
         for (int k = 1; k <= km; ++k) s.pt(i, j, k) = q2[k];
         for (int iq = 0; iq < nq; ++iq) {        // map1_q2 (:1746-1763)
           for (int k = 1; k <= km; ++k) q1[k] = s.q[iq](i, j, k);
-          map_col(km, pe1, q1, km, pe2, q2);
+          map_col_split(km, pe1, q1, km, pe2, q2, 0, T(0.), Kord(remap_opts().kord_tr, remap_opts().kord_tr_pert, true, 0.));
           for (int k = 1; k <= km; ++k) s.q[iq](i, j, k) = q2[k];
         }
         for (int k = 1; k <= km + 1; ++k) { s.pk(i, j, k) = pk2[k]; s.peln(i, j, k) = pn2[k]; pe2s(i, j, k) = pe2[k]; }

@@ -458,18 +458,18 @@ void lagrangian_to_eulerian_nh(bool last_step, DynState<T>& s, NhState<T>& n, co
       pn2[1] = pn1[1]; pn2[km + 1] = pn1[km + 1]; pk2[1] = s.pk(i, j, 1); pk2[km + 1] = s.pk(i, j, km + 1);
       for (int k = 2; k <= km; ++k) { pn2[k] = log(pe2[k]); pk2[k] = exp(akap * pn2[k]); }
       for (int k = 1; k <= km; ++k) q1[k] = s.pt(i, j, k);
-      map_col(km, pn1, q1, km, pn2, q2);
+      map_col_split(km, pn1, q1, km, pn2, q2, 1, T(0.), Kord(remap_opts().kord_tm, remap_opts().kord_tm_pert, true, 184.));
       for (int k = 1; k <= km; ++k) s.pt(i, j, k) = q2[k];
       for (int iq = 0; iq < nq; ++iq) {
         for (int k = 1; k <= km; ++k) q1[k] = s.q[iq](i, j, k);
-        map_col(km, pe1, q1, km, pe2, q2);
+        map_col_split(km, pe1, q1, km, pe2, q2, 0, T(0.), Kord(remap_opts().kord_tr, remap_opts().kord_tr_pert, true, 0.));
         for (int k = 1; k <= km; ++k) s.q[iq](i, j, k) = q2[k];
       }
       for (int k = 1; k <= km; ++k) q1[k] = n.w(i, j, k);
-      map_col(km, pe1, q1, km, pe2, q2, -2, ws(i, j));
+      map_col_split(km, pe1, q1, km, pe2, q2, -2, ws(i, j), Kord(remap_opts().kord_wz, remap_opts().kord_wz_pert));
       for (int k = 1; k <= km; ++k) n.w(i, j, k) = q2[k];
       for (int k = 1; k <= km; ++k) q1[k] = n.delz(i, j, k);
-      map_col(km, pe1, q1, km, pe2, q2);
+      map_col_split(km, pe1, q1, km, pe2, q2, 1, T(0.), Kord(remap_opts().kord_tm, remap_opts().kord_tm_pert));      // delz: map1_ppm, iv = 1, abs(kord_tm) (fv_mapz_tlm.F90:627-637)
       for (int k = 1; k <= km; ++k) n.delz(i, j, k) = -(q2[k] * s.delp(i, j, k));
       for (int k = 1; k <= km + 1; ++k) { s.pk(i, j, k) = pk2[k]; s.peln(i, j, k) = pn2[k]; pe2s(i, j, k) = pe2[k]; }
       for (int k = 1; k <= km; ++k) s.pkz(i, j, k) = exp(akap * log(rrg * s.delp(i, j, k) / n.delz(i, j, k) * s.pt(i, j, k)));

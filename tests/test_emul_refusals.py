@@ -10,7 +10,9 @@ from common import Case
     (dict(hord_dp=5), "hord"),                            # trajectory schemes built: 1, 2, 333, 8, 10
     (dict(hord_mt=6, hord_mt_pert=2), "hord"),
     (dict(hydrostatic=0, a_imp=0.4), "a_imp"),
-    (dict(kord_tm=-9), "kord"),
+    (dict(kord_tm=-8), "kord"),                          # trajectory profiles built: linear (> 16) and the limited 9, 10, 11
+    (dict(kord_tm_pert=-9), "kord"),                     # the perturbation profile is the linear one
+    (dict(hydrostatic=0, kord_wz=9), "kord"),            # limited profiles: hydrostatic remap only
     (dict(kord_tr=8), "kord"),
 ])
 def test_unsupported_options_are_refused(kw, needle):

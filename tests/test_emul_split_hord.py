@@ -118,3 +118,69 @@ def test_nh_cube():
     N.cube_check_nh_fv(c, TL)
     N.cube_check_nh_fv(c, AD)
     N.cube_check_nh_dot_product(c)
+
+
+# ---- split_kord: the trajectory remapped with the limited profiles (cs_profile / scalar_profile, kord 9 / 10 / 11), the perturbation with
+#      the linear one (fv_mapz_tlm.F90:494-523, :596-637, :780-827)
+@pytest.fixture(scope="module", params=[9, 10, 11])
+def kcase(request):
+    k = request.param
+    return Case(nx=12, ny=10, npz=14, n_split=2, k_split=2, dt=1800.0, backend="emul", nq=3, kord_tm=-k, kord_mt=k, kord_tr=k, kord_wz=17)
+
+
+@pytest.mark.parametrize("mode", [TL, AD])
+@pytest.mark.parametrize("last", [0, 1])
+def test_kord_remap(kcase, mode, last):
+    from groups import check_remap
+    check_remap(kcase, mode, last, 1e-11)
+
+
+@pytest.mark.parametrize("mode", [TL, AD])
+def test_kord_fv_dynamics(kcase, mode):
+    check_fv_dynamics(kcase, mode, 1e-10)
+
+
+def test_kord_step_nl_and_dot_product(kcase):
+    from groups import check_step_nl
+    check_step_nl(kcase, 1e-10)
+    lhs, rhs = dot_product_step(kcase)
+    assert abs(lhs - rhs) <= 1e-12 * abs(lhs), (lhs, rhs)
+
+
+def test_operational_pairing_on_the_cube():
+    """trajectory hord 10 / kord 9, perturbation hord 2 (1 in the sponge) / kord 17: six faces, whole step"""
+    from groups import cube_check_fv_dynamics, cube_dot_product_step
+    c = CubeCase(n=8, npz=12, n_split=2, k_split=2, backend="emul", oracle=True, nq=2, kord_tm=-9, kord_mt=9, kord_tr=9, **SPLIT10)
+    cube_check_fv_dynamics(c, TL, 1e-10)
+    cube_check_fv_dynamics(c, AD, 1e-10)
+    lhs, rhs = cube_dot_product_step(c)
+    assert abs(lhs - rhs) <= 1e-12 * abs(lhs), (lhs, rhs)
+
+
+@pytest.mark.parametrize("kord", [9, 10, 11])
+def test_kord_remap_noisy_columns(monkeypatch, kord):
+    """columns with 2-delta-z noise, local extrema, zero and negative tracer values: every branch of the limited profiles (extrema tests,
+    Huynh's constraint, the positive-definite limiter, q < qmin) -- where kord 9, 10 and 11 differ from each other"""
+    import groups
+    c = Case(nx=12, ny=10, npz=16, n_split=1, k_split=1, dt=900.0, backend="emul", nq=3, kord_tm=-kord, kord_mt=kord, kord_tr=kord)
+    rng = np.random.default_rng(5)
+    orig = groups._dyn_outputs
+
+    def noisy(cc):
+        T, P = orig(cc)
+        saw = np.where(np.arange(T["pt"].shape[0])[:, None, None] % 2 == 0, 1.0, -1.0)
+        T["pt"] = T["pt"] * (1.0 + 0.02 * saw * rng.random(T["pt"].shape))
+        T["pt"][3:6] *= 0.55                                   # below t_min = 184 K in places (T_v = pt * pkz)
+        T["u"] = T["u"] + 4.0 * saw[: T["u"].shape[0]] * rng.random(T["u"].shape) - 2.0
+        T["v"] = T["v"] * (1.0 - 1.5 * rng.random(T["v"].shape))     # sign changes
+        return T, P
+    monkeypatch.setattr(groups, "_dyn_outputs", noisy)
+    for n in range(c.nq):
+        q = c.qtraj[n][0]
+        saw = np.where(np.arange(q.shape[0])[:, None, None] % 2 == 0, 1.0, -1.0)
+        q *= (1.0 + 0.9 * saw * rng.random(q.shape))
+        q[rng.random(q.shape) < 0.1] = 0.0
+        q[rng.random(q.shape) < 0.03] *= -1.0
+    groups.check_remap(c, TL, 0, 1e-11)
+    groups.check_remap(c, TL, 1, 1e-11)
+    groups.check_remap(c, AD, 1, 1e-11)

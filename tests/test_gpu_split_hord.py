@@ -60,3 +60,29 @@ def test_dot_product_c96l32_six_faces():
     c = CubeCase(n=96, npz=32, n_split=3, k_split=2, dt=900.0, backend="hip", oracle=False, nq=2, **SPLIT10)
     lhs, rhs = cube_dot_product_step(c)
     assert abs(lhs - rhs) <= 1e-11 * abs(lhs), (lhs, rhs)
+
+
+@pytest.mark.parametrize("kord", [9, 10, 11])
+def test_split_kord(kord):
+    """trajectory remapped with the limited profiles, perturbation with the linear one: remap alone and the whole step"""
+    from common import Case
+    from groups import check_remap, check_fv_dynamics, dot_product_step, check_step_nl
+    c = Case(nx=24, ny=20, npz=14, n_split=2, k_split=2, dt=1800.0, backend="hip", nq=3, kord_tm=-kord, kord_mt=kord, kord_tr=kord)
+    check_remap(c, TL, 0, 1e-11)
+    check_remap(c, AD, 1, 1e-11)
+    check_fv_dynamics(c, TL, 1e-10)
+    check_fv_dynamics(c, AD, 1e-10)
+    check_step_nl(c, 1e-10)
+    lhs, rhs = dot_product_step(c)
+    assert abs(lhs - rhs) <= 1e-12 * abs(lhs), (lhs, rhs)
+
+
+def test_operational_pairing_six_faces():
+    """trajectory hord 10 / kord 9, perturbation hord 2 (1 in the sponge) / kord 17"""
+    from common import CubeCase
+    from groups import cube_check_fv_dynamics, cube_dot_product_step
+    c = CubeCase(n=16, npz=12, n_split=2, k_split=2, backend="hip", oracle=True, nq=2, kord_tm=-9, kord_mt=9, kord_tr=9, **SPLIT10)
+    cube_check_fv_dynamics(c, TL, 1e-10)
+    cube_check_fv_dynamics(c, AD, 1e-10)
+    lhs, rhs = cube_dot_product_step(c)
+    assert abs(lhs - rhs) <= 1e-11 * abs(lhs), (lhs, rhs)
