@@ -105,6 +105,8 @@ def scheme_string(o, nh):
     s = "hord mt/vt/tm/dp/tr=%d/%d/%d/%d/%d (sponge: %s), kord=%d, nord=%d" % (o.hord_mt_pert, o.hord_vt_pert, o.hord_tm_pert, o.hord_dp_pert, o.hord_tr_pert, sponge, abs(o.kord_tm), o.nord)
     if (o.hord_mt, o.hord_vt, o.hord_tm, o.hord_dp, o.hord_tr) != (o.hord_mt_pert, o.hord_vt_pert, o.hord_tm_pert, o.hord_dp_pert, o.hord_tr_pert):
         s += ", split_hord: trajectory %d/%d/%d/%d/%d" % (o.hord_mt, o.hord_vt, o.hord_tm, o.hord_dp, o.hord_tr)
+    if abs(o.kord_tm) != abs(o.kord_tm_pert):
+        s = s.replace("kord=%d" % abs(o.kord_tm), "kord=%d (split_kord: trajectory %d)" % (abs(o.kord_tm_pert), abs(o.kord_tm)))
     if nh:
         s += ", a_imp=%g (%s)" % (o.a_imp, "SIM1" if o.a_imp > 0.999 else "SIM")
     return s
@@ -126,6 +128,7 @@ def main():
                     help="BASELINE config 3: w, delz prognostic, nh_core active (hydrostatic = 0); not the headline workload")
     ap.add_argument("--hord-traj", type=int, default=0,
                     help="trajectory advection scheme (8 or 10) with the perturbation schemes left at their defaults: split_hord (not the headline configuration)")
+    ap.add_argument("--kord-traj", type=int, default=0, help="trajectory remap profile (9, 10 or 11) with the linear perturbation profile: split_kord, hydrostatic only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-host-transport", action="store_true",
                     help="multi-rank rehearsal on ONE GPU (RCCL refuses two ranks per device): gloo process group, halo messages staged "
@@ -201,6 +204,8 @@ def main():
         active = len(cube.faces_of(rank, world)) > 0
         if active:
             nhkw = dict(hydrostatic=0) if args.nonhydrostatic else {}
+            if args.kord_traj:
+                nhkw.update(kord_tm=-args.kord_traj, kord_mt=args.kord_traj, kord_tr=args.kord_traj)
             if args.hord_traj:
                 nhkw.update(hord_mt=args.hord_traj, hord_vt=args.hord_traj, hord_tm=args.hord_traj, hord_dp=args.hord_traj, hord_tr=args.hord_traj)
             c = CubeCase(n=args.nx, npz=args.npz, n_split=args.n_split, k_split=args.k_split, dt=args.dt, backend="hip", nq=args.nq,
