@@ -77,6 +77,7 @@ HD TV operator/(double a, const TV& b) { const double q = a / b.v; return tv1n(b
 HD TV dlog(const TV& a) { return tv1n(a, log(a.v), 1. / a.v); }
 HD TV dexp(const TV& a) { const double e = exp(a.v); return tv1n(a, e, e); }
 HD double val(const TV& a) { return a.v; }
+HD void set_val(TV& a, double x) { a.v = x; }      // the derivative stays (split_kord: values by the limited profile)
 // scale 1 form (what the workspace stores)
 HD TV tv_unit(const TV& x) { return (x.id < 0 || x.s == 1.) ? x : TV(x.v, 1., x.t->push(x.id, -1, x.s, 0.), x.t); }
 

@@ -584,7 +584,6 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
   for (int kd : {o.kord_tm, o.kord_mt, o.kord_wz, o.kord_tr}) {
     const int ak = kd < 0 ? -kd : kd;
     if (ak <= 16 && !(ak >= 9 && ak <= 11)) { err = "kord_tm/kord_mt/kord_wz/kord_tr: the linear profile (|kord| > 16) or, for the trajectory, the limited profiles 9, 10, 11"; return false; }
-    if (ak <= 16 && !o.hydrostatic) { err = "kord: limited trajectory profiles (split_kord) are built for the hydrostatic remap only"; return false; }
     if (ak <= 16 && npz < 6) { err = "kord: limited trajectory profiles need npz >= 6"; return false; }
   }
   //   tracer advection: the perturbation runs with the trajectory scheme (no split_hord recompute); hord_tr_ks_* are read by the
@@ -763,6 +762,7 @@ inline NhColArgs Dycore::nh_args(double dt_) const {
   NhColArgs a{};
   a.g = g; a.ws = nh_ws; a.ws_stride = (size_t)g.ntile * g.plane; a.tape = nh_tape; a.hs = hs_dev; a.lev = lev_dev;
   a.zvir = opt.zvir; a.cp_air = opt.cp_air;
+  a.kord_tm = opt.kord_tm; a.kord_tr = opt.kord_tr; a.kord_wz = opt.kord_wz;
   { const char* e = std::getenv("FV3LM_NH_TAPE"); a.use_tape = (e && e[0] == '1') ? 1 : 0; }
   a.dt = dt_; a.akap = opt.akap; a.ptop = opt.ptop; a.rdgas = opt.rdgas; a.grav = opt.grav; a.a_imp = opt.a_imp; a.p_fac = opt.p_fac; a.scale_z = opt.scale_z;
   return a;
@@ -773,7 +773,8 @@ inline void Dycore::add_col(Program& P, const char* group, int kind, const NhCol
   static const char* tags[][3] = {{"riem_c.nl", "riem_c.tl", "riem_c.ad"}, {"riem3.nl", "riem3.tl", "riem3.ad"}, {"edge_profile.nl", "edge_profile.tl", "edge_profile.ad"},
                                   {"zh_init.nl", "zh_init.tl", "zh_init.ad"}, {"p_ring.nl", "p_ring.tl", "p_ring.ad"},
                                   {"remap_field_nh.nl", "remap_field_nh.tl", "remap_field_nh.ad"}, {"remap_press_nh.nl", "remap_press_nh.tl", "remap_press_nh.ad"},
-                                  {"remap_w_nh.nl", "remap_w_nh.tl", "remap_w_nh.ad"}};
+                                  {"remap_w_nh.nl", "remap_w_nh.tl", "remap_w_nh.ad"}, {"remap_field_nh_lim.nl", "remap_field_nh_lim.tl", "remap_field_nh_lim.ad"},
+                                  {"remap_w_nh_lim.nl", "remap_w_nh_lim.tl", "remap_w_nh_lim.ad"}};
   Op op{group, [self, kind, a, r, skip, when](Exec& e, int mode) {
     if (when == 2 && !self->last_acoustic) return;
     NhColArgs b = a; b.last_call = (when == 3 ? self->remap_last : self->last_acoustic) ? 1 : 0;

@@ -272,12 +272,15 @@ inline void Dynamics::build_remap_nh() {
   const Rect A = R(1, g.nx, 1, g.ny);
   t_m = S("remap_t", npz); w_m = S("remap_w", npz); dz_m = S("remap_dz", npz);
   for (int n = 0; n < nq; ++n) { char nm[24]; std::snprintf(nm, sizeof nm, "remap_q%d", n + 1); q_m.push_back(S(nm, npz)); }
+  // split_kord: the column kernels that also run the trajectory's limited profile (instantiations of their own)
+  const bool anylim = kord_limited(opt.kord_tm) || kord_limited(opt.kord_tr) || kord_limited(opt.kord_wz);
+  const int kfield = anylim ? NHC_RM_FIELD_LIM : NHC_RM_FIELD, kw = anylim ? NHC_RM_W_LIM : NHC_RM_W;
   auto args = [&](int what) { NhColArgs a = nh_args(0.); a.ak = ak_dev; a.bk = bk_dev; a.what = what; return a; };
   { NhColArgs a = args(0); a.f[0] = f("pe"); a.f[1] = f("peln"); a.f[2] = f("pt"); a.f[3] = f("delp"); a.f[4] = f("delz"); a.f[5] = t_m;
-    add_col(remap_nh, "remap", NHC_RM_FIELD, a, A, Rect{1, 0, 1, 0}, 3); }
-  { NhColArgs a = args(1); a.f[0] = f("pe"); a.f[1] = f("w"); a.f[2] = f("ws"); a.f[3] = w_m; add_col(remap_nh, "remap", NHC_RM_W, a, A, Rect{1, 0, 1, 0}, 3); }
-  { NhColArgs a = args(2); a.f[0] = f("pe"); a.f[1] = f("delz"); a.f[2] = f("delp"); a.f[3] = dz_m; add_col(remap_nh, "remap", NHC_RM_FIELD, a, A, Rect{1, 0, 1, 0}, 3); }
-  for (int n = 0; n < nq; ++n) { NhColArgs a = args(3); a.f[0] = f("pe"); a.f[1] = q[n]; a.f[2] = q_m[n]; add_col(remap_nh, "remap", NHC_RM_FIELD, a, A, Rect{1, 0, 1, 0}, 3); }
+    add_col(remap_nh, "remap", kfield, a, A, Rect{1, 0, 1, 0}, 3); }
+  { NhColArgs a = args(1); a.f[0] = f("pe"); a.f[1] = f("w"); a.f[2] = f("ws"); a.f[3] = w_m; add_col(remap_nh, "remap", kw, a, A, Rect{1, 0, 1, 0}, 3); }
+  { NhColArgs a = args(2); a.f[0] = f("pe"); a.f[1] = f("delz"); a.f[2] = f("delp"); a.f[3] = dz_m; add_col(remap_nh, "remap", kfield, a, A, Rect{1, 0, 1, 0}, 3); }
+  for (int n = 0; n < nq; ++n) { NhColArgs a = args(3); a.f[0] = f("pe"); a.f[1] = q[n]; a.f[2] = q_m[n]; add_col(remap_nh, "remap", kfield, a, A, Rect{1, 0, 1, 0}, 3); }
   { NhColArgs a = args(nq > 0 ? 1 : 0); a.f[0] = f("pe"); a.f[1] = f("peln"); a.f[2] = f("pk"); a.f[3] = t_m; a.f[4] = dz_m; a.f[5] = nq > 0 ? q_m[0] : Fld{};
     a.f[6] = f("delp"); a.f[7] = f("pkz"); a.f[8] = f("pt"); a.f[9] = pe2; add_col(remap_nh, "remap", NHC_RM_PRESS, a, A, Rect{1, 0, 1, 0}, 3);
     remap_nh.back().accum = true; }     // overwrites delp, peln, pk: left out of the adjoint's trajectory recompute

@@ -25,6 +25,7 @@ struct NhColArgs {
   const double *ak, *bk;               // hybrid coefficients, device [npz+1] (vertical remap)
   double zvir, cp_air;
   int last_call, what;
+  int kord_tm, kord_tr, kord_wz;       // trajectory remap profiles (|kord| <= 16: the limited profile gives the values, kinds NHC_RM_*_LIM)
   int use_tape;                        // adjoint of the implicit solvers: 1 = taped run of the generic code (FV3LM_NH_TAPE=1), 0 = nh_ad.h
 };
 HD void riem_c_col_ad(const NhColArgs& a, const ColWs& ws, int tile, int i, int j, double hs);
@@ -333,10 +334,14 @@ HD void ring_col(const IO& io, const NhColArgs& a) {
 // RS_P1 source interfaces (km+1), RS_Q1 layer means (km), RS_P2 target interfaces (km+1).  iv = -2: vertical velocity, the
 // value qs at the lower boundary is given (:8549-8590).
 enum { RS_P1 = 0, RS_Q1, RS_P2, RS_G, RS_E, RS_COUNT };
-template <class IO, class FOut>
-HD void map_col_io(const IO& io, int km, const ColWs& ws, int iv, const typename IO::T& qs, const FOut& out) {
+// LIM + a limited trajectory profile P: the values of the outputs come from the limited profile (remap.h map_loop_lim on the values, kept in
+// the gam slot, which the solve no longer needs), the sensitivities stay those of the linear profile (split_kord).
+template <bool LIM = false, class IO, class FOut>
+HD void map_col_io(const IO& io, int km, const ColWs& ws, int iv, const typename IO::T& qs, const FOut& out0, const LimProfile& P = LimProfile{17, 1, false, 0.}) {
   typedef typename IO::T T;
   WArr<IO> pe1{io, ws, RS_P1}, q1{io, ws, RS_Q1}, pe2{io, ws, RS_P2}, gam{io, ws, RS_G}, qe{io, ws, RS_E};
+  const bool lim = LIM && kord_limited(P.kord);
+  auto out = [&](int k, T x) { if (LIM && lim) set_val(x, val(gam(k))); out0(k, x); };
   if (iv == -2) {
     gam.set(2, io.cst(0.5)); qe.set(1, 1.5 * q1(1));
     for (int k = 2; k <= km - 1; ++k) {
@@ -369,6 +374,9 @@ HD void map_col_io(const IO& io, int km, const ColWs& ws, int iv, const typename
     qe.set(km + 1, qf);
     for (int k = km; k >= 1; --k) { qf = qe(k) - gam(k) * qf; qe.set(k, qf); }
   }
+  if constexpr (LIM) if (lim)
+    map_loop_lim(P, km, [&](int k) { return val(pe1(k)); }, [&](int k) { return val(q1(k)); }, [&](int k) { return val(pe2(k)); }, [&](int k) { return val(qe(k)); },
+                 [&](int k, double x) { gam.set(k, io.cst(x)); });
   int k0 = 1;
   T qsum = io.cst(0.);
   for (int k = 1; k <= km; ++k) {
@@ -420,7 +428,7 @@ HD void rm_target(const IO& io, const NhColArgs& a, const ColWs& ws, int slot_pe
 //   1  f: 0 pe 1 w 2 ws -> 3 w                                         (map1_ppm, iv = -2, :1772-1780)
 //   2  f: 0 pe 1 delz 2 delp -> 3 delz                                 (specific volume / g :1635-1641, map1_ppm :1782-1796)
 //   3  f: 0 pe 1 q -> 2 q                                              (map1_q2 :1746-1763)
-template <class IO>
+template <bool LIM = false, class IO>
 HD void remap_field_col_nh(const IO& io, const NhColArgs& a, const ColWs& ws) {
   typedef typename IO::T T;
   const int km = a.g.npz;
@@ -432,25 +440,26 @@ HD void remap_field_col_nh(const IO& io, const NhColArgs& a, const ColWs& ws) {
     for (int k = 2; k <= km; ++k) p2.set(k, dlog(p2(k)));
     p2.set(1, p1(1)); p2.set(km + 1, p1(km + 1));
     for (int k = 1; k <= km; ++k) { const T pt = io.ld(2, k); q1.set(k, pt * dexp(k1k * dlog(rrg * io.ld(3, k) / io.ld(4, k) * pt))); }
-    map_col_io(io, km, ws, 1, io.cst(0.), [&](int k, const T& x) { io.st(5, k, x); });
+    map_col_io<LIM>(io, km, ws, 1, io.cst(0.), [&](int k, const T& x) { io.st(5, k, x); }, LimProfile{a.kord_tm, 1, true, 184.});      // map_scalar, t_min = 184
     return;
   }
   for (int k = 1; k <= km + 1; ++k) p1.set(k, io.ld(0, k));
   if (a.what == 1) {
     for (int k = 1; k <= km; ++k) q1.set(k, io.ld(1, k));
-    map_col_io(io, km, ws, -2, io.ld(2, 1), [&](int k, const T& x) { io.st(3, k, x); });
+    map_col_io<LIM>(io, km, ws, -2, io.ld(2, 1), [&](int k, const T& x) { io.st(3, k, x); }, LimProfile{a.kord_wz, -2, false, 0.});
   } else if (a.what == 2) {
     for (int k = 1; k <= km; ++k) q1.set(k, -(io.ld(1, k) / io.ld(2, k)));
-    map_col_io(io, km, ws, 1, io.cst(0.), [&](int k, const T& x) { io.st(3, k, -(x * (p2(k + 1) - p2(k)))); });
+    map_col_io<LIM>(io, km, ws, 1, io.cst(0.), [&](int k, const T& x) { io.st(3, k, -(x * (p2(k + 1) - p2(k)))); }, LimProfile{a.kord_tm, 1, false, 0.});      // map1_ppm with abs(kord_tm) (fv_mapz_tlm.F90:627-637)
   } else {
     for (int k = 1; k <= km; ++k) q1.set(k, io.ld(1, k));
-    map_col_io(io, km, ws, 1, io.cst(0.), [&](int k, const T& x) { io.st(2, k, x); });
+    map_col_io<LIM>(io, km, ws, 0, io.cst(0.), [&](int k, const T& x) { io.st(2, k, x); }, LimProfile{a.kord_tr, 0, true, 0.});      // map1_q2: iv = 0 (read by the limited profile only)
   }
 }
 // Adjoint of remap_field_col_nh without the tape: the column map itself is the hydrostatic path's hand-written
 // map_col_ad (remap.h; map_col_ad_iv<-2> for the vertical velocity), the pre- and post-transforms are differentiated
 // here.  FV3LM_NH_TAPE=1 keeps the w map on the tape (NHC_RM_W), which is what the tests compare against.
 // Raw workspace slots: 0..12 map_col_ad, 13..15 staged trajectories.
+template <bool LIM = false>
 HD void remap_field_col_nh_ad(const NhColArgs& a, const ColWs& ws, int tile, int i, int j) {
   const Geom& g = a.g; const int km = g.npz;
   const MapAdSlots S{0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12};
@@ -488,7 +497,9 @@ HD void remap_field_col_nh_ad(const NhColArgs& a, const ColWs& ws, int tile, int
   if (a.what == 2) {
     auto q1 = [&](int k) { return -(a.f[1].t[F(1, k)] / a.f[2].t[F(2, k)]); };
     auto outq = [&](int k, double x) { ws.at(15, k) = x; };
-    map_col<double>(km, pe1, q1, pe2, outq, ws, 13, 14);          // mapped -delz/delp: needed by the product rule below
+    bool done = false;
+    if constexpr (LIM) if (kord_limited(a.kord_tm)) { map_col_lim(LimProfile{a.kord_tm, 1, false, 0.}, km, pe1, q1, pe2, outq, ws, 13, 14); done = true; }
+    if (!done) map_col<double>(km, pe1, q1, pe2, outq, ws, 13, 14);          // mapped -delz/delp: needed by the product rule below
     for (int k = 1; k <= km; ++k) {
       const double oa = a.f[3].p[F(3, k)], dpa = -ws.at(15, k) * oa;
       ws.at(S.SP2, k + 1) += dpa; ws.at(S.SP2, k) -= dpa;
@@ -613,7 +624,7 @@ HD void ring_col_ad(const NhColArgs& a, int tile, int i, int j) {
   }
 }
 
-enum NhColKind { NHC_RIEM_C = 0, NHC_RIEM3, NHC_EDGE, NHC_ZH_INIT, NHC_RING, NHC_RM_FIELD, NHC_RM_PRESS, NHC_RM_W };
+enum NhColKind { NHC_RIEM_C = 0, NHC_RIEM3, NHC_EDGE, NHC_ZH_INIT, NHC_RING, NHC_RM_FIELD, NHC_RM_PRESS, NHC_RM_W, NHC_RM_FIELD_LIM, NHC_RM_W_LIM };
 // One kernel per (operator, mode): each gets its own register allocation (the taped remap needs ~250 VGPRs, the nonlinear
 // solvers a fraction of that).
 template <int KIND, int MODE>
@@ -628,6 +639,7 @@ struct NhColFn {
     else if (KIND == NHC_ZH_INIT) zh_init_col(io, a, hs);
     else if (KIND == NHC_RING) ring_col(io, a);
     else if (KIND == NHC_RM_FIELD || KIND == NHC_RM_W) remap_field_col_nh(io, a, ws);
+    else if (KIND == NHC_RM_FIELD_LIM || KIND == NHC_RM_W_LIM) remap_field_col_nh<true>(io, a, ws);
     else remap_press_col_nh(io, a);
   }
   HD void operator()(int i, int j, int zz) const {
@@ -643,6 +655,7 @@ struct NhColFn {
     if (KIND == NHC_ZH_INIT && MODE == MODE_AD && !a.use_tape) { zh_init_col_ad(a, z, i, j); return; }
     if (KIND == NHC_RM_PRESS && MODE == MODE_AD && !a.use_tape) { remap_press_col_nh_ad(a, z, i, j); return; }
     if ((KIND == NHC_RM_FIELD || KIND == NHC_RM_W) && MODE == MODE_AD && !(KIND == NHC_RM_W && a.use_tape)) { remap_field_col_nh_ad(a, ws, z, i, j); return; }
+    if ((KIND == NHC_RM_FIELD_LIM || KIND == NHC_RM_W_LIM) && MODE == MODE_AD && !(KIND == NHC_RM_W_LIM && a.use_tape)) { remap_field_col_nh_ad<true>(a, ws, z, i, j); return; }
     if (KIND == NHC_RIEM_C && MODE == MODE_AD && !a.use_tape) { riem_c_col_ad(a, ws, z, i, j, hs); return; }
     if (KIND == NHC_RIEM3 && MODE == MODE_AD && !a.use_tape) { riem3_col_ad(a, ws, z, i, j, hs); return; }
     if (MODE == MODE_NL) { ColNL io{a.g, a.f, z, i, j, nullptr}; body(io, ws, hs); }
@@ -666,7 +679,7 @@ inline double nh_col_bytes(const NhColArgs& a, int kind, int mode, const Rect& R
     case NHC_EDGE: nin = 2; nout = 2; break;
     case NHC_ZH_INIT: nin = 1; nout = 1; break;
     case NHC_RING: nin = 1; nout = 1; break;
-    case NHC_RM_FIELD: case NHC_RM_W: nin = a.what == 0 ? 5 : a.what == 3 ? 2 : 3; nout = 1; break;
+    case NHC_RM_FIELD: case NHC_RM_W: case NHC_RM_FIELD_LIM: case NHC_RM_W_LIM: nin = a.what == 0 ? 5 : a.what == 3 ? 2 : 3; nout = 1; break;
     default: nin = 6; nout = 4; break;      // NHC_RM_PRESS
   }
   double cols = double(R.i1 - R.i0 + 1) * double(R.j1 - R.j0 + 1);
@@ -699,6 +712,8 @@ inline void run_nh_col(Exec& ex, int mode, const NhColArgs& a0, int kind, const 
     case NHC_RING: run_nh_col_k<NHC_RING>(ex, mode, a, R, skip, tag); break;
     case NHC_RM_FIELD: run_nh_col_k<NHC_RM_FIELD>(ex, mode, a, R, skip, tag); break;
     case NHC_RM_W: run_nh_col_k<NHC_RM_W>(ex, mode, a, R, skip, tag); break;
+    case NHC_RM_FIELD_LIM: run_nh_col_k<NHC_RM_FIELD_LIM>(ex, mode, a, R, skip, tag); break;
+    case NHC_RM_W_LIM: run_nh_col_k<NHC_RM_W_LIM>(ex, mode, a, R, skip, tag); break;
     default: run_nh_col_k<NHC_RM_PRESS>(ex, mode, a, R, skip, tag); break;
   }
 }

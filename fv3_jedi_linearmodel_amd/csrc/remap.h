@@ -189,31 +189,9 @@ HD void lim_layer(const LimProfile& P, int k, int km, const FA& a1, const FE& qe
   }
   if (iv == 0) cs_limiters(ex, a, a2, a3, a4, 0);
 }
-// map_col on double with the limited profile: the same tridiagonal solve (edge values into slot SE), then the mapping loop with
-// lim_layer's (a2, a3, a4).  Slots SG, SE in units of double.
-template <class FP1, class FQ1, class FP2, class FOut>
-HD void map_col_lim(const LimProfile& P, int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const FOut& out, const ColWs& ws, int SG, int SE) {
-  {
-    double dpa = pe1(2) - pe1(1), dpb = pe1(3) - pe1(2);
-    double grat = dpb / dpa, bet = grat * (grat + 0.5);
-    double qf = ((grat + grat) * (grat + 1.) * q1(1) + q1(2)) / bet, gam = (1. + grat * (grat + 1.5)) / bet;
-    ws.at(SE, 1) = qf; ws.at(SG, 1) = gam;
-    double d4 = grat, a_prev = q1(1), dp_prev = dpa;
-    for (int k = 2; k <= km; ++k) {
-      const double dpk = pe1(k + 1) - pe1(k), ak_ = q1(k);
-      d4 = dp_prev / dpk;
-      bet = 2. + d4 + d4 - gam;
-      qf = (3. * (a_prev + d4 * ak_) - qf) / bet;
-      gam = d4 / bet;
-      ws.at(SE, k) = qf; ws.at(SG, k) = gam;
-      a_prev = ak_; dp_prev = dpk;
-    }
-    const double a_bot = 1. + d4 * (d4 + 1.5);
-    double qe = (2. * d4 * (d4 + 1.) * q1(km) + q1(km - 1) - a_bot * qf) / (d4 * (d4 + 0.5) - a_bot * gam);
-    ws.at(SE, km + 1) = qe;
-    for (int k = km; k >= 1; --k) { qe = ws.at(SE, k) - ws.at(SG, k) * qe; ws.at(SE, k) = qe; }
-  }
-  auto qe = [&](int k) { return ws.at(SE, k); };
+// the mapping loop of map_scalar / map1_ppm / map1_q2 (fv_mapz_tlm.F90:2832-3239) on the limited profile: qe(k) = the unlimited edge values
+template <class FP1, class FQ1, class FP2, class FE, class FOut>
+HD void map_loop_lim(const LimProfile& P, int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const FE& qe, const FOut& out) {
   int k0 = 1;
   double qsum = 0.;
   for (int k = 1; k <= km; ++k) {
@@ -247,6 +225,34 @@ HD void map_col_lim(const LimProfile& P, int km, const FP1& pe1, const FQ1& q1, 
     }
     out(k, qsum / (p2b - p2t));
   }
+}
+
+// map_col on double with the limited profile: the same tridiagonal solve (edge values into slot SE), then the mapping loop with
+// lim_layer's (a2, a3, a4).  Slots SG, SE in units of double.
+template <class FP1, class FQ1, class FP2, class FOut>
+HD void map_col_lim(const LimProfile& P, int km, const FP1& pe1, const FQ1& q1, const FP2& pe2, const FOut& out, const ColWs& ws, int SG, int SE) {
+  {
+    double dpa = pe1(2) - pe1(1), dpb = pe1(3) - pe1(2);
+    double grat = dpb / dpa, bet = grat * (grat + 0.5);
+    double qf = ((grat + grat) * (grat + 1.) * q1(1) + q1(2)) / bet, gam = (1. + grat * (grat + 1.5)) / bet;
+    ws.at(SE, 1) = qf; ws.at(SG, 1) = gam;
+    double d4 = grat, a_prev = q1(1), dp_prev = dpa;
+    for (int k = 2; k <= km; ++k) {
+      const double dpk = pe1(k + 1) - pe1(k), ak_ = q1(k);
+      d4 = dp_prev / dpk;
+      bet = 2. + d4 + d4 - gam;
+      qf = (3. * (a_prev + d4 * ak_) - qf) / bet;
+      gam = d4 / bet;
+      ws.at(SE, k) = qf; ws.at(SG, k) = gam;
+      a_prev = ak_; dp_prev = dpk;
+    }
+    const double a_bot = 1. + d4 * (d4 + 1.5);
+    double qe = (2. * d4 * (d4 + 1.) * q1(km) + q1(km - 1) - a_bot * qf) / (d4 * (d4 + 0.5) - a_bot * gam);
+    ws.at(SE, km + 1) = qe;
+    for (int k = km; k >= 1; --k) { qe = ws.at(SE, k) - ws.at(SG, k) * qe; ws.at(SE, k) = qe; }
+  }
+  auto qe = [&](int k) { return ws.at(SE, k); };
+  map_loop_lim(P, km, pe1, q1, pe2, qe, out);
 }
 HD bool kord_limited(int kord) { return (kord < 0 ? -kord : kord) <= 16; }
 

@@ -12,7 +12,7 @@ from common import Case
     (dict(hydrostatic=0, a_imp=0.4), "a_imp"),
     (dict(kord_tm=-8), "kord"),                          # trajectory profiles built: linear (> 16) and the limited 9, 10, 11
     (dict(kord_tm_pert=-9), "kord"),                     # the perturbation profile is the linear one
-    (dict(hydrostatic=0, kord_wz=9), "kord"),            # limited profiles: hydrostatic remap only
+    (dict(hydrostatic=0, kord_wz=12), "kord"),
     (dict(kord_tr=8), "kord"),
 ])
 def test_unsupported_options_are_refused(kw, needle):

@@ -184,3 +184,15 @@ def test_kord_remap_noisy_columns(monkeypatch, kord):
     groups.check_remap(c, TL, 0, 1e-11)
     groups.check_remap(c, TL, 1, 1e-11)
     groups.check_remap(c, AD, 1, 1e-11)
+
+
+def test_nh_split_kord():
+    """non-hydrostatic remap with limited trajectory profiles: T (map_scalar), tracers, delz (iv = 1) and w (iv = -2, kord_wz)"""
+    import nh_checks as N
+    c = Case(nx=10, ny=8, npz=12, n_split=2, k_split=2, dt=1200.0, nq=2, backend="emul", hydrostatic=0, kord_tm=-9, kord_mt=9, kord_tr=9, kord_wz=9, **SPLIT10)
+    N.check_nh_fv_tangent(c)
+    N.check_nh_fv_adjoint(c)
+    N.check_nh_fv_dot_product(c)
+    c = Case(nx=10, ny=8, npz=12, n_split=2, k_split=1, dt=600.0, nq=1, backend="emul", hydrostatic=0, kord_tm=-10, kord_mt=10, kord_tr=11, kord_wz=10)
+    N.check_nh_fv_tangent(c)
+    N.check_nh_fv_adjoint(c)

@@ -86,3 +86,13 @@ def test_operational_pairing_six_faces():
     cube_check_fv_dynamics(c, AD, 1e-10)
     lhs, rhs = cube_dot_product_step(c)
     assert abs(lhs - rhs) <= 1e-11 * abs(lhs), (lhs, rhs)
+
+
+def test_nonhydrostatic_split_kord():
+    """non-hydrostatic, trajectory hord 10 / kord 9 (kord_wz 9 for w), perturbation linear: six faces against the oracle"""
+    from common import CubeCase
+    import nh_checks as N
+    c = CubeCase(n=12, npz=12, n_split=2, k_split=2, dt=1200.0, nq=1, backend="hip", oracle=True, hydrostatic=0, kord_tm=-9, kord_mt=9, kord_tr=9, kord_wz=9, **SPLIT10)
+    N.cube_check_nh_fv(c, TL)
+    N.cube_check_nh_fv(c, AD)
+    N.cube_check_nh_dot_product(c)
