@@ -111,30 +111,50 @@ DEV void tp_fused_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int
   auto own_i = [&](int i) { return (i >= I0 && i <= I1) || (firstx && i < I0) || (lastx && i > I1); };
   auto own_j = [&](int j) { return (j >= J0 && j <= J1) || (firsty && j < J0) || (lasty && j > J1); };
 
+  // Tangent mode, device build: operands of the NEXT phase are fetched into registers before the barrier that ends the current one --
+  // with one 1024-thread block per CU (107 KB of LDS) nothing else hides the HBM latency behind a barrier.
+  constexpr bool PRE = NTH > 1 && !TRAJ && !std::is_same<T, double>::value;      // the nonlinear kernel runs three blocks per CU: they hide each other's latency, and the registers would cost it one
+  constexpr int N2A = TPF_QW * (TPF_H + 1), N2B = (TPF_W + 1) * TPF_QH, N3A = TPF_QW * TPF_H, N3B = TPF_W * TPF_QH;
+  constexpr int E2A = PRE ? (N2A + NTH - 1) / NTH : 1, E2B = PRE ? (N2B + NTH - 1) / NTH : 1, E3A = PRE ? (N3A + NTH - 1) / NTH : 1, E3B = PRE ? (N3B + NTH - 1) / NTH : 1;
+  T cy_pre[E2A], cx_pre[E2B], y0_pre[E3A], y1_pre[E3A], ry_pre[E3A], x0_pre[E3B], x1_pre[E3B], rx_pre[E3B];
+  if constexpr (PRE) {
+    { int u = 0; TPF_LOOP(e, N2A) { const int i = I0 - 3 + e % TPF_QW, j = J0 + e / TPF_QW; cy_pre[u++] = (i <= I1 + 3 && j <= J1 + 1) ? IO::ld(a.cry, at(i, j)) : T(0.); } }
+    { int u = 0; TPF_LOOP(e, N2B) { const int i = I0 + e % (TPF_W + 1), j = J0 - 3 + e / (TPF_W + 1); cx_pre[u++] = (i <= I1 + 1 && j <= J1 + 3) ? IO::ld(a.crx, at(i, j)) : T(0.); } }
+  }
   // ---- the block of q and its halo
   { constexpr int w = TPF_QW, n = w * TPF_QH;
     TPF_LOOP(e, n) { const int i = I0 - 3 + e % w, j = J0 - 3 + e / w; if (i <= I1 + 3 && j <= J1 + 3) q.set(i, j, IO::ld(a.q, at(i, j))); } }
   TPF_SYNC();
+  if constexpr (PRE) {
+    { int u = 0; TPF_LOOP(e, N3A) { const int i = I0 - 3 + e % TPF_QW, j = J0 + e / TPF_QW; const bool in = i <= I1 + 3 && j <= J1;
+        y0_pre[u] = in ? IO::ld(a.yfx, at(i, j)) : T(0.); y1_pre[u] = in ? IO::ld(a.yfx, at(i, j + 1)) : T(0.); ry_pre[u] = in ? IO::ld(a.ray, at(i, j)) : T(1.); ++u; } }
+    { int u = 0; TPF_LOOP(e, N3B) { const int i = I0 + e % TPF_W, j = J0 - 3 + e / TPF_W; const bool in = i <= I1 && j <= J1 + 3;
+        x0_pre[u] = in ? IO::ld(a.xfx, at(i, j)) : T(0.); x1_pre[u] = in ? IO::ld(a.xfx, at(i + 1, j)) : T(0.); rx_pre[u] = in ? IO::ld(a.rax, at(i, j)) : T(1.); ++u; } }
+  }
   // ---- inner sweeps: fy2 = yppm(q) on the halo'd columns (copy_corners view 2), fx2 = xppm(q) on the halo'd rows (view 1)
   { constexpr int w = TPF_QW, n = w * (TPF_H + 1);
+    int u = 0;
     TPF_LOOP(e, n) {
       const int i = I0 - 3 + e % w, j = J0 + e / w;
+      const int uu = PRE ? u++ : 0;
       if (i > I1 + 3 || j > J1 + 1) continue;
       auto line = [&](int jj) -> T { int ii = i, j2 = jj; if (face) corner_map(g, 2, ii, j2); return q.get(ii, j2); };
       const MetY da{c.m.dya, c, tile, i};
-      const T cc = IO::ld(a.cry, at(i, j));
+      const T cc = PRE ? cy_pre[uu] : IO::ld(a.cry, at(i, j));
       const T f = flux1d(iord_in, j, ny + 1, line, da, cc);
       fy2.set(i, j, f);
       if (STORE && own_i(i) && (j <= J1 || lasty)) a.fy2.t[at(i, j)] = val(f);
       if (!TRAJ && a.do_acc && own_i(i) && (j <= J1 || lasty)) IO::st(a.acy, at(i, j), IO::ld(a.acy, at(i, j)) + cc);
     } }
   { constexpr int w = TPF_W + 1, n = w * TPF_QH;
+    int u = 0;
     TPF_LOOP(e, n) {
       const int i = I0 + e % w, j = J0 - 3 + e / w;
+      const int uu = PRE ? u++ : 0;
       if (i > I1 + 1 || j > J1 + 3) continue;
       auto line = [&](int ii) -> T { int i2 = ii, jj = j; if (face) corner_map(g, 1, i2, jj); return q.get(i2, jj); };
       const MetX da{c.m.dxa, c, tile, j};
-      const T cc = IO::ld(a.crx, at(i, j));
+      const T cc = PRE ? cx_pre[uu] : IO::ld(a.crx, at(i, j));
       const T f = flux1d(iord_in, i, nx + 1, line, da, cc);
       fx2.set(i, j, f);
       if (STORE && own_j(j) && (i <= I1 || lastx)) a.fx2.t[at(i, j)] = val(f);
@@ -143,20 +163,24 @@ DEV void tp_fused_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int
   TPF_SYNC();
   // ---- q_i, q_j: the field advanced by the inner fluxes (tp_core_tlm.F90:149-159, :173-181)
   { constexpr int w = TPF_QW, n = w * TPF_H;
+    int u = 0;
     TPF_LOOP(e, n) {
       const int i = I0 - 3 + e % w, j = J0 + e / w;
+      const int uu = PRE ? u++ : 0;
       if (i > I1 + 3 || j > J1) continue;
-      const T f0 = IO::ld(a.yfx, at(i, j)) * fy2.get(i, j), f1 = IO::ld(a.yfx, at(i, j + 1)) * fy2.get(i, j + 1);
-      const T x = (q.get(i, j) * MET(area, i, j) + f0 - f1) / IO::ld(a.ray, at(i, j));
+      const T f0 = (PRE ? y0_pre[uu] : IO::ld(a.yfx, at(i, j))) * fy2.get(i, j), f1 = (PRE ? y1_pre[uu] : IO::ld(a.yfx, at(i, j + 1))) * fy2.get(i, j + 1);
+      const T x = (q.get(i, j) * MET(area, i, j) + f0 - f1) / (PRE ? ry_pre[uu] : IO::ld(a.ray, at(i, j)));
       qi.set(i, j, x);
       if (STORE && own_i(i)) a.q_i.t[at(i, j)] = val(x);
     } }
   { constexpr int w = TPF_W, n = w * TPF_QH;
+    int u = 0;
     TPF_LOOP(e, n) {
       const int i = I0 + e % w, j = J0 - 3 + e / w;
+      const int uu = PRE ? u++ : 0;
       if (i > I1 || j > J1 + 3) continue;
-      const T f0 = IO::ld(a.xfx, at(i, j)) * fx2.get(i, j), f1 = IO::ld(a.xfx, at(i + 1, j)) * fx2.get(i + 1, j);
-      const T x = (q.get(i, j) * MET(area, i, j) + f0 - f1) / IO::ld(a.rax, at(i, j));
+      const T f0 = (PRE ? x0_pre[uu] : IO::ld(a.xfx, at(i, j))) * fx2.get(i, j), f1 = (PRE ? x1_pre[uu] : IO::ld(a.xfx, at(i + 1, j))) * fx2.get(i + 1, j);
+      const T x = (q.get(i, j) * MET(area, i, j) + f0 - f1) / (PRE ? rx_pre[uu] : IO::ld(a.rax, at(i, j)));
       qj.set(i, j, x);
       if (STORE && own_j(j)) a.q_j.t[at(i, j)] = val(x);
     } }
