@@ -384,12 +384,18 @@ struct Dycore {
   void build_tp(Program& P, const char* grp, const std::string& pre, Fld q, Fld crx, Fld cry, Fld xfx, Fld yfx, Fld rax,
                 Fld ray, Fld mx, Fld my, Fld mass, int hsel, int dsel, bool use_mass, Fld fx, Fld fy, int nk = 0, const Fld* acc4 = nullptr) {
     const int is = 1, ie = g.nx, js = 1, je = g.ny, isd = g.isd(), ied = g.ied(), jsd = g.jsd(), jed = g.jed(), npz = nk ? nk : g.npz;
-    Fld fy2 = W((pre + "_fy2").c_str(), npz), q_i = W((pre + "_qi").c_str(), npz), fxo = W((pre + "_fxo").c_str(), npz);
-    Fld fx2 = W((pre + "_fx2").c_str(), npz), q_j = W((pre + "_qj").c_str(), npz), fyo = W((pre + "_fyo").c_str(), npz);
     // nonlinear and tangent modes: the whole routine as one LDS-tiled launch (tpfused.h); the staged launches below then serve the
     // adjoint only (FV3LM_TP_FUSED=0 runs them in every mode -- the two forms agree bit for bit)
     const char* fenv = std::getenv("FV3LM_TP_FUSED");
     const bool fused = !(fenv && fenv[0] == '0');
+    // The outer fluxes fxo, fyo are trajectory arrays of their own only while something reads them: the staged flux assembly.  With the
+    // hand-written outer adjoint (which re-evaluates them from q_i, q_j in passing) they are neither stored by the nonlinear launch nor
+    // part of a trajectory slot; the names then alias fx2 / fy2 for the staged ops that never run.
+    const char* aenv0 = std::getenv("FV3LM_TP_AD_FUSED");
+    const bool own_fo = !(fused && !(fenv && fenv[0] == '3') && !(aenv0 && aenv0[0] == '0'));
+    Fld fy2 = W((pre + "_fy2").c_str(), npz), q_i = W((pre + "_qi").c_str(), npz);
+    Fld fx2 = W((pre + "_fx2").c_str(), npz), q_j = W((pre + "_qj").c_str(), npz);
+    Fld fxo = own_fo ? W((pre + "_fxo").c_str(), npz) : fx2, fyo = own_fo ? W((pre + "_fyo").c_str(), npz) : fy2;
     const size_t first_op = P.size();
     // the four 1-D PPM sweeps; on a face each is a bulk launch (4-point edge values everywhere) plus two strips three flux
     // points wide next to the face edges (one-sided edge values, corner views of the inner sweeps)
@@ -455,7 +461,7 @@ struct Dycore {
       a.mass = use_mass ? mass : Fld{}; a.d2b = d2b; a.fx = fx; a.fy = fy;
       a.fy2 = fy2; a.q_i = q_i; a.fxo = fxo; a.fx2 = fx2; a.q_j = q_j; a.fyo = fyo;
       a.hsel = hsel; a.dsel = dsel; a.use_mass = use_mass ? 1 : 0; a.nk = npz;
-      a.do_acc = 0;
+      a.do_acc = 0; a.store_fo = own_fo ? 1 : 0;
       if (acc4) { a.acx = acc4[0]; a.acy = acc4[1]; a.amfx = acc4[2]; a.amfy = acc4[3]; }
       Ctx* cp = &ctx;
       // default: the tiled form (tpfused.h, first half); FV3LM_TP_FUSED=3: the marching form (second half; measured slower, kept for reference)

@@ -25,6 +25,7 @@ struct TpFusedArgs {
   // flux capacitors of d_sw (sw_core_tlm.F90:3000-3016): cx += crx, cy += cry, mfx += fx, mfy += fy folded into this launch
   // (t == nullptr: none).  do_acc is cleared for the adjoint's trajectory recompute, which must leave the accumulators alone.
   Fld acx, acy, amfx, amfy; int do_acc;
+  int store_fo = 1;                              // fxo, fyo are arrays of their own (0: the names alias fx2 / fy2 and nothing may write them)
 };
 #ifndef FV3LM_TPF_H
 #define FV3LM_TPF_H 16
@@ -199,7 +200,7 @@ DEV void tp_fused_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int
         auto line = [&](int ii) -> T { return qi.get(ii, j); };
         const MetX da{c.m.dxa, c, tile, j};
         const T fo = flux1d(iord, i, nx + 1, line, da, IO::ld(a.crx, at(i, j)));
-        if (STORE) a.fxo.t[at(i, j)] = val(fo);
+        if (STORE && a.store_fo) a.fxo.t[at(i, j)] = val(fo);
         T f = 0.5 * (fo + fx2.get(i, j)) * IO::ld(a.mx, at(i, j));
         if (dmp) {
           T f2;
@@ -215,7 +216,7 @@ DEV void tp_fused_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int
         auto line = [&](int jj) -> T { return qj.get(i, jj); };
         const MetY da{c.m.dya, c, tile, i};
         const T fo = flux1d(iord, j, ny + 1, line, da, IO::ld(a.cry, at(i, j)));
-        if (STORE) a.fyo.t[at(i, j)] = val(fo);
+        if (STORE && a.store_fo) a.fyo.t[at(i, j)] = val(fo);
         T f = 0.5 * (fo + fy2.get(i, j)) * IO::ld(a.my, at(i, j));
         if (dmp) {
           T f2;
@@ -235,7 +236,7 @@ inline void tpf_grid(const Geom& g, int& nbx, int& nby) { nbx = (g.nx + TPF_W - 
 // trajectory intermediates of the nonlinear mode
 inline double tpf_bytes(const TpFusedArgs& a, const Geom& g, int mode) {
   const double cells = double(g.nx) * g.ny * g.ntile * a.nk, nin = 9. + (a.d2b.t ? 1. : 0.) + (a.mass.t ? 1. : 0.);
-  return 8. * cells * (mode == MODE_TL ? 2. * (nin + 2.) : (nin + 2.) + 6.);
+  return 8. * cells * (mode == MODE_TL ? 2. * (nin + 2.) : (nin + 2.) + (a.store_fo ? 6. : 4.));
 }
 
 #ifndef FV3LM_HOST_EMUL
@@ -345,7 +346,7 @@ DEV void tp_outer_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, 
         const MetX da{c.m.dxa, c, tile, j};
         const Dual fl = ppm_flux<Dual>(iord, face, i, nx + 1, line, da, Dual(cc, 1.));
         a.crx.p[at(i, j)] += fl.d * fo;
-        a.mx.p[at(i, j)] += 0.5 * (a.fxo.t[at(i, j)] + a.fx2.t[at(i, j)]) * a.fx.p[at(i, j)];
+        a.mx.p[at(i, j)] += 0.5 * (fl.v + a.fx2.t[at(i, j)]) * a.fx.p[at(i, j)];      // fl.v = the outer flux fxo, re-evaluated from q_i
         a.fx2.p[at(i, j)] = fo;
       }
       if (i <= I1 && (j <= J1 || lasty)) {
@@ -354,7 +355,7 @@ DEV void tp_outer_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, 
         const MetY da{c.m.dya, c, tile, i};
         const Dual fl = ppm_flux<Dual>(iord, face, j, ny + 1, line, da, Dual(cc, 1.));
         a.cry.p[at(i, j)] += fl.d * fo;
-        a.my.p[at(i, j)] += 0.5 * (a.fyo.t[at(i, j)] + a.fy2.t[at(i, j)]) * a.fy.p[at(i, j)];
+        a.my.p[at(i, j)] += 0.5 * (fl.v + a.fy2.t[at(i, j)]) * a.fy.p[at(i, j)];
         a.fy2.p[at(i, j)] = fo;
       }
     } }
@@ -420,10 +421,10 @@ inline void run_tp_outer_ad(Exec& ex, const TpFusedArgs& a0, const Ctx& c) {
   TpFusedArgs a = a0;
   for (Fld* f : {&a.q, &a.crx, &a.cry, &a.xfx, &a.yfx, &a.rax, &a.ray, &a.mx, &a.my, &a.mass, &a.d2b, &a.fx, &a.fy, &a.fy2, &a.q_i, &a.fxo, &a.fx2, &a.q_j, &a.fyo}) *f = ex.sh(*f);
   int nbx, nby; tpf_grid(c.g, nbx, nby);
-  // algorithmic bytes: trajectory q_i, q_j, crx, cry, mx, my, fxo, fx2, fyo, fy2 and the adjoints fx, fy read; q_i, q_j, fx2, fy2 adjoints written;
+  // algorithmic bytes: trajectory q_i, q_j, crx, cry, mx, my, fx2, fy2 and the adjoints fx, fy read; q_i, q_j, fx2, fy2 adjoints written;
   // crx, cry, mx, my adjoints read-modify-written
   const double cells = double(c.g.nx) * c.g.ny * c.g.ntile * a.nk;
-  ex.mark_begin("TpOuter", ".ad", 8. * cells * (10. + 2. + 4. + 8.));
+  ex.mark_begin("TpOuter", ".ad", 8. * cells * (8. + 2. + 4. + 8.));
 #ifdef FV3LM_HOST_EMUL
   std::vector<double> lds((size_t)TPA_NT);
   for (int z = 0; z < c.g.ntile * a.nk; ++z)
