@@ -19,8 +19,14 @@ def build_emul():
     if os.path.exists(EMUL_SO) and all(os.path.getmtime(EMUL_SO) >= os.path.getmtime(s) for s in srcs):
         return EMUL_SO
     os.makedirs(os.path.dirname(EMUL_SO), exist_ok=True)
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-DFV3LM_HOST_EMUL", "-shared", "-o", EMUL_SO,
-                           os.path.join(CSRC, "fv3lm_capi.cpp")])
+    import fcntl
+    with open(EMUL_SO + ".lock", "w") as lock:        # pytest -n: one worker builds, the others wait and find it done
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not (os.path.exists(EMUL_SO) and all(os.path.getmtime(EMUL_SO) >= os.path.getmtime(s) for s in srcs)):
+            tmp = EMUL_SO + ".%d.tmp" % os.getpid()
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-DFV3LM_HOST_EMUL", "-shared", "-o", tmp,
+                                   os.path.join(CSRC, "fv3lm_capi.cpp")])
+            os.replace(tmp, EMUL_SO)
     return EMUL_SO
 
 
