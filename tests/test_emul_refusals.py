@@ -25,3 +25,11 @@ def test_nonhydrostatic_needs_three_levels():
     with pytest.raises(Exception) as e:
         Case(nx=10, ny=8, npz=2, backend="emul", oracle=False, hydrostatic=0)
     assert "npz" in str(e.value)
+
+
+def test_split_hord_needs_the_fused_transport(monkeypatch):
+    """the values-only trajectory pass exists in the tiled fused fv_tp_2d only: with the staged form forced, create fails loudly"""
+    monkeypatch.setenv("FV3LM_TP_FUSED", "0")
+    with pytest.raises(Exception) as e:
+        Case(nx=10, ny=8, npz=12, backend="emul", oracle=False, hord_dp=10)
+    assert "split_hord" in str(e.value), str(e.value)

@@ -96,3 +96,12 @@ def test_nonhydrostatic_split_kord():
     N.cube_check_nh_fv(c, TL)
     N.cube_check_nh_fv(c, AD)
     N.cube_check_nh_dot_product(c)
+
+
+def test_dot_product_c192l127_operational_pairing():
+    """the headline size with the operational pairing (trajectory hord 10 / kord 9, perturbation 2 / 17): TL/AD dot-product identity"""
+    from common import CubeCase
+    from groups import cube_dot_product_step
+    c = CubeCase(n=192, npz=127, n_split=6, k_split=2, dt=450.0, backend="hip", oracle=False, nq=4, kord_tm=-9, kord_mt=9, kord_tr=9, **SPLIT10)
+    lhs, rhs = cube_dot_product_step(c)
+    assert abs(lhs - rhs) <= 1e-11 * abs(lhs), (lhs, rhs)
