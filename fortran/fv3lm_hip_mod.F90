@@ -31,7 +31,7 @@ module fv3lm_hip_mod
     integer(c_int) :: hord_mt_ks_pert, hord_vt_ks_pert, hord_tm_ks_pert, hord_dp_ks_pert, hord_tr_ks_pert
     integer(c_int) :: kord_tm, kord_mt, kord_wz, kord_tr
     integer(c_int) :: kord_tm_pert, kord_mt_pert, kord_wz_pert, kord_tr_pert
-    integer(c_int) :: hydrostatic, pad_
+    integer(c_int) :: hydrostatic, split_damp
     real(c_double) :: dddmp, d2_bg, d4_bg, vtdm4, d2_bg_k1, d2_bg_k2, d_con, ke_bg
     real(c_double) :: dddmp_pert, d2_bg_pert, d4_bg_pert, vtdm4_pert, d2_bg_k1_pert, d2_bg_k2_pert, d2_bg_ks_pert
     real(c_double) :: akap, cp, zvir, grav_jedi

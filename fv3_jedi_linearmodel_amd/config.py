@@ -15,7 +15,7 @@ class Options(C.Structure):
             "nord_pert do_vort_damp_pert n_sponge_pert hord_ks_traj hord_ks_pert "
             "hord_mt_ks_traj hord_vt_ks_traj hord_tm_ks_traj hord_dp_ks_traj hord_tr_ks_traj "
             "hord_mt_ks_pert hord_vt_ks_pert hord_tm_ks_pert hord_dp_ks_pert hord_tr_ks_pert "
-            "kord_tm kord_mt kord_wz kord_tr kord_tm_pert kord_mt_pert kord_wz_pert kord_tr_pert hydrostatic pad_").split()]
+            "kord_tm kord_mt kord_wz kord_tr kord_tm_pert kord_mt_pert kord_wz_pert kord_tr_pert hydrostatic split_damp").split()]
         + [(n, C.c_double) for n in (
             "dddmp d2_bg d4_bg vtdm4 d2_bg_k1 d2_bg_k2 d_con ke_bg "
             "dddmp_pert d2_bg_pert d4_bg_pert vtdm4_pert d2_bg_k1_pert d2_bg_k2_pert d2_bg_ks_pert "

@@ -149,6 +149,11 @@ struct LevelParams {
   int hord_mt_t, hord_vt_t, hord_tm_t, hord_dp_t, hord_tr_t, hord_tm_g_t;
   int nord, nord_v, nord_w, nord_t, nord_v_pert;
   double d2_divg, damp_vt, damp_w, damp_t, d_con, damp_vt_pert;
+  // split_damp (fv_arrays_tlmadm.F90:76): the divergence damping the tangent / adjoint is taken of -- the perturbation's own nord_k_pert,
+  // d2_divg_pert, dddmp_pert, d4_bg_pert (dyn_core_tlm.F90:835-921, sw_core_tlm.F90:2358-2366) where the flag is set, the trajectory's
+  // otherwise -- and the perturbation's damping pair of the heat transport, taken BEFORE the perturbation sponge rules (:856-859)
+  int split_damp = 0, nord_p = 0, nord_t_pert = 0;
+  double d2_divg_p = 0., damp_t_pert = 0., dddmp = 0., d4_bg = 0., dddmp_p = 0., d4_bg_p = 0.;
   // tracer_2d sub-cycling of the current call (fv_tracer2d_tlm.F90:1306-1345): sub-steps this level takes and 1/that
   int tr_ksplt = 1; double tr_frac = 1.0;
   double dp_ref = 0.;       // ak(k+1)-ak(k) + (bk(k+1)-bk(k))*1e5 (dyn_core_tlm.F90:1704-1706), non-hydrostatic interface weights

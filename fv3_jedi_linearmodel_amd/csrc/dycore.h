@@ -15,6 +15,7 @@
 #include "nh.h"
 #include "nh_ad.h"
 #include "tpfused.h"
+#include "dampt.h"
 #include <functional>
 #include <map>
 #include <memory>
@@ -102,9 +103,13 @@ inline bool resolve_level(const Options& o, int k, int npz, LevelParams& lp) {
     }
   }
   int hmp = o.hord_mt_pert, htp = o.hord_tm_pert, hvp = o.hord_vt_pert, hpp = o.hord_dp_pert;
+  int nord_k_pert = o.nord_pert;
   int nord_v_pert = (2 > o.nord_pert) ? o.nord_pert : 2;
   double damp_vt_pert = o.do_vort_damp_pert ? o.vtdm4_pert : 0.;
+  double d2_divg_pert = (0.20 > o.d2_bg_pert) ? o.d2_bg_pert : 0.20;
+  const int nord_t_pert = nord_v_pert; const double damp_t_pert = damp_vt_pert;      // :856-859: before the sponge rules below touch nord_v_pert / damp_vt_pert
   if (k <= o.n_sponge_pert) {
+    nord_k_pert = 0;
     if (k <= o.n_sponge_pert - 1) {
       if (o.hord_ks_traj) { hord_m = o.hord_mt_ks_traj; hord_t = o.hord_tm_ks_traj; hord_v = o.hord_vt_ks_traj; hord_p = o.hord_dp_ks_traj; }
       if (o.hord_ks_pert) { hmp = o.hord_mt_ks_pert; htp = o.hord_tm_ks_pert; hvp = o.hord_vt_ks_pert; hpp = o.hord_dp_ks_pert; }
@@ -114,6 +119,7 @@ inline bool resolve_level(const Options& o, int k, int npz, LevelParams& lp) {
     if (0.01 < o.d2_bg_pert) d2p = (o.d2_bg_pert < kfac) ? kfac : o.d2_bg_pert;
     else if (0.01 < kfac) d2p = kfac;
     else d2p = 0.01;
+    d2_divg_pert = d2p;
     if (o.do_vort_damp_pert) { nord_v_pert = 0; damp_vt_pert = 0.5 * d2p; }
   }
   lp.hord_mt = hmp; lp.hord_vt = hvp; lp.hord_tm = htp; lp.hord_dp = hpp; lp.hord_tr = o.hord_tr_pert;
@@ -122,6 +128,10 @@ inline bool resolve_level(const Options& o, int k, int npz, LevelParams& lp) {
   lp.nord = nord_k; lp.nord_v = nord_v; lp.nord_w = nord_w; lp.nord_t = nord_t; lp.nord_v_pert = nord_v_pert;
   lp.d2_divg = d2_divg; lp.damp_vt = damp_vt; lp.damp_w = damp_w; lp.damp_t = damp_t; lp.d_con = d_con_k;
   lp.damp_vt_pert = damp_vt_pert;
+  lp.split_damp = o.split_damp ? 1 : 0; lp.nord_t_pert = nord_t_pert; lp.damp_t_pert = damp_t_pert;
+  lp.dddmp = o.dddmp; lp.d4_bg = o.d4_bg;
+  if (o.split_damp) { lp.nord_p = nord_k_pert; lp.d2_divg_p = d2_divg_pert; lp.dddmp_p = o.dddmp_pert; lp.d4_bg_p = o.d4_bg_pert; }
+  else { lp.nord_p = nord_k; lp.d2_divg_p = d2_divg; lp.dddmp_p = o.dddmp; lp.d4_bg_p = o.d4_bg; }
   return true;
 }
 
@@ -443,7 +453,7 @@ struct Dycore {
     }
     // split_hord: some level runs this transport with a trajectory scheme other than the scheme the tangent / adjoint is taken of
     bool any_split = false;
-    for (int k = 0; k < npz && k < (int)lev_host.size(); ++k) any_split = any_split || level_split(lev_host[k], hsel);
+    for (int k = 0; k < npz && k < (int)lev_host.size(); ++k) any_split = any_split || level_split(lev_host[k], hsel, dsel);
     TpFlux t; t.in[0] = fxo; t.in[1] = fx2; t.in[2] = mx; t.in[3] = fyo; t.in[4] = fy2; t.in[5] = my;
     t.in[6] = (dsel != DAMP_NONE) ? q : Fld{}; t.in[7] = d2b; t.in[8] = use_mass ? mass : Fld{};
     for (int n = 6; n < 9; ++n) if (!t.in[n].t) t.in[n].nk = npz;
@@ -476,8 +486,17 @@ struct Dycore {
       if (any_split) {       // the trajectory pass of the split levels: its own damping Laplacian (run as a nonlinear launch in the tangent mode too), then the chain
         if (dsel != DAMP_NONE) {
           Fld d2t = W((pre + "_d2t").c_str(), npz);
-          TpD2D h; h.in[0] = q; h.out[0] = d2t; h.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); h.k1 = npz; h.dsel = dsel; h.use_mass = use_mass; h.hsel = hsel; h.traj = 1;
+          // a trajectory nord of 2 (split_damp, nord >= 2): two Laplacians, the first into a scratch array on the range widened by one
+          bool nord2 = false;
+          for (int k = 0; k < npz && k < (int)lev_host.size(); ++k) { int n_; double d_; damp_of(lev_host[k], dsel, n_, d_, false); nord2 = nord2 || (n_ == 2 && d_ > 1.e-4 && level_split(lev_host[k], hsel, dsel)); }
           const size_t n0 = P.size();
+          TpD2D h; h.in[0] = q; h.out[0] = d2t; h.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); h.k1 = npz; h.dsel = dsel; h.use_mass = use_mass; h.hsel = hsel; h.traj = 1;
+          if (nord2) {
+            Fld d2a = W((pre + "_d2a").c_str(), npz);
+            TpD2D h1 = h; h1.out[0] = d2a; h1.orect[0] = R(is - 2, ie + 2, js - 2, je + 2); h1.pass = 1;
+            add_face(P, grp, h1, 2);
+            h.in[0] = d2a;
+          }
           add_face(P, grp, h, 1);
           for (size_t n = n0; n < P.size(); ++n) {
             auto f = P[n].fn;
@@ -578,8 +597,22 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
   if (!face && ntile != 1) { err = "ntile > 1 needs face = 1 (whole cube faces); face = 0 is the single doubly-periodic tile"; return false; }
   if (face && nx != ny) { err = "cube faces are square: nx must equal ny"; return false; }
   if (ntile < 1) { err = "ntile < 1"; return false; }
-  if (o.nord > 1 || o.nord_pert > 1 || o.nord < 0) { err = "nord/nord_pert in {0,1} only"; return false; }
   nh = !o.hydrostatic;
+  if (o.nord_pert > 1 || o.nord_pert < 0) { err = "nord_pert in {0,1} only (the divergence damping whose tangent / adjoint is taken; the trajectory's nord may be 2 or 3 with split_damp)"; return false; }
+  if (o.nord > 3 || o.nord < 0) { err = "nord in 0..3 only"; return false; }
+  if (!o.split_damp) {
+    // run_setup_pert (fv_control_tlmadm.F90:220-229) has overwritten the trajectory's damping options by the perturbation's: two different
+    // sets with split_damp = 0 describe no state the reference can be in
+    if (o.nord != o.nord_pert || o.dddmp != o.dddmp_pert || o.d2_bg != o.d2_bg_pert || o.d4_bg != o.d4_bg_pert || (o.do_vort_damp != 0) != (o.do_vort_damp_pert != 0) ||
+        o.vtdm4 != o.vtdm4_pert || o.d2_bg_k1 != o.d2_bg_k1_pert || o.d2_bg_k2 != o.d2_bg_k2_pert) {
+      err = "split_damp = 0 but the trajectory's damping options (nord, dddmp, d2_bg, d4_bg, do_vort_damp, vtdm4, d2_bg_k1, d2_bg_k2) differ from the *_pert ones: set split_damp = 1 "
+            "(fv_arrays_tlmadm.F90:76) or hand over equal values (run_setup_pert, fv_control_tlmadm.F90:220-229)";
+      return false;
+    }
+  } else {
+    if (o.nord == 0 && o.nord_pert > 0) { err = "split_damp: nord = 0 with nord_pert > 0 -- c_sw computes divg_d only for the trajectory's nord > 0 (sw_core_tlm.F90: IF (nord .GT. 0) divergence_corner), the perturbation's damping would read an undefined array"; return false; }
+    if (nh && o.nord > 1) { err = "non-hydrostatic with a trajectory nord > 1: the w / height damping would need the tangent of del6_vt_flux with nord 2 (sw_core_tlm.F90:1713-1726), not built"; return false; }
+  }
   if (nh && npz < 3) { err = "non-hydrostatic solver needs npz >= 3"; return false; }
   if (nh && !(o.a_imp > 0.5)) { err = "non-hydrostatic: a_imp must be > 0.5 (semi-implicit solver; the reference's a_imp <= 0.5 Riemann-invariant solver is not built)"; return false; }
   // options whose other values are not built are refused, never silently replaced by what is built:
@@ -954,14 +987,48 @@ inline void Dycore::build_acoustic() {
   { DdBD s; s.in[0] = da; s.in[1] = db; s.out[0] = dc; s.orect[0] = R(is, ie + 1, js, je + 1); s.k1 = npz; add_face(P, "d_sw", s, 1); }
   build_a2b(P, "d_sw", "a2bw", wk, vortb, npz);
   { DdC s; s.in[0] = ke; s.in[1] = dc; s.in[2] = divgd; s.in[3] = vortb; s.out[0] = ke2; s.orect[0] = R(is, ie + 1, js, je + 1);
-    s.dt = dt; s.dddmp = opt.dddmp; s.d4_bg = opt.d4_bg; s.k1 = npz; add(P, "d_sw", s); }
+    s.dt = dt; s.k1 = npz; add(P, "d_sw", s); }
+  // split_damp (sw_core_tlm.F90:2350-2369): the stages above are COMPUTE_DIVERGENCE_DAMPING_TLM with the perturbation's coefficients, whose
+  // tangent / adjoint is kept; the trajectory's own damping -- nord up to 3 -- gives the VALUES of ke2 (dampt.h), nonlinear and tangent mode alike
+  { bool need = false; int max_nord = 0;
+    for (int k = 0; k < npz; ++k) { const LevelParams& l = lev_host[k]; max_nord = std::max(max_nord, l.nord);
+      need = need || (l.split_damp && (l.nord != l.nord_p || l.d2_divg != l.d2_divg_p || l.dddmp != l.dddmp_p || l.d4_bg != l.d4_bg_p)); }
+    if (need) {
+      Fld s1 = max_nord >= 1 ? W("ddt_s1", npz) : Fld{}, s2 = max_nord >= 2 ? W("ddt_s2", npz) : Fld{};
+      Dycore* self = this;
+      Op op{"d_sw", [self, u, v, ua, va, uc, vc, divgd, vortb, ke, ke2, s1, s2, dt, max_nord](Exec& e, int) {
+        DampTArgs a; a.g = self->g; a.m = self->ctx.m; a.lev = self->lev_dev;
+        a.u = e.sh(u).t; a.v = e.sh(v).t; a.ua = e.sh(ua).t; a.va = e.sh(va).t; a.uc = e.sh(uc).t; a.vc = e.sh(vc).t;
+        a.divgd = e.sh(divgd).t; a.vortb = e.sh(vortb).t; a.ke = e.sh(ke).t; a.ke2 = e.sh(ke2).t; a.s1 = e.sh(s1).t; a.s2 = e.sh(s2).t; a.dt = dt;
+        run_damp_t(e, a, max_nord);
+      }};
+      op.modes = (1u << MODE_NL) | (1u << MODE_TL); op.name = "DampT";
+      P.push_back(op);
+    } }
   Fld fxv = W("fxv", npz), fyv = W("fyv", npz);
   build_tp(P, "d_sw", "tpv", vorta, crx, cry, xfx, yfx, rax, ray, xfx, yfx, Fld{}, HORD_VT, DAMP_NONE, false, fxv, fyv);
   Fld d6 = W("del6_d2", npz);
   { Del6AD s; s.in[0] = wk; s.out[0] = d6; s.orect[0] = R(is - 1, ie + 1, js - 1, je + 1); s.k1 = npz; add_face(P, "d_sw", s, 1); }
   Fld u_m = W("u_m", npz), v_m = W("v_m", npz);
-  { DswUpdateUV s; s.in[0] = u; s.in[1] = v; s.in[2] = ke2; s.in[3] = fxv; s.in[4] = fyv; s.in[5] = wk; s.in[6] = d6; s.out[0] = u_m; s.out[1] = v_m;
-    s.orect[0] = R(is, ie, js, je + 1); s.orect[1] = R(is, ie + 1, js, je); s.k1 = npz; add(P, "d_sw", s); }
+  { bool n2 = false;       // the trajectory's vorticity damping with nord_v = 2 (split_damp, nord >= 2): two more Laplacians, values only
+    for (int k = 0; k < npz; ++k) n2 = n2 || (lev_host[k].nord_v == 2 && lev_host[k].damp_vt > 1.e-5);
+    auto uv_stage = [&](auto s) { s.in[0] = u; s.in[1] = v; s.in[2] = ke2; s.in[3] = fxv; s.in[4] = fyv; s.in[5] = wk; s.in[6] = d6; s.out[0] = u_m; s.out[1] = v_m;
+      s.orect[0] = R(is, ie, js, je + 1); s.orect[1] = R(is, ie + 1, js, je); s.k1 = npz; return s; };
+    if (!n2) add(P, "d_sw", uv_stage(DswUpdateUV{}));
+    else {
+      Fld l1 = W("d6t_a", npz), l2 = W("d6t_b", npz);
+      Dycore* self = this;
+      Op op{"d_sw", [self, wk, l1, l2](Exec& e, int) {
+        const Geom& g_ = self->g;
+        LapTArgs a{g_, self->ctx.m, self->lev_dev, e.sh(wk).t, e.sh(l1).t, 1};
+        for_points(e, Rect{-1, g_.nx + 2, -1, g_.ny + 2}, g_.ntile * g_.npz, LapTPass{a}, "LapT.1", 0.);
+        a.src = e.sh(l1).t; a.dst = e.sh(l2).t; a.pass = 2;
+        for_points(e, Rect{0, g_.nx + 1, 0, g_.ny + 1}, g_.ntile * g_.npz, LapTPass{a}, "LapT.2", 0.);
+      }};
+      op.modes = (1u << MODE_NL) | (1u << MODE_TL); op.name = "LapT";
+      P.push_back(op);
+      auto s2 = uv_stage(DswUpdateUVT<true>{}); s2.in[7] = l2; add(P, "d_sw", s2);
+    } }
   // delp, pt of the step: first needed with their halo by geopk / the pressure gradient; the exchange runs beside the KE / vorticity /
   // damping launches of d_sw
   add_halo_async(P, "halo_dp", H_CELL, delp_o); add_halo_async(P, "halo_dp", H_CELL, pt_o);

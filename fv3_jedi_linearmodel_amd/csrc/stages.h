@@ -730,14 +730,27 @@ HD T lap_corner(const A& a, const Ctx& c, int tile, int i, int j) {
 }
 enum DampSel { DAMP_NONE = 0, DAMP_V = 1, DAMP_T = 2 };
 // pert: the level's transport runs with split schemes and this is the perturbation chain: nord_v_pert / damp_vt_pert for the mass
-// (sw_core_tlm.F90:1672-1679) and, as nord_t_pert / damp_t_pert = the same pair (dyn_core_tlm.F90:856-859), for the heat transport
+// (sw_core_tlm.F90:1672-1679), nord_t_pert / damp_t_pert for the heat transport (:1795-1800) -- the latter pair is the former as it
+// stands BEFORE the perturbation sponge rules override it (dyn_core_tlm.F90:856-859 vs :913-917)
 HD void damp_of(const LevelParams& l, int sel, int& nord, double& damp_c, bool pert = false) {
   if (sel != DAMP_V && sel != DAMP_T) { nord = -1; damp_c = 0.; }
-  else if (pert) { nord = l.nord_v_pert; damp_c = l.damp_vt_pert; }
+  else if (pert) { if (sel == DAMP_V) { nord = l.nord_v_pert; damp_c = l.damp_vt_pert; } else { nord = l.nord_t_pert; damp_c = l.damp_t_pert; } }
   else if (sel == DAMP_V) { nord = l.nord_v; damp_c = l.damp_vt; }
   else { nord = l.nord_t; damp_c = l.damp_t; }
 }
-HD bool level_split(const LevelParams& l, int hsel) { return hord_traj_of(l, hsel) != hord_of(l, hsel); }
+// (damp_c da_min)^(nord+1), tp_core_tlm.F90:206, :228
+HD double damp_pow(double x, int nord) { double r = x; for (int n = 0; n < nord; ++n) r *= x; return r; }
+// Does the level run this transport twice -- the tangent / adjoint with the perturbation's scheme and damping, the values again with the
+// trajectory's?  split_hord: the schemes differ (sw_core_tlm.F90:1664-1682); split_damp: the reference takes the two-call branch for the
+// mass and heat transports whatever the schemes (:1664, :1787) -- the second call changes the values only where the damping pairs differ,
+// so only then is it made here.
+HD bool level_split(const LevelParams& l, int hsel, int dsel = DAMP_NONE) {
+  if (hord_traj_of(l, hsel) != hord_of(l, hsel)) return true;
+  if (!l.split_damp || (dsel != DAMP_V && dsel != DAMP_T)) return false;
+  int n0, n1; double d0, d1; damp_of(l, dsel, n0, d0, false); damp_of(l, dsel, n1, d1, true);
+  const bool on0 = d0 > 1.e-4, on1 = d1 > 1.e-4;
+  return on0 != on1 || (on0 && (n0 != n1 || d0 != d1));
+}
 struct TpD2D {
   static constexpr bool LDS_FW_OK = true;
   STAGE_BASE("TpD2", 1, 1)   // in: q   out: d2b  (is-1..ie+1, js-1..je+1); zero where the level does not use nord=1
@@ -748,16 +761,20 @@ struct TpD2D {
   HD bool alias(const Ctx& c, int, int i, int j, int n, int& ai, int& aj) const { return corner_alias(c.g, n + 1, i, j, ai, aj); }
   int dsel; int use_mass;
   int hsel = -1, traj = 0;      // the transport's scheme selector; traj: the Laplacian of the values-only trajectory pass of a split level
+  int pass = 0;                 // 1: the first of the two Laplacians of a nord = 2 level (trajectory pass), written to a scratch array
   HD static constexpr Box box(int) { return Box{-1, 1, -1, 1, 0, 0}; }
   template <bool EDGE, class T, class A>
   HD void eval_e(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    const bool split = hsel >= 0 && level_split(c.lev[k - 1], hsel);
+    const bool split = hsel >= 0 && level_split(c.lev[k - 1], hsel, dsel);
     int nord; double dc; damp_of(c.lev[k - 1], dsel, nord, dc, split && !traj);
     o[0] = T(0.);
     if (traj && !split) return;
-    if (nord != 1 || !(dc > 1.e-4)) return;
-    const double damp = use_mass ? 1.0 : (dc * c.m.da_min) * (dc * c.m.da_min);
-    o[0] = damp * lap_corner<EDGE, 0, T>(a, c, tile, i, j);
+    if (nord < 1 || !(dc > 1.e-4)) return;
+    // nord = 2 (a trajectory pass only): this is the second Laplacian, of the first one's result (in[0] = TpD2D with pass = 1), sign as
+    // in tp_core_tlm.F90:2019-2031
+    if (pass == 1) { if (nord == 2) o[0] = lap_corner<EDGE, 0, T>(a, c, tile, i, j); return; }
+    const double damp = use_mass ? 1.0 : damp_pow(dc * c.m.da_min, nord);
+    o[0] = (nord == 2 ? -damp : damp) * lap_corner<EDGE, 0, T>(a, c, tile, i, j);
   }
 };
 typedef Edged<TpD2D, false> TpD2;
@@ -772,10 +789,10 @@ struct TpFlux {
   HD static constexpr Box box(int M) { return (M == 6 || M == 7 || M == 8) ? Box{-1, 0, -1, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    int nord; double dc; damp_of(c.lev[k - 1], dsel, nord, dc, hsel >= 0 && level_split(c.lev[k - 1], hsel));
+    int nord; double dc; damp_of(c.lev[k - 1], dsel, nord, dc, hsel >= 0 && level_split(c.lev[k - 1], hsel, dsel));
     const bool dmp = (dsel != DAMP_NONE) && (dc > 1.e-4);
     double damp = 0.;
-    if (dmp) { damp = dc * c.m.da_min; if (nord == 1) damp = damp * damp; }
+    if (dmp) damp = damp_pow(dc * c.m.da_min, nord);
     o[0] = o[1] = T(0.);
     if ((a.want & 0x1u) && orect[0].has(i, j)) {
       T f = 0.5 * (IN(0, i, j) + IN(1, i, j)) * IN(2, i, j);
@@ -814,11 +831,11 @@ struct TpDamp {
   HD static constexpr Box box(int) { return Box{-1, 0, -1, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    int nord; double dc; damp_of(c.lev[k - 1], dsel, nord, dc, hsel >= 0 && level_split(c.lev[k - 1], hsel));
+    int nord; double dc; damp_of(c.lev[k - 1], dsel, nord, dc, hsel >= 0 && level_split(c.lev[k - 1], hsel, dsel));
     const bool dmp = (dsel != DAMP_NONE) && (dc > 1.e-4);
     o[0] = o[1] = T(0.);
     if (!dmp) return;
-    double damp = dc * c.m.da_min; if (nord == 1) damp = damp * damp;
+    const double damp = damp_pow(dc * c.m.da_min, nord);
     if ((a.want & 0x1u) && orect[0].has(i, j)) {
       T f2;
       if (nord == 0) { f2 = MET(del6_v, i, j) * (IN(0, i - 1, j) - IN(0, i, j)); if (!use_mass) f2 = damp * f2; }
@@ -942,7 +959,7 @@ struct DdAD {
   HD static constexpr Box box(int M) { return M == 0 ? Box{0, 1, 0, 1, 0, 0} : (M == 3 || M == 4) ? Box{-1, 0, -1, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
   template <bool EDGE, class T, class A>
   HD void eval_e(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
-    const int nord = c.lev[k - 1].nord;
+    const int nord = c.lev[k - 1].nord_p;      // the damping whose tangent / adjoint is taken (split_damp: the perturbation's)
     constexpr bool F = EDGE; const int npx = c.g.nx + 1, npy = c.g.ny + 1;
     o[0] = o[1] = T(0.);
     if (nord == 0) {   // :7874-7922
@@ -1073,29 +1090,27 @@ struct A2bB_ {
 };
 struct DdC {   // Smagorinsky-type coefficient and damping term added to KE (:7938-7956, :8023-8070)
   STAGE_COMMON("DdC", 4, 1)   // in: ke dc divgd vort_b   out: ke2
-  double dt, dddmp, d4_bg;
+  double dt;
   HD static constexpr Box box(int) { return Box{0, 0, 0, 0, 0, 0}; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     const LevelParams& l = c.lev[k - 1];
-    const double absdt = dt >= 0. ? dt : -dt;
+    const double absdt = dt >= 0. ? dt : -dt, dddmp = l.dddmp_p, d4_bg = l.d4_bg_p, d2_divg = l.d2_divg_p;
     T ke = IN(0, i, j), dcv = IN(1, i, j);
-    if (l.nord == 0) {
+    if (l.nord_p == 0) {
       T x = dcv * dt;
       T abs2 = (val(x) >= 0.) ? x : -x;
       T y3 = dddmp * abs2;
       T y1 = (0.20 > val(y3)) ? y3 : T(0.20);
-      T mx = (l.d2_divg < val(y1)) ? y1 : T(l.d2_divg);
+      T mx = (d2_divg < val(y1)) ? y1 : T(d2_divg);
       o[0] = ke + (c.m.da_min_c * mx) * dcv;
     } else {
       T delpc = IN(2, i, j);
       T vs = T(0.);
       if (!(dddmp < 1.e-5)) { T vb = IN(3, i, j); vs = absdt * dsqrt(delpc * delpc + vb * vb); }
       T y2 = (0.20 > dddmp * val(vs)) ? dddmp * vs : T(0.20);
-      T mx = (l.d2_divg < val(y2)) ? y2 : T(l.d2_divg);
-      const double pw = c.m.da_min_c * d4_bg;
-      double dd8 = pw;
-      for (int n = 0; n < l.nord; ++n) dd8 *= pw;
+      T mx = (d2_divg < val(y2)) ? y2 : T(d2_divg);
+      const double dd8 = damp_pow(c.m.da_min_c * d4_bg, l.nord_p);
       o[0] = ke + ((c.m.da_min_c * mx) * delpc + dd8 * dcv);
     }
   }
@@ -1117,12 +1132,15 @@ typedef Edged<Del6AD, false> Del6A;
 typedef Edged<Del6AD, true> Del6AE;
 // momentum update (sw_core_tlm.F90:3555-3564) + vorticity-damping fluxes, trajectory and
 // perturbation coefficients kept apart (sw_core_tlm.F90:2436-2452, :2502-2530)
-struct DswUpdateUV {
-  STAGE_BASE("DswUpdateUV", 7, 2)   // in: u v ke2 fxv fyv wk d2b   out: u_n v_n
+// N2: the build whose trajectory runs its vorticity damping with nord_v = 2 on some level (split_damp with nord >= 2): the twice-applied
+// Laplacian comes in as one more, values-only, input (dampt.h LapTPass)
+template <bool N2>
+struct DswUpdateUVT {
+  STAGE_BASE(N2 ? "DswUpdateUV2" : "DswUpdateUV", N2 ? 8 : 7, 2)   // in: u v ke2 fxv fyv wk d2b [d2bb]   out: u_n v_n
   STAGE_NO_ALIAS
-  HD static constexpr bool uses(int M, int di, int dj, int) { return M == 2 ? !(di == 1 && dj == 1) : (M == 5 || M == 6) ? !(di == -1 && dj == -1) : true; }
-  HD static constexpr unsigned wants(int M) { return (M == 0 || M == 4) ? 0x1u : (M == 1 || M == 3) ? 0x2u : 0x3u; }
-  HD static constexpr Box box(int M) { return M == 2 ? Box{0, 1, 0, 1, 0, 0} : (M == 5 || M == 6) ? Box{-1, 0, -1, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
+  HD static constexpr bool uses(int M, int di, int dj, int) { return M == 2 ? !(di == 1 && dj == 1) : (M >= 5) ? !(di == -1 && dj == -1) : true; }
+  HD static constexpr unsigned wants(int M) { return M == 7 ? 0x0u : (M == 0 || M == 4) ? 0x1u : (M == 1 || M == 3) ? 0x2u : 0x3u; }
+  HD static constexpr Box box(int M) { return M == 2 ? Box{0, 1, 0, 1, 0, 0} : (M >= 5) ? Box{-1, 0, -1, 0, 0, 0} : Box{0, 0, 0, 0, 0, 0}; }
   HD static double pw(double x, int n) { double r = x; for (int m = 0; m < n; ++m) r *= x; return r; }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
@@ -1136,6 +1154,7 @@ struct DswUpdateUV {
       if ((dt_ && l.nord_v == 0) || (dp_ && l.nord_v_pert == 0)) e0 = MET(del6_u, i, j) * (IN(5, i, j - 1) - IN(5, i, j));
       if ((dt_ && l.nord_v == 1) || (dp_ && l.nord_v_pert == 1)) e1 = MET(del6_u, i, j) * (IN(6, i, j) - IN(6, i, j - 1));
       T vt_t = d4t * (l.nord_v == 0 ? e0 : e1), vt_p = d4p * (l.nord_v_pert == 0 ? e0 : e1);
+      if constexpr (N2) if (dt_ && l.nord_v == 2) vt_t = T(d4t * (MET(del6_u, i, j) * (val(IN(7, i, j)) - val(IN(7, i, j - 1)))));
       o[0] = IN(0, i, j) * MET(dx, i, j) + (ke - IN(2, i + 1, j)) + IN(4, i, j) + combine(vt_t, vt_p);
     }
     if ((a.want & 0x2u) && orect[1].has(i, j)) {
@@ -1143,10 +1162,12 @@ struct DswUpdateUV {
       if ((dt_ && l.nord_v == 0) || (dp_ && l.nord_v_pert == 0)) e0 = MET(del6_v, i, j) * (IN(5, i - 1, j) - IN(5, i, j));
       if ((dt_ && l.nord_v == 1) || (dp_ && l.nord_v_pert == 1)) e1 = MET(del6_v, i, j) * (IN(6, i, j) - IN(6, i - 1, j));
       T ut_t = d4t * (l.nord_v == 0 ? e0 : e1), ut_p = d4p * (l.nord_v_pert == 0 ? e0 : e1);
+      if constexpr (N2) if (dt_ && l.nord_v == 2) ut_t = T(d4t * (MET(del6_v, i, j) * (val(IN(7, i, j)) - val(IN(7, i - 1, j)))));
       o[1] = IN(1, i, j) * MET(dy, i, j) + (ke - IN(2, i, j + 1)) - IN(3, i, j) - combine(ut_t, ut_p);
     }
   }
 };
+typedef DswUpdateUVT<false> DswUpdateUV;
 
 // ===================================================================== tracer_2d (fv_tracer2d_tlm.F90:1148-1446)
 // Sub-cycling: Courant numbers and mass fluxes of a level are divided by the number of sub-steps it takes

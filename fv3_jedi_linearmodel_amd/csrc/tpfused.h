@@ -85,7 +85,7 @@ template <class T, bool STORE, int NTH, bool TRAJ = false>
 DEV void tp_fused_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx, int by, double* lds, int tid, int nth) {
   typedef TpfIO<T> IO;
   static_assert(!TRAJ || (std::is_same<T, double>::value && !STORE), "the trajectory pass computes values only");
-  const bool split = level_split(c.lev[k - 1], a.hsel);
+  const bool split = level_split(c.lev[k - 1], a.hsel, a.dsel);
   if (TRAJ && !split) return;
   const Geom& g = c.g;
   const int nx = g.nx, ny = g.ny;
@@ -190,7 +190,7 @@ DEV void tp_fused_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int
   int nord; double dc; damp_of(c.lev[k - 1], a.dsel, nord, dc, split && !TRAJ);
   const bool dmp = (a.dsel != DAMP_NONE) && (dc > 1.e-4);
   double damp = 0.;
-  if (dmp) { damp = dc * c.m.da_min; if (nord == 1) damp = damp * damp; }
+  if (dmp) damp = damp_pow(dc * c.m.da_min, nord);
   const Fld& d2 = TRAJ ? a.d2b_t : a.d2b;
   { constexpr int w = TPF_W + 1, n = w * (TPF_H + 1);
     TPF_LOOP(e, n) {

@@ -40,7 +40,12 @@ typedef struct fv3lm_options {
   int hord_mt_ks_pert, hord_vt_ks_pert, hord_tm_ks_pert, hord_dp_ks_pert, hord_tr_ks_pert;
   int kord_tm, kord_mt, kord_wz, kord_tr;                          /* trajectory remap profiles */
   int kord_tm_pert, kord_mt_pert, kord_wz_pert, kord_tr_pert;      /* perturbation remap profiles (fv_flags_pert_type): |kord| > 16, the linear one */
-  int hydrostatic, pad_;
+  int hydrostatic;
+  int split_damp;   /* fv_flags_pert_type%split_damp (fv_arrays_tlmadm.F90:76; the reference's default is .true.).  1: the perturbation takes its own damping
+                       (nord_pert, dddmp_pert, d2_bg_pert, d4_bg_pert, vtdm4_pert ... with the perturbation sponge rules, dyn_core_tlm.F90:835-921), the
+                       trajectory values the trajectory's (sw_core_tlm.F90:1664-1682, :1787-1803, :2341-2369); the trajectory's nord may then be 2 or 3.
+                       0: run_setup_pert has copied the perturbation's damping options onto the trajectory (fv_control_tlmadm.F90:220-229): the two sets
+                       handed over must then be equal, anything else is refused. */
   double dddmp, d2_bg, d4_bg, vtdm4, d2_bg_k1, d2_bg_k2, d_con, ke_bg;
   double dddmp_pert, d2_bg_pert, d4_bg_pert, vtdm4_pert, d2_bg_k1_pert, d2_bg_k2_pert, d2_bg_ks_pert;
   double akap, cp, zvir, grav_jedi;                          /* JEDI constants */

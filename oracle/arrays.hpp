@@ -109,6 +109,13 @@ struct LevelParams {
   int nord_v_pert; double damp_vt_pert;
   // perturbation advection schemes where they differ from the trajectory's (split_hord): fv_tp_2d runs twice then (tp_core.hpp fv_tp_2d_split)
   int hord_mt_pert, hord_vt_pert, hord_tm_pert, hord_dp_pert;
+  // split_damp (fv_arrays_tlmadm.F90:76, sw_core_tlm.F90:1664, :1787, :2341-2369): the perturbation's own divergence damping
+  // (nord_k_pert, d2_divg_pert of dyn_core_tlm.F90:839-918 with dddmp_pert, d4_bg_pert) and its own damping pair in the heat
+  // transport -- nord_t_pert / damp_t_pert are taken BEFORE the perturbation sponge overrides nord_v_pert / damp_vt_pert
+  // (dyn_core_tlm.F90:856-859 vs :913-917)
+  bool split_damp = false;
+  int nord_pert = 0, nord_t_pert = 0;
+  double d2_divg_pert = 0., damp_t_pert = 0., dddmp_pert = 0., d4_bg_pert = 0.;
 };
 
 struct Flags {

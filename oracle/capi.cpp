@@ -110,7 +110,7 @@ const char* orc_metric_names() { return METRIC_NAMES; }
 
 // iopt: hord_mt,hord_vt,hord_tm,hord_dp,hord_tr, nord, do_vort_damp, n_sponge,
 //       hord_*_pert(5), nord_pert, do_vort_damp_pert, n_sponge_pert, hord_ks_traj, hord_ks_pert,
-//       hord_*_ks_traj(5), hord_*_ks_pert(5), kord_tm, kord_mt, kord_wz, kord_tr, kord_*_pert(4)        (36 ints)
+//       hord_*_ks_traj(5), hord_*_ks_pert(5), kord_tm, kord_mt, kord_wz, kord_tr, kord_*_pert(4), split_damp        (37 ints)
 // ropt: dddmp,d2_bg,d4_bg,vtdm4,d2_bg_k1,d2_bg_k2,d_con,ke_bg, dddmp_pert,d2_bg_pert,d4_bg_pert,vtdm4_pert,
 //       d2_bg_k1_pert,d2_bg_k2_pert,d2_bg_ks_pert, akap,cp,zvir,grav_jedi, cp_air,rdgas,rvgas,grav,radius,omega,hlv,
 //       ptop, da_min, da_min_c                                                            (29 doubles)
@@ -138,6 +138,7 @@ void* orc_create(int nx, int ny, int npz, int nq, const double* const* metrics, 
   o.hord_mt_ks_pert = *p++; o.hord_vt_ks_pert = *p++; o.hord_tm_ks_pert = *p++; o.hord_dp_ks_pert = *p++; o.hord_tr_ks_pert = *p++;
   h->ro.kord_tm = *p++; h->ro.kord_mt = *p++; h->ro.kord_wz = *p++; h->ro.kord_tr = *p++;
   h->ro.kord_tm_pert = *p++; h->ro.kord_mt_pert = *p++; h->ro.kord_wz_pert = *p++; h->ro.kord_tr_pert = *p++;
+  o.split_damp = *p++ != 0;
   const double* r = ropt;
   o.dddmp = *r++; o.d2_bg = *r++; o.d4_bg = *r++; o.vtdm4 = *r++; o.d2_bg_k1 = *r++; o.d2_bg_k2 = *r++; o.d_con = *r++; o.ke_bg = *r++;
   o.dddmp_pert = *r++; o.d2_bg_pert = *r++; o.d4_bg_pert = *r++; o.vtdm4_pert = *r++; o.d2_bg_k1_pert = *r++;

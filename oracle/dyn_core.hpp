@@ -22,6 +22,7 @@ struct DampOpts {
   int nord_pert = 1; double dddmp_pert = 0.2, d2_bg_pert = 0.015, d4_bg_pert = 0.15; bool do_vort_damp_pert = true;
   double vtdm4_pert = 0.0005, d2_bg_k1_pert = 4., d2_bg_k2_pert = 2., d2_bg_ks_pert = 2.; int n_sponge_pert = 9;
   bool hord_ks_traj = true, hord_ks_pert = true;
+  bool split_damp = false;       // fv_flags_pert_type%split_damp (the reference's default is .true.)
   int hord_mt_ks_traj = 1, hord_vt_ks_traj = 1, hord_tm_ks_traj = 1, hord_dp_ks_traj = 1, hord_tr_ks_traj = 1;
   int hord_mt_ks_pert = 1, hord_vt_ks_pert = 1, hord_tm_ks_pert = 1, hord_dp_ks_pert = 1, hord_tr_ks_pert = 1;
 };
@@ -66,10 +67,13 @@ inline bool level_params(const DampOpts& o, int k, int npz, LevelParams& lp) {
     }
   }
   int hord_m_pert = o.hord_mt_pert, hord_t_pert = o.hord_tm_pert, hord_v_pert = o.hord_vt_pert, hord_p_pert = o.hord_dp_pert;
+  int nord_k_pert = o.nord_pert;
   int nord_v_pert = (2 > o.nord_pert) ? o.nord_pert : 2;
   double d2_divg_pert = (0.20 > o.d2_bg_pert) ? o.d2_bg_pert : 0.20;
   double damp_vt_pert = o.do_vort_damp_pert ? o.vtdm4_pert : 0.;
+  const int nord_t_pert = nord_v_pert; const double damp_t_pert = damp_vt_pert;     // :856-859, before the sponge rules below
   if (k <= o.n_sponge_pert) {
+    nord_k_pert = 0;
     if (k <= o.n_sponge_pert - 1) {
       if (o.hord_ks_traj) { hord_m = o.hord_mt_ks_traj; hord_t = o.hord_tm_ks_traj; hord_v = o.hord_vt_ks_traj; hord_p = o.hord_dp_ks_traj; }
       if (o.hord_ks_pert) { hord_m_pert = o.hord_mt_ks_pert; hord_t_pert = o.hord_tm_ks_pert; hord_v_pert = o.hord_vt_ks_pert; hord_p_pert = o.hord_dp_ks_pert; }
@@ -85,6 +89,8 @@ inline bool level_params(const DampOpts& o, int k, int npz, LevelParams& lp) {
   lp.d2_divg = d2_divg; lp.damp_vt = damp_vt; lp.damp_w = damp_w; lp.damp_t = damp_t; lp.d_con = d_con_k;
   lp.nord_v_pert = nord_v_pert; lp.damp_vt_pert = damp_vt_pert;
   lp.hord_mt_pert = hord_m_pert; lp.hord_vt_pert = hord_v_pert; lp.hord_tm_pert = hord_t_pert; lp.hord_dp_pert = hord_p_pert;
+  lp.split_damp = o.split_damp; lp.nord_pert = nord_k_pert; lp.d2_divg_pert = d2_divg_pert; lp.nord_t_pert = nord_t_pert; lp.damp_t_pert = damp_t_pert;
+  lp.dddmp_pert = o.dddmp_pert; lp.d4_bg_pert = o.d4_bg_pert;
   return true;
 }
 

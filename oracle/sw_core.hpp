@@ -550,8 +550,47 @@ void del6_vt_flux(int nord, double damp, const Arr2<T>& q, Arr2<T>& d2, Arr2<T>&
   }
 }
 
+// fill_corners of a B-grid (corner-point) scalar, tools/fv_mp_nlm_mod.F90:1055-1084 (FILL = XDir / YDir, BGRID), and of a D-grid
+// vector pair, fill_corners_dgrid :1271-1303 with mySign = -1 (VECTOR): the corner squares of the halo of a whole cube face.
+template <class T>
+void fill_corners_bgrid(Arr2<T>& q, int dir, const Bounds& bd) {
+  const int npx = bd.npx, npy = bd.npy, ng = bd.ng;
+  for (int j = 1; j <= ng; ++j)
+    for (int i = 1; i <= ng; ++i) {
+      if (dir == 1) {
+        if (bd.sw_corner) q(1 - i, 1 - j) = q(1 - j, i + 1);
+        if (bd.nw_corner) q(1 - i, npy + j) = q(1 - j, npy - i);
+        if (bd.se_corner) q(npx + i, 1 - j) = q(npx + j, i + 1);
+        if (bd.ne_corner) q(npx + i, npy + j) = q(npx + j, npy - i);
+      } else {
+        if (bd.sw_corner) q(1 - j, 1 - i) = q(i + 1, 1 - j);
+        if (bd.nw_corner) q(1 - j, npy + i) = q(i + 1, npy + j);
+        if (bd.se_corner) q(npx + j, 1 - i) = q(npx - i, 1 - j);
+        if (bd.ne_corner) q(npx + j, npy + i) = q(npx - i, npy + j);
+      }
+    }
+}
+template <class T>
+void fill_corners_dgrid_vector(Arr2<T>& x, Arr2<T>& y, const Bounds& bd) {
+  const int npx = bd.npx, npy = bd.npy, ng = bd.ng; const double sgn = -1.0;
+  for (int j = 1; j <= ng; ++j)
+    for (int i = 1; i <= ng; ++i) {
+      if (bd.sw_corner) x(1 - i, 1 - j) = sgn * y(1 - j, i);
+      if (bd.nw_corner) x(1 - i, npy + j) = y(1 - j, npy - i);
+      if (bd.se_corner) x(npx - 1 + i, 1 - j) = y(npx + j, i);
+      if (bd.ne_corner) x(npx - 1 + i, npy + j) = sgn * y(npx + j, npy - i);
+    }
+  for (int j = 1; j <= ng; ++j)
+    for (int i = 1; i <= ng; ++i) {
+      if (bd.sw_corner) y(1 - i, 1 - j) = sgn * x(j, 1 - i);
+      if (bd.nw_corner) y(1 - i, npy - 1 + j) = x(j, npy + i);
+      if (bd.se_corner) y(npx + i, 1 - j) = x(npx - j, 1 - i);
+      if (bd.ne_corner) y(npx + i, npy - 1 + j) = sgn * x(npx - j, npy + i);
+    }
+}
+
 // compute_divergence_damping, sw_core_tlm.F90:7760-8072 (_TLM :8178-8598), grid_type<3, not
-// stretched, nord <= 1 (so fill_corners is never called: nt = 0).
+// stretched; nord > 1 fills the corner squares before each difference (fill_c, :8463-8530).
 template <class T>
 void compute_divergence_damping(int nord, double d2_bg, double d4_bg, double dddmp, double dt, Arr2<T>& vort,
                                 Arr2<T>& ptc, Arr2<T>& delpc, Arr2<T>& ke, const Arr2<T>& u, const Arr2<T>& v,
@@ -561,7 +600,7 @@ void compute_divergence_damping(int nord, double d2_bg, double d4_bg, double ddd
   const bool face = bd.any_edge();
   const int is2 = face ? std::max(2, is) : is, ie1 = face ? std::min(npx - 1, ie + 1) : ie + 1;
   const double absdt = dt >= 0. ? dt : -dt;
-  assert(nord <= 1);
+  assert(nord <= 3);
   if (nord == 0) {   // :7874-7957
     for (int j = js; j <= je + 1; ++j) {
       if (face && (j == 1 || j == npy)) {
@@ -601,10 +640,14 @@ void compute_divergence_damping(int nord, double d2_bg, double d4_bg, double ddd
     const int n2 = nord + 1;
     for (int n = 1; n <= nord; ++n) {
       const int nt = nord - n;
+      const bool fill_c = nt != 0 && (bd.sw_corner || bd.se_corner || bd.ne_corner || bd.nw_corner);
+      if (fill_c) fill_corners_bgrid(divg_d, 1, bd);
       for (int j = js - nt; j <= je + 1 + nt; ++j)
         for (int i = is - 1 - nt; i <= ie + 1 + nt; ++i) vc(i, j) = (divg_d(i + 1, j) - divg_d(i, j)) * g.divg_u(i, j);
+      if (fill_c) fill_corners_bgrid(divg_d, 2, bd);
       for (int j = js - 1 - nt; j <= je + 1 + nt; ++j)
         for (int i = is - nt; i <= ie + 1 + nt; ++i) uc(i, j) = (divg_d(i, j + 1) - divg_d(i, j)) * g.divg_v(i, j);
+      if (fill_c) fill_corners_dgrid_vector(vc, uc, bd);
       for (int j = js - nt; j <= je + 1 + nt; ++j)
         for (int i = is - nt; i <= ie + 1 + nt; ++i) divg_d(i, j) = uc(i, j - 1) - uc(i, j) + vc(i - 1, j) - vc(i, j);
       if (bd.sw_corner) divg_d(1, 1) = divg_d(1, 1) - uc(1, 0);
@@ -802,7 +845,7 @@ void d_sw(Arr2<T>& delp, Arr2<T>& pt, Arr2<T>& u, Arr2<T>& v, Arr2<T>& uc, Arr2<
     for (int i = isd; i <= ied; ++i) ra_y(i, j) = g.area(i, j) + (yfx_adv(i, j) - yfx_adv(i, j + 1));
   // delp transport (:2979-2986): nord=nord_v, damp_c=damp_v, no mass
   fv_tp_2d_split<T>(delp, crx_adv, cry_adv, lp.hord_dp, lp.hord_dp_pert, fx, fy, xfx_adv, yfx_adv, g, bd, ra_x, ra_y, nullptr, nullptr,
-                    nullptr, lp.nord_v, lp.damp_vt, lp.nord_v_pert, lp.damp_vt_pert);
+                    nullptr, lp.nord_v, lp.damp_vt, lp.nord_v_pert, lp.damp_vt_pert, lp.split_damp);
   for (int j = jsd; j <= jed; ++j)            // flux capacitors :2988-3006
     for (int i = is; i <= ie + 1; ++i) cx(i, j) = cx(i, j) + crx_adv(i, j);
   for (int j = js; j <= je; ++j)
@@ -825,9 +868,10 @@ void d_sw(Arr2<T>& delp, Arr2<T>& pt, Arr2<T>& u, Arr2<T>& v, Arr2<T>& uc, Arr2<
       for (int i = is; i <= ie; ++i) (*w)(i, j) = delp(i, j) * (*w)(i, j) + (gx(i, j) - gx(i + 1, j) + (gy(i, j) - gy(i, j + 1))) * g.rarea(i, j);
   }
   // pt transport (:3064-3072): mass=delp, nord_t, damp_t
-  // perturbation damping of the split call: nord_t_pert = nord_v_pert(k), damp_t_pert = damp_vt_pert(k) (dyn_core_tlm.F90:856-859)
+  // perturbation damping of the split call: nord_t_pert, damp_t_pert = nord_v_pert(k), damp_vt_pert(k) as they stand BEFORE the
+  // perturbation sponge overrides the latter two (dyn_core_tlm.F90:856-859, :913-917)
   fv_tp_2d_split<T>(pt, crx_adv, cry_adv, lp.hord_tm, lp.hord_tm_pert, gx, gy, xfx_adv, yfx_adv, g, bd, ra_x, ra_y, &fx, &fy, &delp,
-                    lp.nord_t, lp.damp_t, lp.nord_v_pert, lp.damp_vt_pert);
+                    lp.nord_t, lp.damp_t, lp.nord_t_pert, lp.damp_t_pert, lp.split_damp);
   for (int j = js; j <= je; ++j)              // :3107-3116
     for (int i = is; i <= ie; ++i) {
       pt(i, j) = pt(i, j) * delp(i, j) + (gx(i, j) - gx(i + 1, j) + (gy(i, j) - gy(i, j + 1))) * g.rarea(i, j);
@@ -884,8 +928,22 @@ void d_sw(Arr2<T>& delp, Arr2<T>& pt, Arr2<T>& u, Arr2<T>& v, Arr2<T>& uc, Arr2<
         if (lp.damp_w > 1.e-5) (*w)(i, j) = (*w)(i, j) + dw(i, j);
       }
   }
-  compute_divergence_damping(lp.nord, lp.d2_divg, d4_bg, dddmp, dt, vort, ptc, delpc, ke, u, v, uc, vc, ua, va,
-                             divg_d, wk, g, bd);
+  if (!lp.split_damp) {
+    compute_divergence_damping(lp.nord, lp.d2_divg, d4_bg, dddmp, dt, vort, ptc, delpc, ke, u, v, uc, vc, ua, va,
+                               divg_d, wk, g, bd);
+  } else {
+    // sw_core_tlm.F90:2350-2369: the _TLM routine with the perturbation's coefficients on copies (*_tj) -- its tangents are kept --
+    // then the nonlinear routine with the trajectory's coefficients, whose values are kept
+    Arr2<T> wk_tj = wk, vort_tj = vort, delpc_tj = delpc, ptc_tj = ptc, ke_tj = ke, vc_tj = vc, uc_tj = uc, divg_d_tj = divg_d;
+    compute_divergence_damping(lp.nord_pert, lp.d2_divg_pert, lp.d4_bg_pert, lp.dddmp_pert, dt, vort_tj, ptc_tj, delpc_tj, ke_tj, u, v,
+                               uc_tj, vc_tj, ua, va, divg_d_tj, wk_tj, g, bd);
+    Arr2<double> wkd = values_of(wk), vortd = values_of(vort), delpcd = values_of(delpc), ptcd = values_of(ptc), ked = values_of(ke),
+                 ud = values_of(u), vd = values_of(v), ucd = values_of(uc), vcd = values_of(vc), uad = values_of(ua), vad = values_of(va),
+                 dgd = values_of(divg_d);
+    compute_divergence_damping<double>(lp.nord, lp.d2_divg, d4_bg, dddmp, dt, vortd, ptcd, delpcd, ked, ud, vd, ucd, vcd, uad, vad, dgd, wkd, g, bd);
+    for (int j = js; j <= je + 1; ++j)
+      for (int i = is; i <= ie + 1; ++i) { ke(i, j) = ke_tj(i, j); set_val(ke(i, j), ked(i, j)); }
+  }
   for (int j = jsd; j <= jed; ++j)            // :3535-3540 hydrostatic
     for (int i = isd; i <= ied; ++i) vort(i, j) = wk(i, j) + g.f0(i, j);
   fv_tp_2d_split<T>(vort, crx_adv, cry_adv, lp.hord_vt, lp.hord_vt_pert, fx, fy, xfx_adv, yfx_adv, g, bd, ra_x, ra_y, nullptr, nullptr,

@@ -262,8 +262,9 @@ template <class T> Arr2<double> values_of(const Arr2<T>& a) {
 template <class T>
 void fv_tp_2d_split(const Arr2<T>& q, const Arr2<T>& crx, const Arr2<T>& cry, int hord, int hord_pert, Arr2<T>& fx, Arr2<T>& fy,
                     const Arr2<T>& xfx, const Arr2<T>& yfx, const Grid& g, const Bounds& bd, const Arr2<T>& ra_x, const Arr2<T>& ra_y,
-                    const Arr2<T>* mfx, const Arr2<T>* mfy, const Arr2<T>* mass, int nord, double damp_c, int nord_pert, double damp_c_pert) {
-  if (hord == hord_pert) { fv_tp_2d<T>(q, crx, cry, hord, fx, fy, xfx, yfx, g, bd, ra_x, ra_y, mfx, mfy, mass, nord, damp_c); return; }
+                    const Arr2<T>* mfx, const Arr2<T>* mfy, const Arr2<T>* mass, int nord, double damp_c, int nord_pert, double damp_c_pert,
+                    bool split_damp = false) {      // split_damp: the two-call branch whatever the schemes (sw_core_tlm.F90:1664, :1787)
+  if (hord == hord_pert && !split_damp) { fv_tp_2d<T>(q, crx, cry, hord, fx, fy, xfx, yfx, g, bd, ra_x, ra_y, mfx, mfy, mass, nord, damp_c); return; }
   fv_tp_2d<T>(q, crx, cry, hord_pert, fx, fy, xfx, yfx, g, bd, ra_x, ra_y, mfx, mfy, mass, nord_pert, damp_c_pert);
   const Arr2<double> qd = values_of(q), cxd = values_of(crx), cyd = values_of(cry), xd = values_of(xfx), yd = values_of(yfx), rxd = values_of(ra_x), ryd = values_of(ra_y);
   Arr2<double> mxd, myd, msd, fxd(bd), fyd(bd);

@@ -38,8 +38,8 @@ class Oracle:
         arrs = [np.ascontiguousarray(metrics[n][0], dtype=np.float64) for n in names]
         mp = (_dp * len(arrs))(*[_ptr(a) for a in arrs])
         il = opt.int_list()
-        # orc_create iopt: 28 scheme ints + kord_tm, kord_mt, kord_wz, kord_tr + the four kord_*_pert
-        iopt = (C.c_int * 36)(*il[:36])
+        # orc_create iopt: 28 scheme ints + kord_tm, kord_mt, kord_wz, kord_tr + the four kord_*_pert + split_damp
+        iopt = (C.c_int * 37)(*(il[:36] + [opt.split_damp]))
         rl = opt.real_list()
         ropt = (C.c_double * 29)(*(rl + [da_min, da_min_c]))
         assert len(rl) == 27
