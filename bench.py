@@ -23,7 +23,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
 
@@ -99,6 +98,64 @@ def cpu_baseline(args, opt):
                                                               t_ad / max(t_tl, 1e-9), t_ad, wall)}
 
 
+def host_emulation_library():
+    """The product's stage code compiled for the host (tests/_emul/, built by __graft_entry__.build(); -O3 with AVX2 + FMA where the host has
+    them, else the tests' -O2 build)."""
+    flags = ""
+    try:
+        flags = [l for l in open("/proc/cpuinfo") if l.startswith("flags")][0]
+    except Exception:
+        pass
+    fast = os.path.join(ROOT, "tests", "_emul", "libfv3lm_emul_o3.so")
+    if os.path.exists(fast) and " avx2" in flags and " fma" in flags:
+        return fast, "-O3 -mavx2 -mfma"
+    slow = os.path.join(ROOT, "tests", "_emul", "libfv3lm_emul.so")
+    return (slow, "-O2") if os.path.exists(slow) else (None, "")
+
+
+def cpu_baseline_emul(args):
+    """Second CPU comparator: the product's own algorithm with its hand-written adjoints on the host cores -- P single-core
+    workers at once, each one 32 x 32-column tile of the workload's depth (1.5 MB per field, ~150 fields live per acoustic step: out of the core's caches), step_tl + step_nl +
+    step_ad like the timed region.  Trajectory slots as memory allows (a worker with all of them recomputes nothing in its backward
+    sweep, like the reference's tape)."""
+    import subprocess
+    so, how = host_emulation_library()
+    if so is None:
+        return None
+    P = os.cpu_count() or 1
+    if hasattr(os, "sched_getaffinity"):
+        P = min(P, len(os.sched_getaffinity(0)))
+    P = min(P, 16)
+    nx = 32
+    per_field = (nx + 7) * (nx + 7) * args.npz * 8 / 2.0 ** 30
+    base_gb, slot_gb = 420 * per_field, 125 * per_field        # arenas (trajectory + perturbation sides) / one trajectory slot, generously
+    try:
+        avail_gb = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] / 1048576.0
+    except Exception:
+        avail_gb = 32.0
+    P = max(1, min(P, int(0.8 * avail_gb / (base_gb + 2 * slot_gb))))
+    slots = max(0, min(args.n_split * args.k_split, int((0.8 * avail_gb / P - base_gb) / slot_gb)))
+    env = dict(os.environ); env["HIP_VISIBLE_DEVICES"] = ""; env["OMP_NUM_THREADS"] = "1"; env["FV3LM_TRAJ_SLOTS"] = str(slots)
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_emul_worker.py"), so, str(nx), str(args.npz), str(args.n_split), str(args.k_split), str(args.nq),
+           str(args.dt), "1" if args.nonhydrostatic else "0"]
+    t0 = time.time()
+    procs = [subprocess.Popen(cmd + [str(20250114 + w)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True) for w in range(P)]
+    res = []
+    for p in procs:
+        out, err = p.communicate(timeout=1500)
+        if p.returncode != 0:
+            raise RuntimeError("host-emulation worker failed: " + err[-400:])
+        res.append(json.loads(out.strip().splitlines()[-1]))
+    wall = time.time() - t0
+    tt = {k: max(r[k] for r in res) for k in ("t_tl", "t_nl", "t_ad")}
+    cols = sum(r["columns"] for r in res)
+    return {"value": cols / (tt["t_tl"] + tt["t_nl"] + tt["t_ad"]), "unit": "column-updates/s", "cores": P, "kind": "product host-emulation, hand-written adjoints",
+            "sample": "the product's stage code built for the host (g++ %s -DFV3LM_HOST_EMUL, single-threaded loops), %d single-core workers at once, each one %dx%d-column "
+                      "periodic tile, L%d, k_split=%d n_split=%d nq=%d, %d of %d trajectory slots: slowest worker step_tl %.1f s + step_nl %.1f s + step_ad %.1f s; wall %.0f s "
+                      "incl. start-up.  The reference Fortran is unbuildable here (FMS)" % (how, P, nx, nx, args.npz, args.k_split, args.n_split, args.nq, slots,
+                                                                                           args.n_split * args.k_split, tt["t_tl"], tt["t_nl"], tt["t_ad"], wall)}
+
+
 def scheme_string(o, nh):
     """the scheme flags actually in force (fv3lm_options of the instance that was timed)"""
     sponge = ("%d/%d/%d/%d below level %d" % (o.hord_mt_ks_pert, o.hord_vt_ks_pert, o.hord_tm_ks_pert, o.hord_dp_ks_pert, o.n_sponge_pert)) if o.hord_ks_pert else "off"
@@ -107,6 +164,8 @@ def scheme_string(o, nh):
         s += ", split_hord: trajectory %d/%d/%d/%d/%d" % (o.hord_mt, o.hord_vt, o.hord_tm, o.hord_dp, o.hord_tr)
     if abs(o.kord_tm) != abs(o.kord_tm_pert):
         s = s.replace("kord=%d" % abs(o.kord_tm), "kord=%d (split_kord: trajectory %d)" % (abs(o.kord_tm_pert), abs(o.kord_tm)))
+    if o.split_damp:
+        s += ", split_damp: trajectory nord=%d dddmp=%g d4_bg=%g / perturbation nord=%d dddmp=%g d4_bg=%g" % (o.nord, o.dddmp, o.d4_bg, o.nord_pert, o.dddmp_pert, o.d4_bg_pert)
     if nh:
         s += ", a_imp=%g (%s)" % (o.a_imp, "SIM1" if o.a_imp > 0.999 else "SIM")
     return s
@@ -129,12 +188,32 @@ def main():
     ap.add_argument("--hord-traj", type=int, default=0,
                     help="trajectory advection scheme (8 or 10) with the perturbation schemes left at their defaults: split_hord (not the headline configuration)")
     ap.add_argument("--kord-traj", type=int, default=0, help="trajectory remap profile (9, 10 or 11) with the linear perturbation profile: split_kord, hydrostatic only")
+    ap.add_argument("--nord-traj", type=int, default=0, help="trajectory divergence-damping order (2 or 3) beside nord_pert = 1: split_damp (not the headline configuration)")
+    ap.add_argument("--split-damp", action="store_true", help="split_damp = .true. (the reference's default) with equal namelist values: the perturbation sponge rules differ")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-host-transport", action="store_true",
                     help="multi-rank rehearsal on ONE GPU (RCCL refuses two ranks per device): gloo process group, halo messages staged "
                          "through host memory by a transport callback; exercises everything but the RCCL send/recv calls themselves")
     ap.add_argument("--profile-out", default="")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process starts N fresh children, one rank per GPU, before anything here has
+        # touched the GPU (no torch import, no HIP call), hands them the torch.distributed environment and passes rank 0's line through.
+        import socket
+        import subprocess
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+        procs = []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+        out0, _ = procs[0].communicate()
+        rcs = [procs[0].returncode] + [p_.wait() for p_ in procs[1:]]
+        sys.stdout.write(out0)
+        sys.exit(max(abs(rc) for rc in rcs))
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -151,8 +230,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     import ctypes as C
     import fv3_jedi_linearmodel_amd as fv3
-    from common import Case, CubeCase
-    from groups import step_state, cube_step_state
+    from fv3_jedi_linearmodel_amd.harness import Case, CubeCase, step_state, cube_step_state, cube_nh_state
     lib = fv3.load_hip_library()
     lib.L.fv3lm_set_device(C.c_int(local))
     cube_mode = args.tiles == "cube"
@@ -206,14 +284,17 @@ def main():
             nhkw = dict(hydrostatic=0) if args.nonhydrostatic else {}
             if args.kord_traj:
                 nhkw.update(kord_tm=-args.kord_traj, kord_mt=args.kord_traj, kord_tr=args.kord_traj)
+            if args.nord_traj:
+                nhkw.update(split_damp=1, nord=args.nord_traj)
+            if args.split_damp:
+                nhkw.update(split_damp=1)
             if args.hord_traj:
                 nhkw.update(hord_mt=args.hord_traj, hord_vt=args.hord_traj, hord_tm=args.hord_traj, hord_dp=args.hord_traj, hord_tr=args.hord_traj)
             c = CubeCase(n=args.nx, npz=args.npz, n_split=args.n_split, k_split=args.k_split, dt=args.dt, backend="hip", nq=args.nq,
                          rank=rank, world=world, **nhkw)
             T, P = cube_step_state(c)
             if args.nonhydrostatic:
-                import nh_checks
-                Tn, Pn = nh_checks.cube_nh_state(c)
+                Tn, Pn = cube_nh_state(c)
                 T.update(w=Tn[4], delz=Tn[5]); P.update(w=Pn[4], delz=Pn[5])
     else:
         c = Case(nx=args.nx, ny=args.nx, npz=args.npz, n_split=args.n_split, k_split=args.k_split, dt=args.dt, backend="hip",
@@ -307,6 +388,13 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args, c.opt)
             except Exception as e:   # the baseline leg must never hide the measurement
                 out["cpu_baseline"] = {"value": None, "unit": "column-updates/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+            try:
+                if not args.nonhydrostatic:
+                    em = cpu_baseline_emul(args)
+                    if em is not None:
+                        out["cpu_baseline"]["host_emulation"] = em
+            except Exception as e:
+                out["cpu_baseline"]["host_emulation"] = {"value": None, "sample": "failed: %r" % (e,)}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

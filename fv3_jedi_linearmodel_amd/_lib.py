@@ -212,6 +212,10 @@ class Dycore:
     # ---- the host's boundary copies on the device (compact arrays [ntile, nk, ny, nx], no halo) ----
     def _cptrs(self, d, names, out=False):
         keep = []
+        required = ["u", "v", "pt", "delp"] + ["q%d" % (m + 1) for m in range(self.dims.nq)] + ([] if self.options.hydrostatic else ["w", "delz"])
+        missing = [n for n in required if n not in d or d[n] is None]
+        if missing:
+            raise Fv3LmError("boundary copy: missing array(s) %s" % ", ".join(missing))
         def one(n):
             if n not in d or d[n] is None:
                 return None

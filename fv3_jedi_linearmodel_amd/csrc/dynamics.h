@@ -172,11 +172,16 @@ struct Dynamics : Dycore {
   void tracer_ad();
   void fv_dynamics(int mode);
   // non-hydrostatic: pe, peln, pk come out of the last acoustic step and pkz from the equation of state; nothing to prepare
-  void step_tl() { if (!nh) pressures(MODE_TL); fv_dynamics(MODE_TL); }
+  // "Edge of pert always needs to be filled" (DYN/fv3jedi_lm_dynamics_mod.F90:386-399): the perturbation's D-grid edge rows up(:, jec+1),
+  // vp(iec+1, :) come from the neighbour faces (mpp_get_boundary) before compute_fv3_pressures_tlm / FV_DYNAMICS_TLM; the adjoint of that
+  // fill (mpp_get_boundary_ad, :651-665) follows FV_DYNAMICS_BWD and compute_fv3_pressures_bwd.  Both belong to the operator whatever way
+  // the host moved its arrays in (pert_to_fv3 zeroes those rows, :848-849); the forward fill is idempotent, the adjoint one clears the rows
+  // it has moved, so a host that repeats either changes nothing.
+  void step_tl() { halo(MODE_TL, H_DEDGE, f("u"), f("v")); if (!nh) pressures(MODE_TL); fv_dynamics(MODE_TL); }
   void step_nl() { if (!nh) pressures(MODE_NL); fv_dynamics(MODE_NL); }
   // after step_nl() has stored the checkpoints.  The backward sweep leaves the initial delp trajectory
   // in place (first acoustic checkpoint), from which the initial pressures are recomputed.
-  void step_ad() { fv_dynamics(MODE_AD); if (!nh) { pressures(MODE_NL); pressures(MODE_AD); } }
+  void step_ad() { fv_dynamics(MODE_AD); if (!nh) { pressures(MODE_NL); pressures(MODE_AD); } halo(MODE_AD, H_DEDGE, f("u"), f("v")); }
 
   double* ckq(int km, int n) { return ck_k + (size_t)km * ck_k_stride + (size_t)n * n3; }                       // q before tracer
   double* ckm(int km, int n) { return ck_k + (size_t)km * ck_k_stride + (size_t)(nq + n) * n3; }                // mfx mfy cx cy
@@ -237,8 +242,9 @@ inline void Dynamics::destroy2() {
 inline bool Dynamics::traj_to_fv3(const double* u, const double* v, const double* t, const double* delp, const double* const* qs, const double* w,
                                   const double* delz, const double* phis) {
   if (!u || !v || !t || !delp || (nq > 0 && !qs) || (nh && (!w || !delz))) { err = "traj_to_fv3: null array"; return false; }
+  for (int n = 0; n < nq; ++n) if (!qs[n]) { err = "traj_to_fv3: null tracer array"; return false; }      // before anything is touched
   compact_in(f("u"), 0, u); compact_in(f("v"), 0, v); compact_in(f("pt"), 0, t); compact_in(f("delp"), 0, delp);
-  for (int n = 0; n < nq; ++n) { if (!qs[n]) { err = "traj_to_fv3: null tracer array"; return false; } compact_in(q[n], 0, qs[n]); }
+  for (int n = 0; n < nq; ++n) compact_in(q[n], 0, qs[n]);
   if (nh) { compact_in(f("w"), 0, w); compact_in(f("delz"), 0, delz); }
   halo(MODE_NL, H_DEDGE, f("u"), f("v"));
   if (phis) { Fld hs; hs.t = hs_dev; hs.p = nullptr; hs.nk = 1; compact_in(hs, 0, phis); halo(MODE_NL, H_CELL, hs); }
@@ -249,6 +255,7 @@ inline bool Dynamics::traj_to_fv3(const double* u, const double* v, const double
 inline bool Dynamics::pert_to_fv3(const double* u, const double* v, const double* t, const double* delp, const double* const* qs, const double* w,
                                   const double* delz) {
   if (!u || !v || !t || !delp || (nq > 0 && !qs) || (nh && (!w || !delz))) { err = "pert_to_fv3: null array"; return false; }
+  for (int n = 0; n < nq; ++n) if (!qs[n]) { err = "pert_to_fv3: null tracer array"; return false; }
   compact_in(f("u"), 1, u); compact_in(f("v"), 1, v); compact_in(f("pt"), 1, t); compact_in(f("delp"), 1, delp);
   for (int n = 0; n < nq; ++n) compact_in(q[n], 1, qs[n]);
   if (nh) { compact_in(f("w"), 1, w); compact_in(f("delz"), 1, delz); }
@@ -257,6 +264,7 @@ inline bool Dynamics::pert_to_fv3(const double* u, const double* v, const double
 // fv3_to_pert (:893-933): compute-domain values back to the host; the device perturbation is cleared as the reference clears FV_AtmP
 inline bool Dynamics::fv3_to_pert(double* u, double* v, double* t, double* delp, double* const* qs, double* w, double* delz) {
   if (!u || !v || !t || !delp || (nq > 0 && !qs) || (nh && (!w || !delz))) { err = "fv3_to_pert: null array"; return false; }
+  for (int n = 0; n < nq; ++n) if (!qs[n]) { err = "fv3_to_pert: null tracer array"; return false; }
   compact_out(f("u"), 1, u); compact_out(f("v"), 1, v); compact_out(f("pt"), 1, t); compact_out(f("delp"), 1, delp);
   for (int n = 0; n < nq; ++n) compact_out(q[n], 1, qs[n]);
   if (nh) { compact_out(f("w"), 1, w); compact_out(f("delz"), 1, delz); }

@@ -12,6 +12,7 @@ struct fv3lm_handle { Dynamics d; };
 
 static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return 1; }
+static int g_live = 0;      // handles alive in this process (one per GPU / MPI rank in production; tests create several)
 
 extern "C" {
 
@@ -31,25 +32,34 @@ int fv3lm_create(fv3lm_handle** out, const fv3lm_dims* dm, const fv3lm_options* 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail("fv3lm_create: no HIP device visible (this library has no CPU fallback)");
 #endif
-  sticky_error().clear();
+  // The failure record is per process (exec.h sticky_error): a fault of a LIVE handle that no call has reported yet must not be erased by
+  // the creation of another one -- that create fails with it instead; with no handle alive there is nobody left to report it to.
+  if (!sticky_error().empty()) {
+    if (g_live > 0) return fail("fv3lm_create: an earlier failure of a live handle is pending: " + sticky_error());
+    sticky_error().clear();
+  }
   fv3lm_handle* h = new fv3lm_handle;
-  // every failure path releases what was allocated so far (destroy2 / destroy accept a partly built object)
-  auto bail = [&](std::string e) { h->d.destroy2(); h->d.destroy(); delete h; return fail("fv3lm_create: " + e); };   // e by value: it may live in *h
+  // every failure path releases what was allocated so far (destroy2 / destroy accept a partly built object); the failure is reported here, once
+  auto bail = [&](std::string e) { h->d.destroy2(); h->d.destroy(); delete h; sticky_error().clear(); return fail("fv3lm_create: " + e); };   // e by value: it may live in *h
   if (!h->d.init(dm->nx, dm->ny, dm->npz, dm->ntile, dm->face, dm->nq, dm->dt, dm->n_split, dm->k_split, *opt, metrics, da_min,
                  da_min_c, phis)) return bail(h->d.err);
   if (!sticky_error().empty()) return bail(sticky_error());
   if (!h->d.init2(ak, bk)) return bail(h->d.err);
   if (!sticky_error().empty()) return bail(sticky_error());
   *out = h;
+  ++g_live;
   return 0;
 }
 
 int fv3lm_destroy(fv3lm_handle* h) {
   if (!h) return 0;
-  h->d.destroy2(); h->d.destroy(); delete h; return 0;
+  h->d.destroy2(); h->d.destroy(); delete h;
+  if (--g_live <= 0) { g_live = 0; sticky_error().clear(); }      // the last handle takes its unreported failures with it
+  return 0;
 }
 
 static bool find(fv3lm_handle* h, const char* name, Fld& f) {
+  if (std::string(name) == "phis") { f = Fld{}; f.t = h->d.hs_dev; f.p = h->d.hs_dev; f.nk = 1; return true; }      // surface geopotential, one padded plane per tile (trajectory only)
   auto it = h->d.F.find(name);
   if (it == h->d.F.end()) { g_err = std::string("unknown field ") + name; return false; }
   f = it->second; return true;

@@ -317,23 +317,7 @@ def check_remap(c, mode, last_step, tol):
         assert e < tol, (n, "ad", e)
 
 
-def step_state(c):
-    """Temperature-based state as the L2 driver hands it over (pt = T), plus numpy pressures."""
-    pe, peln, pk, pkz = np_pressures(c, c.traj["delp"][0])
-    qv = c.qtraj[0][0] if c.nq else 0.0
-    Tt = c.traj["pt"][0] * pkz / (1.0 + c.opt.zvir * qv)
-    T = dict(u=c.traj["u"][0], v=c.traj["v"][0], pt=Tt, delp=c.traj["delp"][0], pe=pe, peln=peln, pk=pk, pkz=pkz)
-    P = dict(u=c.pert["u"][0], v=c.pert["v"][0], pt=20.0 * c.pert["pt"][0], delp=c.pert["delp"][0])
-    # TL of the pressures by finite... no: exact linearisation in numpy
-    k = c.opt.akap
-    pe_p = np.concatenate([np.zeros_like(P["delp"][:1]), np.cumsum(P["delp"], axis=0)], axis=0)
-    peln_p = pe_p / pe; pk_p = k * peln_p * pk
-    den = k * (peln[1:] - peln[:-1])
-    pkz_p = ((pk_p[1:] - pk_p[:-1]) * den - (pk[1:] - pk[:-1]) * k * (peln_p[1:] - peln_p[:-1])) / den ** 2
-    P.update(pe=pe_p, peln=peln_p, pk=pk_p, pkz=pkz_p)
-    for n in range(c.nq):
-        T["q%d" % (n + 1)], P["q%d" % (n + 1)] = c.qtraj[n][0], c.qpert[n][0]
-    return T, P
+from fv3_jedi_linearmodel_amd.harness import step_state, cube_step_state      # noqa: E402,F401  (the package's own state builders)
 
 
 def check_fv_dynamics(c, mode, tol):
@@ -457,26 +441,6 @@ def cube_dot_product(c, seed=3):
     c.dy.dyn_core(AD)
     rhs = sum(float(np.sum(c.dy.get(n, 1) * c.pert[n])) for n in ins)
     return lhs, rhs
-
-
-def cube_step_state(c):
-    """as step_state, six faces"""
-    k = c.opt.akap
-    delp = c.traj["delp"]
-    pe = np.concatenate([np.full_like(delp[:, :1], c.opt.ptop), c.opt.ptop + np.cumsum(delp, axis=1)], axis=1)
-    peln = np.log(pe); pk = np.exp(k * peln)
-    pkz = (pk[:, 1:] - pk[:, :-1]) / (k * (peln[:, 1:] - peln[:, :-1]))
-    qv = c.qtraj[0] if c.nq else 0.0
-    T = dict(u=c.traj["u"], v=c.traj["v"], pt=c.traj["pt"] * pkz / (1.0 + c.opt.zvir * qv), delp=delp, pe=pe, peln=peln, pk=pk, pkz=pkz)
-    P = dict(u=c.pert["u"], v=c.pert["v"], pt=20.0 * c.pert["pt"], delp=c.pert["delp"])
-    pe_p = np.concatenate([np.zeros_like(delp[:, :1]), np.cumsum(P["delp"], axis=1)], axis=1)
-    peln_p = pe_p / pe; pk_p = k * peln_p * pk
-    den = k * (peln[:, 1:] - peln[:, :-1])
-    pkz_p = ((pk_p[:, 1:] - pk_p[:, :-1]) * den - (pk[:, 1:] - pk[:, :-1]) * k * (peln_p[:, 1:] - peln_p[:, :-1])) / den ** 2
-    P.update(pe=pe_p, peln=peln_p, pk=pk_p, pkz=pkz_p)
-    for n in range(c.nq):
-        T["q%d" % (n + 1)], P["q%d" % (n + 1)] = c.qtraj[n], c.qpert[n]
-    return T, P
 
 
 def cube_check_fv_dynamics(c, mode, tol):

@@ -151,20 +151,7 @@ def check_nh_fv_dot_product(c, tol=1e-11):
 
 
 # ---- six faces (tests/common.py CubeCase, oracle/nh.hpp fv_dynamics_nh_cube)
-def cube_nh_state(c):
-    from groups import cube_step_state
-    from fv3_jedi_linearmodel_amd import cube
-    T0, P0 = cube_step_state(c)
-    o = c.opt
-    qv = c.qtraj[0] if c.nq else 0.0
-    delz = -(o.rdgas / o.grav) * T0["pt"] * (1.0 + o.zvir * qv) * np.diff(T0["peln"], axis=1)
-    aux = cube.cube_fields(c.n, c.npz, c.geo, 20250135, "pert")
-    aux2 = cube.cube_fields(c.n, c.npz, c.geo, 20250136, "pert")
-    w = 0.05 * aux["pt"]; w_p = 0.01 * aux2["pt"]; dz_p = 1e-3 * aux2["delp"]
-    names = ["u", "v", "pt", "delp"]
-    T = [T0[n] for n in names] + [w, delz] + [T0["q%d" % (n + 1)] for n in range(c.nq)]
-    P = [P0[n] for n in names] + [w_p, dz_p] + [P0["q%d" % (n + 1)] for n in range(c.nq)]
-    return T, P
+from fv3_jedi_linearmodel_amd.harness import cube_nh_state      # noqa: E402,F401
 
 
 def cube_put(c, T, P=None):

@@ -9,3 +9,8 @@ def test_boundary_copies_periodic_tile():
 
 def test_boundary_copies_six_faces():
     check_boundary_copies(CubeCase(n=8, npz=6, n_split=2, k_split=2, backend="emul", nq=2), cube=True)
+
+
+def test_boundary_copies_against_the_numpy_oracle():
+    from boundary_checks import check_boundary_oracle
+    check_boundary_oracle(CubeCase(n=8, npz=6, n_split=2, k_split=2, backend="emul", nq=2))

@@ -266,6 +266,14 @@ def test_boundary_copies_on_the_device():
     check_boundary_copies(CubeCase(n=12, npz=8, n_split=2, k_split=2, backend="hip", nq=2), cube=True)
 
 
+def test_boundary_copies_against_the_numpy_oracle():
+    """... and against tests/boundary_oracle.py (DYN/fv3jedi_lm_dynamics_mod.F90:717-809, :386-399, :651-665, :846-933 in numpy, independent
+    exchange tables): traj_to_fv3 field by field, the perturbation edge fill of step_tl, its adjoint in step_ad"""
+    from common import CubeCase
+    from boundary_checks import check_boundary_oracle
+    check_boundary_oracle(CubeCase(n=12, npz=8, n_split=2, k_split=2, backend="hip", nq=2))
+
+
 def test_step_nl_matches_the_oracle(case_q):
     from groups import check_step_nl
     check_step_nl(case_q, 1e-11)
