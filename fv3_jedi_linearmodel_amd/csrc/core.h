@@ -32,6 +32,15 @@
 #define DEV __device__ inline
 #endif
 
+// The HIP build is split into translation units that hipcc compiles side by side (__graft_entry__.build(): -DFV3LM_SPLIT_BUILD; tu_*.cpp
+// each define one FV3LM_IMPL_* and hold that module's kernels): a module's launch functions are then ordinary external functions.  The
+// test-only host-emulation build is one translation unit and keeps them inline.
+#ifdef FV3LM_SPLIT_BUILD
+#define FV3LM_LINK
+#else
+#define FV3LM_LINK inline
+#endif
+
 namespace fv3 {
 
 // ------------------------------------------------------------------ scalars

@@ -15,6 +15,7 @@
 #include "nh.h"
 #include "nh_ad.h"
 #include "tpfused.h"
+#include "tpad.h"
 #include "dampt.h"
 #include <functional>
 #include <map>
@@ -401,10 +402,14 @@ struct Dycore {
     // The outer fluxes fxo, fyo are trajectory arrays of their own only while something reads them: the staged flux assembly.  With the
     // hand-written outer adjoint (which re-evaluates them from q_i, q_j in passing) they are neither stored by the nonlinear launch nor
     // part of a trajectory slot; the names then alias fx2 / fy2 for the staged ops that never run.
-    const char* aenv0 = std::getenv("FV3LM_TP_AD_FUSED");
-    const bool own_fo = !(fused && !(fenv && fenv[0] == '3') && !(aenv0 && aenv0[0] == '0'));
-    Fld fy2 = W((pre + "_fy2").c_str(), npz), q_i = W((pre + "_qi").c_str(), npz);
-    Fld fx2 = W((pre + "_fx2").c_str(), npz), q_j = W((pre + "_qj").c_str(), npz);
+    const char* aenv = std::getenv("FV3LM_TP_AD_FUSED");
+    const int adf = !fused ? 0 : aenv ? (aenv[0] == '0' ? 0 : aenv[0] == '1' ? 1 : 2) : 2;      // 2: the whole adjoint as one launch (tpad.h); 1: outer half only; 0: staged
+    const bool own_fo = adf == 0, own_mid = adf < 2;
+    // the inner fluxes and the intermediate fields are trajectory arrays of their own only while a staged adjoint launch reads them; the
+    // fused adjoint recomputes them in LDS, so neither the nonlinear launch stores them nor a trajectory slot holds them -- the names then
+    // alias fx / fy for the staged ops that never run
+    Fld fy2 = own_mid ? W((pre + "_fy2").c_str(), npz) : fy, q_i = own_mid ? W((pre + "_qi").c_str(), npz) : fx;
+    Fld fx2 = own_mid ? W((pre + "_fx2").c_str(), npz) : fx, q_j = own_mid ? W((pre + "_qj").c_str(), npz) : fy;
     Fld fxo = own_fo ? W((pre + "_fxo").c_str(), npz) : fx2, fyo = own_fo ? W((pre + "_fyo").c_str(), npz) : fy2;
     const size_t first_op = P.size();
     // the four 1-D PPM sweeps; on a face each is a bulk launch (4-point edge values everywhere) plus two strips three flux
@@ -461,7 +466,7 @@ struct Dycore {
     t.dsel = dsel; t.use_mass = use_mass; t.hsel = hsel;
     const size_t o3 = P.size();
     add(P, grp, t);
-    if (any_split && !(fused && !(fenv && fenv[0] == '3'))) set_sticky("split_hord needs the tiled fused fv_tp_2d (unset FV3LM_TP_FUSED)");
+    if (any_split && !fused) set_sticky("split_hord / split_damp need the fused fv_tp_2d (unset FV3LM_TP_FUSED)");
     if (fused) {
       size_t d2_op = P.size();      // the damping Laplacian (TpD2) stays a stage of its own in every mode
       for (size_t n = first_op; n < P.size(); ++n) if (P[n].name == "TpD2" || P[n].name == "TpD2e") d2_op = n;
@@ -471,12 +476,10 @@ struct Dycore {
       a.mass = use_mass ? mass : Fld{}; a.d2b = d2b; a.fx = fx; a.fy = fy;
       a.fy2 = fy2; a.q_i = q_i; a.fxo = fxo; a.fx2 = fx2; a.q_j = q_j; a.fyo = fyo;
       a.hsel = hsel; a.dsel = dsel; a.use_mass = use_mass ? 1 : 0; a.nk = npz;
-      a.do_acc = 0; a.store_fo = own_fo ? 1 : 0;
+      a.do_acc = 0; a.store_fo = own_fo ? 1 : 0; a.store_mid = own_mid ? 1 : 0;
       if (acc4) { a.acx = acc4[0]; a.acy = acc4[1]; a.amfx = acc4[2]; a.amfy = acc4[3]; }
       Ctx* cp = &ctx;
-      // default: the tiled form (tpfused.h, first half); FV3LM_TP_FUSED=3: the marching form (second half; measured slower, kept for reference)
-      const bool tiled = !(fenv && fenv[0] == '3');
-      Op op{grp, [a, cp, tiled](Exec& e, int mode) { if (tiled) run_tp_fused(e, mode, a, *cp); else run_tp_march(e, mode, a, *cp); }};
+      Op op{grp, [a, cp](Exec& e, int mode) { run_tp_fused(e, mode, a, *cp); }};
       op.modes = (1u << MODE_NL) | (1u << MODE_TL);
       op.name = "TpFused";
       // what the launch reads / writes (add_halo_async looks for the last op that touches a field; plan_adjoint skips this op: not an adjoint op)
@@ -509,12 +512,11 @@ struct Dycore {
         tr.modes = (1u << MODE_NL) | (1u << MODE_TL); tr.name = "TpFusedTraj";
         P.push_back(tr);
       }
-      // adjoint: flux assembly + the two outer sweeps as one hand-written launch (tpfused.h tp_outer_ad_block); their staged launches
-      // then never run, the damping part of the flux keeps a (small) stage of its own.  FV3LM_TP_AD_FUSED=0: all staged.
-      const char* aenv = std::getenv("FV3LM_TP_AD_FUSED");
-      if (!(aenv && aenv[0] == '0')) {
-        for (size_t n = o1a; n < o1b; ++n) P[n].modes = 0;
-        for (size_t n = o2a; n < o2b; ++n) P[n].modes = 0;
+      // adjoint: the whole routine as ONE hand-written launch (tpad.h); the staged launches then never run, the damping part of the flux keeps a
+      // (small) stage of its own.  FV3LM_TP_AD_FUSED=1: round 2's form (outer half fused, inner half staged); =0: all staged.
+      if (adf > 0) {
+        if (adf == 2) { for (size_t n = first_op; n < o3; ++n) if (!(P[n].name == "TpD2" || P[n].name == "TpD2e")) P[n].modes = 0; }
+        else { for (size_t n = o1a; n < o1b; ++n) P[n].modes = 0; for (size_t n = o2a; n < o2b; ++n) P[n].modes = 0; }
         P[o3].modes = 0;
         if (dsel != DAMP_NONE) {
           TpDamp dm; dm.in[0] = q; dm.in[1] = d2b; dm.in[2] = use_mass ? mass : Fld{};
@@ -523,11 +525,11 @@ struct Dycore {
           dm.dsel = dsel; dm.use_mass = use_mass; dm.hsel = hsel;
           add(P, grp, dm); P.back().modes = 1u << MODE_AD;
         }
-        Op ad{grp, [a, cp](Exec& e, int) { run_tp_outer_ad(e, a, *cp); }};
-        ad.modes = 1u << MODE_AD; ad.name = "TpOuter";
+        Op ad{grp, [a, cp, adf](Exec& e, int) { if (adf == 2) run_tp_ad(e, a, *cp); else run_tp_outer_ad(e, a, *cp); }};
+        ad.modes = 1u << MODE_AD; ad.name = adf == 2 ? "TpAd" : "TpOuter";
         ad.ad_out = {fx.p, fy.p}; ad.ad_out_rect = {R(is, ie + 1, js, je), R(is, ie, js, je + 1)};
-        ad.ad_store = {q_i.p, q_j.p, fx2.p, fy2.p};
-        ad.ad_in = {crx.p, cry.p, mx.p, my.p};
+        if (adf == 2) ad.ad_in = {q.p, crx.p, cry.p, xfx.p, yfx.p, rax.p, ray.p, mx.p, my.p};
+        else { ad.ad_store = {q_i.p, q_j.p, fx2.p, fy2.p}; ad.ad_in = {crx.p, cry.p, mx.p, my.p}; }
         P.push_back(ad);
       }
     }

@@ -1,0 +1,509 @@
+// fv3lm-hip: the ADJOINT of fv_tp_2d (FV_TP_2D_FWD / _BWD, tp_core_adm.F90:7026 / :7263; joint form FV_TP_2D_ADM :109) as ONE LDS-tiled
+// kernel -- flux assembly, the two outer sweeps, the two intermediate updates and the two inner sweeps, transposed in closed form.
+//
+// Round 2 ran it as one hand-written launch for the outer half (tp_outer_ad_block) + six staged gather launches, their strips and corner
+// launches for the inner half, with the adjoints of q_i, q_j, fx2, fy2 and the trajectory of the same four making round trips through
+// HBM.  Here a workgroup owns a 64 x 16 block of cells of one level and GATHERS everything that block owns:
+//
+//   values (as the forward kernel, recomputed, never stored):  q tile -> fy2 -> q_i          (branch A)        q tile -> fx2 -> q_j   (branch B)
+//   A: fxo_ad = fx2_ad' = 0.5 mx fx_ad                      q_i_ad(k)  = sum_m dfxo(m)/dq_i(k) fxo_ad(m)       gi = q_i_ad / ra_y
+//      fy2_ad(m) = 0.5 my fy_ad(m) + yfx(m) (gi(m) - gi(m-1))                 q_ad(k) += area gi(k) + sum_m dfy2(m)/dq(k) fy2_ad(m)
+//      crx_ad += dfxo/dc fxo_ad      mx_ad += 0.5 fxo fx_ad     ra_y_ad -= q_i gi     yfx_ad += fy2 (gi(m) - gi(m-1))
+//      cry_ad += dfy2/dc fy2_ad      my_ad += 0.5 fy2 fy_ad
+//   B: the same with x and y exchanged.
+//
+// The schemes the adjoint is taken of (iord 1, 2, 333) are linear in q for given Courant numbers, so dflux/dq is the closed form ppm_dq
+// (stages.h; the four-cell cube-edge values included) and dflux/dc one ppm_flux<Dual> with only c seeded.  Every output element is
+// owned by exactly one thread: no atomics, fixed summation order.  The outputs ACCUMULATE (the launch never stores: plan_adjoint clears
+// what it touches first).  The damping part of the flux keeps its stage (stages.h TpDamp).
+//
+// Corner halo (cube faces): the inner sweeps read corner-halo cells through the copy_corners view of their direction, i.e. a source
+// cell next to a face corner is ALSO read as a virtual corner cell.  Those few extra contributions (9 source cells per corner and
+// direction) are added by a second, tiny launch that re-derives what it needs from the same global inputs (k_tp_ad_corner).
+#pragma once
+#include "tpfused.h"
+
+namespace fv3 {
+FV3LM_LINK void run_tp_ad(Exec& ex, const TpFusedArgs& a0, const Ctx& c);
+}
+
+#if !defined(FV3LM_SPLIT_BUILD) || defined(FV3LM_IMPL_TPAD)
+namespace fv3 {
+
+#ifndef FV3LM_TPD_H
+#define FV3LM_TPD_H 16
+#endif
+#ifndef FV3LM_TPD_THREADS
+#define FV3LM_TPD_THREADS 512
+#endif
+constexpr int TPD_W = 64, TPD_H = FV3LM_TPD_H;
+constexpr int TPD_QW = TPD_W + 6, TPD_QH = TPD_H + 6;        // halo'd tile
+constexpr int TPD_AW = TPD_W + 12, TPD_AH = TPD_H + 12;      // flux-adjoint tile: three more either side along the sweep
+constexpr int TPD_NQ = TPD_QW * TPD_QH;                      // q; q_i / q_j values, later gi / gj
+constexpr int TPD_NF2 = TPD_QW * (TPD_QH + 1);               // inner flux values, later (in place) their adjoints
+constexpr int TPD_NFA = (TPD_AW * TPD_QH > TPD_AH * TPD_QW ? TPD_AW * TPD_QH : TPD_AH * TPD_QW);    // outer-flux adjoint tile (either orientation)
+constexpr int TPD_NT = 2 * TPD_NQ + TPD_NF2 + 2 * TPD_NFA;   // 8,610 doubles = 69 KB: two blocks per CU
+constexpr int TPD_THREADS = FV3LM_TPD_THREADS;
+
+// Transposed 1-D sweep in two stages.  flux(m) of iord 2 is  q_up c'(3 -+ 2c) + al(m) (1 -+ c)^2 -+ al(m -+ 1) c (1 -+ c)  (upper signs: c > 0,
+// upwind cell m-1; c' = |c|), al(x) = sum_e w_e(x) q(x-2+e): first the adjoint of the edge values al_ad(x) from the (at most three) fluxes
+// that read al(x), then q_ad(k) from the four edge values that read q(k) + the upwind terms.  The flux adjoints f come from LDS tiles that
+// hold zeros outside the range of the fluxes, the Courant numbers c are loaded by the caller (all of a thread's global loads first, then
+// the arithmetic: nothing here waits on memory).
+DEV double tps_al(double fm, double f0, double fp, double cm, double c0, double cp) {      // flux x-1, x, x+1
+  double s = (c0 > 0. ? (1. - c0) * (1. - c0) : (1. + c0) * (1. + c0)) * f0;
+  if (cp > 0.) s -= cp * (1. - cp) * fp;
+  if (!(cm > 0.)) s += cm * (1. + cm) * fm;
+  return s;
+}
+template <class D>
+DEV double tps_w(bool face, int x, int n1, const D& da, int k) {      // coefficient of q(k) in al(x) (stages.h ppm_al_coef; constants away from the cube edges)
+  const int e = k - x + 2;
+  if (e < 0 || e > 3) return 0.;
+  if (!face || (x >= 3 && x <= n1 - 2)) return (e == 0 || e == 3) ? P2 : P1;
+  double w[4]; ppm_w(face, x, n1, da, w);
+  return w[e];
+}
+// q_ad(k): f0, fp = adjoints of flux k, k+1; c0, cp their Courant numbers; al[0..3] = al_ad(k-1 .. k+2); fm2 .. fp2 (iord 333 only) fluxes k-1 .. k+2
+template <class D>
+DEV double tps_q(int iord, bool face, int k, int n1, double f0, double fp, double c0, double cp, const double* al, const D& da) {
+  double s = 0.;
+  if (cp > 0.) s += (iord == 1 ? 1. : cp * (3. - 2. * cp)) * fp;
+  if (!(c0 > 0.)) s += (iord == 1 ? 1. : -c0 * (3. + 2. * c0)) * f0;
+  if (iord == 1) return s;
+#pragma unroll
+  for (int n = 0; n < 4; ++n) if (al[n] != 0.) s += tps_w(face, k - 1 + n, n1, da, k) * al[n];
+  return s;
+}
+// iord 333 has no edge values: three cells per flux (stages.h ppm_dq), fluxes k-1 .. k+2
+template <class D>
+DEV double tps_q333(bool face, int k, int n1, const double* f, const double* cc, const D& da) {
+  double s = 0.;
+#pragma unroll
+  for (int n = 0; n < 4; ++n) { const int m = k - 1 + n; if (m >= 1 && m <= n1 && f[n] != 0.) s += ppm_dq(333, face, m, n1, k, da, cc[n]) * f[n]; }
+  return s;
+}
+
+// One block: cells I0..I1 x J0..J1 of level k of one tile (+ the halo cells next to them in the first / last block row and column).
+template <int NTH>
+DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx, int by, double* lds, int tid, int nth) {
+  (void)nth;
+  const Geom& g = c.g;
+  const int nx = g.nx, ny = g.ny;
+  const bool face = g.face != 0;
+  const int I0 = 1 + bx * TPD_W, I1 = (I0 + TPD_W - 1 < nx) ? I0 + TPD_W - 1 : nx;
+  const int J0 = 1 + by * TPD_H, J1 = (J0 + TPD_H - 1 < ny) ? J0 + TPD_H - 1 : ny;
+  const bool firstx = bx == 0, lastx = I1 == nx, firsty = by == 0, lasty = J1 == ny;
+  const int GI0 = firstx ? I0 - 3 : I0, GI1 = lastx ? I1 + 3 : I1, GJ0 = firsty ? J0 - 3 : J0, GJ1 = lasty ? J1 + 3 : J1;     // owned cells incl. the halo
+  const size_t base = (size_t)(tile * a.nk + k - 1) * g.plane;
+  auto at = [&](int i, int j) -> size_t { return base + g.idx(i, j); };
+  const int iord = hord_of(c.lev[k - 1], a.hsel);
+  double* Q = lds;                       // q values                          (I0-3 .. I1+3) x (J0-3 .. J1+3)
+  double* QG = lds + TPD_NQ;             // q_i / q_j values, then gi / gj    same
+  double* F2 = lds + 2 * TPD_NQ;         // inner flux values, then their adjoints in place
+  double* FA = F2 + TPD_NF2;             // outer-flux adjoint 0.5 m f_ad, three more cells either side along the sweep
+  double* AL = FA + TPD_NFA;             // adjoint of the edge values of the sweep being transposed
+  auto qe = [&](int i, int j) { return (j - (J0 - 3)) * TPD_QW + (i - (I0 - 3)); };
+  auto corner_cell = [&](int i, int j) { return face && (i < 1 || i > nx) && (j < 1 || j > ny); };
+  // q_ad of the owned cells: area term kept by the thread that also finishes the cell (same element loop in both phases)
+  constexpr int EQ = (TPD_NQ + NTH - 1) / NTH;
+  double qacc[EQ];
+
+  { constexpr int n = TPD_NQ;
+    TPF_LOOP(e, n) { const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW; Q[e] = (i <= I1 + 3 && j <= J1 + 3) ? a.q.t[at(i, j)] : 0.; } }
+  TPF_SYNC();
+
+  // ============================== branch A: outer sweep in x, inner sweep in y ==============================
+  {
+    auto f2e = [&](int i, int j) { return (j - (J0 - 2)) * TPD_QW + (i - (I0 - 3)); };          // rows J0-2 .. J1+3
+    auto fae = [&](int i, int j) { return (j - (J0 - 3)) * TPD_AW + (i - (I0 - 6)); };          // columns I0-6 .. I1+6, rows J0-3 .. J1+3
+    auto ale = [&](int i, int j) { return (j - (J0 - 5)) * TPD_QW + (i - (I0 - 3)); };          // inner sweep: rows J0-5 .. J1+6
+    { constexpr int n = TPD_AW * TPD_QH;
+      TPF_LOOP(e, n) {
+        const int i = I0 - 6 + e % TPD_AW, j = J0 - 3 + e / TPD_AW;
+        FA[e] = (i >= 1 && i <= nx + 1 && j >= 1 && j <= ny && i <= I1 + 6 && j <= J1 + 3) ? 0.5 * a.mx.t[at(i, j)] * a.fx.p[at(i, j)] : 0.;
+      } }
+    { constexpr int n = TPD_QW * (TPD_H + 1);       // inner flux values fy2 on rows J0 .. J1+1
+      TPF_LOOP(e, n) {
+        const int i = I0 - 3 + e % TPD_QW, j = J0 + e / TPD_QW;
+        if (i > I1 + 3 || j > J1 + 1) continue;
+        auto line = [&](int jj) -> double { int ii = i, j2 = jj; if (face) corner_map(g, 2, ii, j2); return Q[qe(ii, j2)]; };
+        const MetY da{c.m.dya, c, tile, i};
+        F2[f2e(i, j)] = ppm_flux<double>(iord, face, j, ny + 1, line, da, a.cry.t[at(i, j)]);
+      } }
+    TPF_SYNC();
+    { constexpr int n = TPD_QW * TPD_H;             // q_i values
+      TPF_LOOP(e, n) {
+        const int i = I0 - 3 + e % TPD_QW, j = J0 + e / TPD_QW;
+        if (i > I1 + 3 || j > J1) continue;
+        QG[qe(i, j)] = (Q[qe(i, j)] * MET(area, i, j) + a.yfx.t[at(i, j)] * F2[f2e(i, j)] - a.yfx.t[at(i, j + 1)] * F2[f2e(i, j + 1)]) / a.ray.t[at(i, j)];
+      } }
+    TPF_SYNC();
+    auto FX = [&](int m, int j) { return FA[fae(m, j)]; };
+    { constexpr int w = TPD_W + 1, n = w * TPD_H;   // own x-faces: Courant-number and mass-flux adjoints of the outer sweep
+      TPF_LOOP(e, n) {
+        const int i = I0 + e % w, j = J0 + e / w;
+        if (j > J1 || !(i <= I1 || (lastx && i == I1 + 1))) continue;
+        const double fo = FX(i, j), fxad = a.fx.p[at(i, j)];
+        if (fo == 0. && fxad == 0.) continue;
+        auto line = [&](int ii) -> Dual { return Dual(QG[qe(ii, j)], 0.); };
+        const MetX da{c.m.dxa, c, tile, j};
+        const Dual fl = ppm_flux<Dual>(iord, face, i, nx + 1, line, da, Dual(a.crx.t[at(i, j)], 1.));
+        a.crx.p[at(i, j)] += fl.d * fo;
+        a.mx.p[at(i, j)] += 0.5 * fl.v * fxad;
+      } }
+    auto cl = [](int m, int n1) { return m < 1 ? 1 : (m > n1 ? n1 : m); };      // flux index clamped into its range (the flux adjoint is zero outside: the value does not matter, the address must exist)
+    if (iord == 2) {                                // edge-value adjoints of the outer sweep, columns I0-4 .. I1+5
+      constexpr int n = TPD_AW * TPD_QH;
+      TPF_LOOP(e, n) {
+        const int x = I0 - 6 + e % TPD_AW, j = J0 - 3 + e / TPD_AW;
+        double s = 0.;
+        if (x >= I0 - 4 && x <= I1 + 5 && j >= 1 && j <= ny && j <= J1 + 3) {
+          const double cm = a.crx.t[at(cl(x - 1, nx + 1), j)], c0 = a.crx.t[at(cl(x, nx + 1), j)], cp = a.crx.t[at(cl(x + 1, nx + 1), j)];
+          s = tps_al(FA[e - 1], FA[e], FA[e + 1], cm, c0, cp);
+        }
+        AL[e] = s;
+      } }
+    TPF_SYNC();
+    { constexpr int n = TPD_NQ;                     // gi = q_i_ad / ra_y on the owned columns; own cells: ra_y_ad, the area term of q_ad
+      TPF_LOOPU(e, u, n, EQ) {
+        const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW;
+        double s = 0., acc = 0.;
+        if (i >= GI0 && i <= GI1 && j >= 1 && j <= ny && j <= J1 + 3) {
+          const bool own = j >= J0 && j <= J1;
+          const double ry = a.ray.t[at(i, j)], ar = MET(area, i, j), rold = own ? a.ray.p[at(i, j)] : 0.;
+          const MetX da{c.m.dxa, c, tile, j};
+          const int b0 = fae(i, j);
+          if (iord == 333) {
+            const double f[4] = {FA[b0 - 1], FA[b0], FA[b0 + 1], FA[b0 + 2]};
+            const double cc[4] = {a.crx.t[at(cl(i - 1, nx + 1), j)], a.crx.t[at(cl(i, nx + 1), j)], a.crx.t[at(cl(i + 1, nx + 1), j)], a.crx.t[at(cl(i + 2, nx + 1), j)]};
+            s = tps_q333(face, i, nx + 1, f, cc, da);
+          } else {
+            const double c0 = a.crx.t[at(cl(i, nx + 1), j)], cp = a.crx.t[at(cl(i + 1, nx + 1), j)];
+            const double al[4] = {AL[b0 - 1], AL[b0], AL[b0 + 1], AL[b0 + 2]};
+            s = tps_q(iord, face, i, nx + 1, FA[b0], FA[b0 + 1], c0, cp, al, da);
+          }
+          s = s / ry;
+          if (own) { a.ray.p[at(i, j)] = rold - QG[e] * s; acc = ar * s; }
+        }
+        qacc[u] = acc;
+        QG[e] = s;
+      } }
+    TPF_SYNC();
+    { constexpr int n = TPD_QW * (TPD_QH - 1);      // fy2_ad on rows J0-2 .. J1+3 of the owned columns, in place of the values; own y-faces: yfx_ad, my_ad (inner part)
+      TPF_LOOP(e, n) {
+        const int i = I0 - 3 + e % TPD_QW, m = J0 - 2 + e / TPD_QW;
+        double s = 0.;
+        if (i >= GI0 && i <= GI1 && m >= 1 && m <= ny + 1 && m <= J1 + 3) {
+          const bool in = i >= 1 && i <= nx, own = m >= J0 && (m <= J1 || (lasty && m == J1 + 1));
+          const double yf = a.yfx.t[at(i, m)], fyad = in ? a.fy.p[at(i, m)] : 0., mm = in ? a.my.t[at(i, m)] : 0.;
+          const double dg = (m <= ny ? QG[qe(i, m)] : 0.) - (m >= 2 ? QG[qe(i, m - 1)] : 0.);
+          s = yf * dg + 0.5 * mm * fyad;
+          if (own) {          // yfx and my may be one array (the mass transport): two accumulates in program order
+            const double f2v = F2[e];
+            a.yfx.p[at(i, m)] += f2v * dg;
+            if (in) a.my.p[at(i, m)] += 0.5 * f2v * fyad;
+          }
+        }
+        F2[e] = s;
+      } }
+    TPF_SYNC();
+    auto FY2 = [&](int i, int m) { return (m >= J0 - 2 && m <= J1 + 3) ? F2[f2e(i, m)] : 0.; };
+    if (iord == 2) {                                // edge-value adjoints of the inner sweep, rows J0-4 .. J1+5 of the owned columns
+      constexpr int n = TPD_QW * TPD_AH;
+      TPF_LOOP(e, n) {
+        const int i = I0 - 3 + e % TPD_QW, x = J0 - 5 + e / TPD_QW;
+        double s = 0.;
+        if (i >= GI0 && i <= GI1 && x >= J0 - 4 && x <= J1 + 5) {
+          const double cm = a.cry.t[at(i, cl(x - 1, ny + 1))], c0 = a.cry.t[at(i, cl(x, ny + 1))], cp = a.cry.t[at(i, cl(x + 1, ny + 1))];
+          s = tps_al(FY2(i, x - 1), FY2(i, x), FY2(i, x + 1), cm, c0, cp);
+        }
+        AL[e] = s;
+      } }
+    TPF_SYNC();
+    { constexpr int n = TPD_NQ;                     // transposed inner sweep: q_ad of the owned cells
+      TPF_LOOPU(e, u, n, EQ) {
+        const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW;
+        const double acc = qacc[u];
+        if (i < GI0 || i > GI1 || j < GJ0 || j > GJ1 || corner_cell(i, j)) continue;
+        const double qold = a.q.p[at(i, j)];
+        const MetY da{c.m.dya, c, tile, i};
+        double s;
+        if (iord == 333) {
+          const double f[4] = {FY2(i, j - 1), FY2(i, j), FY2(i, j + 1), FY2(i, j + 2)};
+          const double cc[4] = {a.cry.t[at(i, cl(j - 1, ny + 1))], a.cry.t[at(i, cl(j, ny + 1))], a.cry.t[at(i, cl(j + 1, ny + 1))], a.cry.t[at(i, cl(j + 2, ny + 1))]};
+          s = tps_q333(face, j, ny + 1, f, cc, da);
+        } else {
+          const double c0 = a.cry.t[at(i, cl(j, ny + 1))], cp = a.cry.t[at(i, cl(j + 1, ny + 1))];
+          const int b0 = ale(i, j);
+          const double al[4] = {AL[b0 - TPD_QW], AL[b0], AL[b0 + TPD_QW], AL[b0 + 2 * TPD_QW]};
+          s = tps_q(iord, face, j, ny + 1, FY2(i, j), FY2(i, j + 1), c0, cp, al, da);
+        }
+        a.q.p[at(i, j)] = qold + (acc + s);
+      } }
+    { constexpr int n = TPD_QW * (TPD_H + 1);       // own y-faces: cry_ad of the inner sweep
+      TPF_LOOP(e, n) {
+        const int i = I0 - 3 + e % TPD_QW, m = J0 + e / TPD_QW;
+        if (i < GI0 || i > GI1 || !(m <= J1 || (lasty && m == J1 + 1))) continue;
+        const double f = F2[f2e(i, m)];
+        if (f == 0.) continue;
+        auto line = [&](int jj) -> Dual { int ii = i, j2 = jj; if (face) corner_map(g, 2, ii, j2); return Dual(Q[qe(ii, j2)], 0.); };
+        const MetY da{c.m.dya, c, tile, i};
+        a.cry.p[at(i, m)] += ppm_flux<Dual>(iord, face, m, ny + 1, line, da, Dual(a.cry.t[at(i, m)], 1.)).d * f;
+      } }
+    TPF_SYNC();
+  }
+
+  // ============================== branch B: outer sweep in y, inner sweep in x ==============================
+  {
+    auto f2e = [&](int i, int j) { return (j - (J0 - 3)) * (TPD_QW + 1) + (i - (I0 - 2)); };    // columns I0-2 .. I1+3 (pitch TPD_QW+1), rows J0-3 .. J1+3
+    auto fae = [&](int i, int j) { return (j - (J0 - 6)) * TPD_QW + (i - (I0 - 3)); };          // rows J0-6 .. J1+6, columns I0-3 .. I1+3
+    auto ale = [&](int i, int j) { return (j - (J0 - 3)) * TPD_AW + (i - (I0 - 5)); };          // inner sweep: columns I0-5 .. I1+6 (pitch TPD_AW)
+    { constexpr int n = TPD_QW * TPD_AH;
+      TPF_LOOP(e, n) {
+        const int i = I0 - 3 + e % TPD_QW, j = J0 - 6 + e / TPD_QW;
+        FA[e] = (j >= 1 && j <= ny + 1 && i >= 1 && i <= nx && j <= J1 + 6 && i <= I1 + 3) ? 0.5 * a.my.t[at(i, j)] * a.fy.p[at(i, j)] : 0.;
+      } }
+    { constexpr int w = TPD_W + 1, n = w * TPD_QH;  // inner flux values fx2 on columns I0 .. I1+1
+      TPF_LOOP(e, n) {
+        const int i = I0 + e % w, j = J0 - 3 + e / w;
+        if (i > I1 + 1 || j > J1 + 3) continue;
+        auto line = [&](int ii) -> double { int i2 = ii, jj = j; if (face) corner_map(g, 1, i2, jj); return Q[qe(i2, jj)]; };
+        const MetX da{c.m.dxa, c, tile, j};
+        F2[f2e(i, j)] = ppm_flux<double>(iord, face, i, nx + 1, line, da, a.crx.t[at(i, j)]);
+      } }
+    TPF_SYNC();
+    { constexpr int n = TPD_W * TPD_QH;             // q_j values
+      TPF_LOOP(e, n) {
+        const int i = I0 + e % TPD_W, j = J0 - 3 + e / TPD_W;
+        if (i > I1 || j > J1 + 3) continue;
+        QG[qe(i, j)] = (Q[qe(i, j)] * MET(area, i, j) + a.xfx.t[at(i, j)] * F2[f2e(i, j)] - a.xfx.t[at(i + 1, j)] * F2[f2e(i + 1, j)]) / a.rax.t[at(i, j)];
+      } }
+    TPF_SYNC();
+    auto FY = [&](int i, int m) { return FA[fae(i, m)]; };
+    { constexpr int n = TPD_W * (TPD_H + 1);        // own y-faces: Courant-number and mass-flux adjoints of the outer sweep
+      TPF_LOOP(e, n) {
+        const int i = I0 + e % TPD_W, j = J0 + e / TPD_W;
+        if (i > I1 || !(j <= J1 || (lasty && j == J1 + 1))) continue;
+        const double fo = FY(i, j), fyad = a.fy.p[at(i, j)];
+        if (fo == 0. && fyad == 0.) continue;
+        auto line = [&](int jj) -> Dual { return Dual(QG[qe(i, jj)], 0.); };
+        const MetY da{c.m.dya, c, tile, i};
+        const Dual fl = ppm_flux<Dual>(iord, face, j, ny + 1, line, da, Dual(a.cry.t[at(i, j)], 1.));
+        a.cry.p[at(i, j)] += fl.d * fo;
+        a.my.p[at(i, j)] += 0.5 * fl.v * fyad;
+      } }
+    auto cl = [](int m, int n1) { return m < 1 ? 1 : (m > n1 ? n1 : m); };
+    if (iord == 2) {                                // edge-value adjoints of the outer sweep, rows J0-4 .. J1+5
+      constexpr int n = TPD_QW * TPD_AH;
+      TPF_LOOP(e, n) {
+        const int i = I0 - 3 + e % TPD_QW, x = J0 - 6 + e / TPD_QW;
+        double s = 0.;
+        if (x >= J0 - 4 && x <= J1 + 5 && i >= 1 && i <= nx && i <= I1 + 3) {
+          const double cm = a.cry.t[at(i, cl(x - 1, ny + 1))], c0 = a.cry.t[at(i, cl(x, ny + 1))], cp = a.cry.t[at(i, cl(x + 1, ny + 1))];
+          s = tps_al(FA[e - TPD_QW], FA[e], FA[e + TPD_QW], cm, c0, cp);
+        }
+        AL[e] = s;
+      } }
+    TPF_SYNC();
+    { constexpr int n = TPD_NQ;                     // gj = q_j_ad / ra_x on the owned rows; own cells: ra_x_ad, the area term of q_ad
+      TPF_LOOPU(e, u, n, EQ) {
+        const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW;
+        double s = 0., acc = 0.;
+        if (j >= GJ0 && j <= GJ1 && i >= 1 && i <= nx && i <= I1 + 3) {
+          const bool own = i >= I0 && i <= I1;
+          const double rx = a.rax.t[at(i, j)], ar = MET(area, i, j), rold = own ? a.rax.p[at(i, j)] : 0.;
+          const MetY da{c.m.dya, c, tile, i};
+          const int b0 = fae(i, j);
+          if (iord == 333) {
+            const double f[4] = {FA[b0 - TPD_QW], FA[b0], FA[b0 + TPD_QW], FA[b0 + 2 * TPD_QW]};
+            const double cc[4] = {a.cry.t[at(i, cl(j - 1, ny + 1))], a.cry.t[at(i, cl(j, ny + 1))], a.cry.t[at(i, cl(j + 1, ny + 1))], a.cry.t[at(i, cl(j + 2, ny + 1))]};
+            s = tps_q333(face, j, ny + 1, f, cc, da);
+          } else {
+            const double c0 = a.cry.t[at(i, cl(j, ny + 1))], cp = a.cry.t[at(i, cl(j + 1, ny + 1))];
+            const double al[4] = {AL[b0 - TPD_QW], AL[b0], AL[b0 + TPD_QW], AL[b0 + 2 * TPD_QW]};
+            s = tps_q(iord, face, j, ny + 1, FA[b0], FA[b0 + TPD_QW], c0, cp, al, da);
+          }
+          s = s / rx;
+          if (own) { a.rax.p[at(i, j)] = rold - QG[e] * s; acc = ar * s; }
+        }
+        qacc[u] = acc;
+        QG[e] = s;
+      } }
+    TPF_SYNC();
+    { constexpr int w = TPD_QW - 1, n = w * TPD_QH; // fx2_ad on columns I0-2 .. I1+3 of the owned rows, in place of the values; own x-faces: xfx_ad, mx_ad (inner part)
+      TPF_LOOP(e, n) {
+        const int m = I0 - 2 + e % w, j = J0 - 3 + e / w;
+        double s = 0.;
+        if (j >= GJ0 && j <= GJ1 && m >= 1 && m <= nx + 1 && m <= I1 + 3) {
+          const bool in = j >= 1 && j <= ny, own = m >= I0 && (m <= I1 || (lastx && m == I1 + 1));
+          const double xf = a.xfx.t[at(m, j)], fxad = in ? a.fx.p[at(m, j)] : 0., mm = in ? a.mx.t[at(m, j)] : 0.;
+          const double dg = (m <= nx ? QG[qe(m, j)] : 0.) - (m >= 2 ? QG[qe(m - 1, j)] : 0.);
+          s = xf * dg + 0.5 * mm * fxad;
+          if (own) {          // xfx and mx may be one array (the mass transport): two accumulates in program order
+            const double f2v = F2[f2e(m, j)];
+            a.xfx.p[at(m, j)] += f2v * dg;
+            if (in) a.mx.p[at(m, j)] += 0.5 * f2v * fxad;
+          }
+        }
+        F2[f2e(m, j)] = s;
+      } }
+    TPF_SYNC();
+    auto FX2 = [&](int m, int j) { return (m >= I0 - 2 && m <= I1 + 3) ? F2[f2e(m, j)] : 0.; };
+    if (iord == 2) {                                // edge-value adjoints of the inner sweep, columns I0-4 .. I1+5 of the owned rows
+      constexpr int n = TPD_AW * TPD_QH;
+      TPF_LOOP(e, n) {
+        const int x = I0 - 5 + e % TPD_AW, j = J0 - 3 + e / TPD_AW;
+        double s = 0.;
+        if (j >= GJ0 && j <= GJ1 && x >= I0 - 4 && x <= I1 + 5) {
+          const double cm = a.crx.t[at(cl(x - 1, nx + 1), j)], c0 = a.crx.t[at(cl(x, nx + 1), j)], cp = a.crx.t[at(cl(x + 1, nx + 1), j)];
+          s = tps_al(FX2(x - 1, j), FX2(x, j), FX2(x + 1, j), cm, c0, cp);
+        }
+        AL[e] = s;
+      } }
+    TPF_SYNC();
+    { constexpr int n = TPD_NQ;                     // transposed inner sweep: q_ad of the owned cells
+      TPF_LOOPU(e, u, n, EQ) {
+        const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW;
+        const double acc = qacc[u];
+        if (i < GI0 || i > GI1 || j < GJ0 || j > GJ1 || corner_cell(i, j)) continue;
+        const double qold = a.q.p[at(i, j)];
+        const MetX da{c.m.dxa, c, tile, j};
+        double s;
+        if (iord == 333) {
+          const double f[4] = {FX2(i - 1, j), FX2(i, j), FX2(i + 1, j), FX2(i + 2, j)};
+          const double cc[4] = {a.crx.t[at(cl(i - 1, nx + 1), j)], a.crx.t[at(cl(i, nx + 1), j)], a.crx.t[at(cl(i + 1, nx + 1), j)], a.crx.t[at(cl(i + 2, nx + 1), j)]};
+          s = tps_q333(face, i, nx + 1, f, cc, da);
+        } else {
+          const double c0 = a.crx.t[at(cl(i, nx + 1), j)], cp = a.crx.t[at(cl(i + 1, nx + 1), j)];
+          const int b0 = ale(i, j);
+          const double al[4] = {AL[b0 - 1], AL[b0], AL[b0 + 1], AL[b0 + 2]};
+          s = tps_q(iord, face, i, nx + 1, FX2(i, j), FX2(i + 1, j), c0, cp, al, da);
+        }
+        a.q.p[at(i, j)] = qold + (acc + s);
+      } }
+    { constexpr int w = TPD_W + 1, n = w * TPD_QH;  // own x-faces: crx_ad of the inner sweep
+      TPF_LOOP(e, n) {
+        const int m = I0 + e % w, j = J0 - 3 + e / w;
+        if (j < GJ0 || j > GJ1 || j > J1 + 3 || !(m <= I1 || (lastx && m == I1 + 1))) continue;
+        const double f = F2[f2e(m, j)];
+        if (f == 0.) continue;
+        auto line = [&](int ii) -> Dual { int i2 = ii, jj = j; if (face) corner_map(g, 1, i2, jj); return Dual(Q[qe(i2, jj)], 0.); };
+        const MetX da{c.m.dxa, c, tile, j};
+        a.crx.p[at(m, j)] += ppm_flux<Dual>(iord, face, m, nx + 1, line, da, Dual(a.crx.t[at(m, j)], 1.)).d * f;
+      } }
+  }
+}
+
+// The corner-alias contributions: source cell s next to a face corner is also read, by the inner sweep of direction dir, as the
+// virtual corner cell v = corner_alias(dir, s).  q_ad(s) += sum over the inner fluxes that read v of dflux/dq(v) * flux_ad, with the
+// flux adjoints of the virtual line re-derived from the global inputs (no flux of a virtual line takes part in the flux assembly, so
+// its adjoint is the q_i / q_j part alone).  n = 0 .. 8: the 3 x 3 sources of one corner; dir 2: inner y sweep (branch A), 1: inner x.
+DEV void tp_ad_corner_point(const TpFusedArgs& a, const Ctx& c, int tile, int k, int cn, int n, int dir) {
+  const Geom& g = c.g;
+  if (!g.face) return;
+  const int nx = g.nx, ny = g.ny, ng = g.ng;
+  const size_t base = (size_t)(tile * a.nk + k - 1) * g.plane;
+  auto at = [&](int i, int j) -> size_t { return base + g.idx(i, j); };
+  const int iord = hord_of(c.lev[k - 1], a.hsel);
+  // the 3 x 3 sources of corner cn for this direction: dir 2 reads them from the south / north halo rows next to the corner columns,
+  // dir 1 from the west / east halo columns next to the corner rows (edges.h corner_alias)
+  const bool west = (cn == 0 || cn == 3), south = (cn < 2);
+  int si, sj;
+  if (dir == 2) { si = (west ? 1 : nx - ng + 1) + n % ng; sj = (south ? 1 - ng : ny + 1) + n / ng; }
+  else { si = (west ? 1 - ng : nx + 1) + n % ng; sj = (south ? 1 : ny - ng + 1) + n / ng; }
+  int vi, vj;
+  if (!corner_alias(g, dir, si, sj, vi, vj)) return;
+  double s = 0.;
+  if (dir == 2) {      // virtual cell (vi, vj) in a halo column vi: fluxes fy2(vi, m), m = vj-2 .. vj+3 within 1 .. ny+1
+    const MetY da{c.m.dya, c, tile, vi};
+    auto gi = [&](int r) -> double {       // q_i_ad(vi, r) / ra_y(vi, r)
+      if (r < 1 || r > ny) return 0.;
+      const MetX dx_{c.m.dxa, c, tile, r};
+      double t = 0.;
+      for (int mm = vi - 2; mm <= vi + 3; ++mm) {
+        if (mm < 1 || mm > nx + 1) continue;
+        const double f = 0.5 * a.mx.t[at(mm, r)] * a.fx.p[at(mm, r)];
+        if (f != 0.) t += ppm_dq(iord, true, mm, nx + 1, vi, dx_, a.crx.t[at(mm, r)]) * f;
+      }
+      return t / a.ray.t[at(vi, r)];
+    };
+    for (int m = vj - 2; m <= vj + 3; ++m) {
+      if (m < 1 || m > ny + 1) continue;
+      const double f = a.yfx.t[at(vi, m)] * (gi(m) - gi(m - 1));
+      if (f != 0.) s += ppm_dq(iord, true, m, ny + 1, vj, da, a.cry.t[at(vi, m)]) * f;
+    }
+  } else {
+    const MetX da{c.m.dxa, c, tile, vj};
+    auto gj = [&](int r) -> double {       // q_j_ad(r, vj) / ra_x(r, vj)
+      if (r < 1 || r > nx) return 0.;
+      const MetY dy_{c.m.dya, c, tile, r};
+      double t = 0.;
+      for (int mm = vj - 2; mm <= vj + 3; ++mm) {
+        if (mm < 1 || mm > ny + 1) continue;
+        const double f = 0.5 * a.my.t[at(r, mm)] * a.fy.p[at(r, mm)];
+        if (f != 0.) t += ppm_dq(iord, true, mm, ny + 1, vj, dy_, a.cry.t[at(r, mm)]) * f;
+      }
+      return t / a.rax.t[at(r, vj)];
+    };
+    for (int m = vi - 2; m <= vi + 3; ++m) {
+      if (m < 1 || m > nx + 1) continue;
+      const double f = a.xfx.t[at(m, vj)] * (gj(m) - gj(m - 1));
+      if (f != 0.) s += ppm_dq(iord, true, m, nx + 1, vi, da, a.crx.t[at(m, vj)]) * f;
+    }
+  }
+  if (s != 0.) a.q.p[at(si, sj)] += s;
+}
+
+#ifndef FV3LM_HOST_EMUL
+__global__ void __launch_bounds__(TPD_THREADS) k_tp_ad(TpFusedArgs a, Ctx c) {
+  extern __shared__ double tpd_lds[];
+  int bx = blockIdx.x, by = blockIdx.y; xcd_block(gridDim.x, gridDim.y, bx, by);
+  tp_ad_block<TPD_THREADS>(a, c, blockIdx.z / a.nk, 1 + blockIdx.z % a.nk, bx, by, tpd_lds, threadIdx.x, TPD_THREADS);
+}
+__global__ void __launch_bounds__(64) k_tp_ad_corner(TpFusedArgs a, Ctx c) {
+  // 4 corners x 9 sources: threads 0..35 direction 2, then a second pass direction 1 (the two passes of one thread touch different
+  // sources in general, but a source of both directions -- none exists: the direction-2 sources lie in the south / north halo rows,
+  // the direction-1 sources in the west / east halo columns)
+  const int t = threadIdx.x;
+  if (t >= 36) return;
+  const int tile = blockIdx.x / a.nk, k = 1 + blockIdx.x % a.nk;
+  tp_ad_corner_point(a, c, tile, k, t / 9, t % 9, 2);
+  tp_ad_corner_point(a, c, tile, k, t / 9, t % 9, 1);
+}
+#endif
+
+FV3LM_LINK void run_tp_ad(Exec& ex, const TpFusedArgs& a0, const Ctx& c) {
+  TpFusedArgs a = a0;
+  for (Fld* f : {&a.q, &a.crx, &a.cry, &a.xfx, &a.yfx, &a.rax, &a.ray, &a.mx, &a.my, &a.fx, &a.fy}) *f = ex.sh(*f);
+  const int nbx = (c.g.nx + TPD_W - 1) / TPD_W, nby = (c.g.ny + TPD_H - 1) / TPD_H;
+  // algorithmic bytes: trajectory q, crx, cry, xfx, yfx, ra_x, ra_y, mx, my and the adjoints fx, fy read; the nine input adjoints read-modify-written
+  const double cells = double(c.g.nx) * c.g.ny * c.g.ntile * a.nk;
+  ex.mark_begin("TpAd", ".ad", 8. * cells * (9. + 2. + 18.));
+#ifdef FV3LM_HOST_EMUL
+  std::vector<double> lds((size_t)TPD_NT);
+  for (int z = 0; z < c.g.ntile * a.nk; ++z)
+    for (int by = 0; by < nby; ++by)
+      for (int bx = 0; bx < nbx; ++bx) tp_ad_block<1>(a, c, z / a.nk, 1 + z % a.nk, bx, by, lds.data(), 0, 1);
+  if (c.g.face)
+    for (int z = 0; z < c.g.ntile * a.nk; ++z)
+      for (int t = 0; t < 36; ++t) { tp_ad_corner_point(a, c, z / a.nk, 1 + z % a.nk, t / 9, t % 9, 2); tp_ad_corner_point(a, c, z / a.nk, 1 + z % a.nk, t / 9, t % 9, 1); }
+#else
+  static bool attr = false;
+  if (!attr) { if (hipFuncSetAttribute((const void*)k_tp_ad, hipFuncAttributeMaxDynamicSharedMemorySize, TPD_NT * 8) != hipSuccess) set_sticky("hipFuncSetAttribute(k_tp_ad) failed"); attr = true; }
+  hipLaunchKernelGGL(k_tp_ad, dim3(nbx, nby, c.g.ntile * a.nk), dim3(TPD_THREADS), TPD_NT * 8, ex.stream, a, c);
+#endif
+  ex.mark_end();
+  ex.launches++;
+#ifndef FV3LM_HOST_EMUL
+  if (c.g.face) {
+    ex.mark_begin("TpAd", ".ad_corner", 0.);
+    hipLaunchKernelGGL(k_tp_ad_corner, dim3(c.g.ntile * a.nk), dim3(64), 0, ex.stream, a, c);
+    ex.mark_end();
+    ex.launches++;
+  }
+#endif
+}
+
+}  // namespace fv3
+#endif

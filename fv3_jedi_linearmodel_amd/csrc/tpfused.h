@@ -26,7 +26,28 @@ struct TpFusedArgs {
   // (t == nullptr: none).  do_acc is cleared for the adjoint's trajectory recompute, which must leave the accumulators alone.
   Fld acx, acy, amfx, amfy; int do_acc;
   int store_fo = 1;                              // fxo, fyo are arrays of their own (0: the names alias fx2 / fy2 and nothing may write them)
+  int store_mid = 1;                             // fy2, q_i, fx2, q_j likewise (0: the fused adjoint of tpad.h recomputes them; the nonlinear launch stores nothing)
 };
+// nonlinear / tangent-linear launch (the adjoint runs the staged launches of build_tp); traj: the values-only trajectory pass of
+// the levels with split schemes, in the nonlinear and the tangent mode alike
+FV3LM_LINK void run_tp_fused(Exec& ex, int mode, const TpFusedArgs& a0, const Ctx& c, bool traj = false);
+FV3LM_LINK void run_tp_outer_ad(Exec& ex, const TpFusedArgs& a0, const Ctx& c);
+}  // namespace fv3
+
+#ifdef FV3LM_HOST_EMUL
+#define TPF_SYNC() ((void)0)
+#define TPF_LOOP(e, n) for (int e = tid; e < (n); e += nth)
+#define TPF_LOOPU(e, u, n, E) for (int u = 0, e = 0; e < (n); ++e, ++u)      /* one "thread": slot u of a per-thread array is element e */
+#else
+#define TPF_SYNC() __syncthreads()
+// constant trip count, unrolled: the global loads of a thread's elements of a phase are issued together
+#define TPF_LOOP(e, n) _Pragma("unroll") for (int e = tid; e < (n); e += NTH)
+// the same with the slot index u of a per-thread register array (constant trip count E = ceil(n / NTH): static indices after unrolling)
+#define TPF_LOOPU(e, u, n, E) _Pragma("unroll") for (int u = 0; u < (E); ++u) if (const int e = tid + u * NTH; e < (n))
+#endif
+
+#if !defined(FV3LM_SPLIT_BUILD) || defined(FV3LM_IMPL_TPFUSED)
+namespace fv3 {
 #ifndef FV3LM_TPF_H
 #define FV3LM_TPF_H 16
 #endif
@@ -44,14 +65,6 @@ constexpr int TPF_NQ = TPF_QW * TPF_QH, TPF_NFY2 = TPF_QW * (TPF_H + 1), TPF_NQI
               TPF_NQJ = TPF_W * TPF_QH, TPF_NT = TPF_NQ + TPF_NFY2 + TPF_NQI + TPF_NFX2 + TPF_NQJ;   // doubles per component
 constexpr int TPF_THREADS_NL = FV3LM_TPF_THREADS_NL, TPF_THREADS_TL = FV3LM_TPF_THREADS_TL;
 
-#ifdef FV3LM_HOST_EMUL
-#define TPF_SYNC() ((void)0)
-#define TPF_LOOP(e, n) for (int e = tid; e < (n); e += nth)
-#else
-#define TPF_SYNC() __syncthreads()
-// constant trip count, unrolled: the global loads of a thread's elements of a phase are issued together
-#define TPF_LOOP(e, n) _Pragma("unroll") for (int e = tid; e < (n); e += NTH)
-#endif
 
 template <class T> struct TpfIO;
 template <> struct TpfIO<double> {
@@ -236,7 +249,7 @@ inline void tpf_grid(const Geom& g, int& nbx, int& nby) { nbx = (g.nx + TPF_W - 
 // trajectory intermediates of the nonlinear mode
 inline double tpf_bytes(const TpFusedArgs& a, const Geom& g, int mode) {
   const double cells = double(g.nx) * g.ny * g.ntile * a.nk, nin = 9. + (a.d2b.t ? 1. : 0.) + (a.mass.t ? 1. : 0.);
-  return 8. * cells * (mode == MODE_TL ? 2. * (nin + 2.) : (nin + 2.) + (a.store_fo ? 6. : 4.));
+  return 8. * cells * (mode == MODE_TL ? 2. * (nin + 2.) : (nin + 2.) + (a.store_mid ? (a.store_fo ? 6. : 4.) : 0.));
 }
 
 #ifndef FV3LM_HOST_EMUL
@@ -248,9 +261,7 @@ __global__ void __launch_bounds__(NTH) k_tp_fused(TpFusedArgs a, Ctx c) {
 }
 #endif
 
-// nonlinear / tangent-linear launch (the adjoint runs the staged launches of build_tp); traj: the values-only trajectory pass of
-// the levels with split schemes, in the nonlinear and the tangent mode alike
-inline void run_tp_fused(Exec& ex, int mode, const TpFusedArgs& a0, const Ctx& c, bool traj = false) {
+FV3LM_LINK void run_tp_fused(Exec& ex, int mode, const TpFusedArgs& a0, const Ctx& c, bool traj) {
   TpFusedArgs a = a0;
   for (Fld* f : {&a.q, &a.crx, &a.cry, &a.xfx, &a.yfx, &a.rax, &a.ray, &a.mx, &a.my, &a.mass, &a.d2b, &a.d2b_t, &a.fx, &a.fy, &a.fy2, &a.q_i, &a.fxo, &a.fx2, &a.q_j, &a.fyo, &a.acx, &a.acy, &a.amfx, &a.amfy}) *f = ex.sh(*f);
   a.do_acc = (a.acx.t && !ex.skip_accum) ? 1 : 0;
@@ -263,7 +274,8 @@ inline void run_tp_fused(Exec& ex, int mode, const TpFusedArgs& a0, const Ctx& c
       for (int bx = 0; bx < nbx; ++bx) {
         if (traj) tp_fused_block<double, false, 1, true>(a, c, z / a.nk, 1 + z % a.nk, bx, by, lds.data(), 0, 1);
         else if (mode == MODE_TL) tp_fused_block<Dual, false, 1>(a, c, z / a.nk, 1 + z % a.nk, bx, by, lds.data(), 0, 1);
-        else tp_fused_block<double, true, 1>(a, c, z / a.nk, 1 + z % a.nk, bx, by, lds.data(), 0, 1);
+        else if (a.store_mid) tp_fused_block<double, true, 1>(a, c, z / a.nk, 1 + z % a.nk, bx, by, lds.data(), 0, 1);
+        else tp_fused_block<double, false, 1>(a, c, z / a.nk, 1 + z % a.nk, bx, by, lds.data(), 0, 1);
       }
 #else
   const dim3 grid(nbx, nby, c.g.ntile * a.nk);
@@ -273,8 +285,10 @@ inline void run_tp_fused(Exec& ex, int mode, const TpFusedArgs& a0, const Ctx& c
     static bool attr = false;      // 2 x 53.5 KB of LDS per block: above the 64 KB default limit of a launch
     if (!attr) { if (hipFuncSetAttribute((const void*)k_tp_fused<Dual, false, TPF_THREADS_TL>, hipFuncAttributeMaxDynamicSharedMemorySize, TPF_NT * 16) != hipSuccess) set_sticky("hipFuncSetAttribute(k_tp_fused) failed"); attr = true; }
     hipLaunchKernelGGL((k_tp_fused<Dual, false, TPF_THREADS_TL>), grid, dim3(TPF_THREADS_TL), TPF_NT * 16, ex.stream, a, c);
-  } else {
+  } else if (a.store_mid) {
     hipLaunchKernelGGL((k_tp_fused<double, true, TPF_THREADS_NL>), grid, dim3(TPF_THREADS_NL), TPF_NT * 8, ex.stream, a, c);
+  } else {
+    hipLaunchKernelGGL((k_tp_fused<double, false, TPF_THREADS_NL>), grid, dim3(TPF_THREADS_NL), TPF_NT * 8, ex.stream, a, c);
   }
 #endif
   ex.mark_end();
@@ -417,7 +431,7 @@ __global__ void __launch_bounds__(TPA_THREADS) k_tp_outer_ad(TpFusedArgs a, Ctx 
 }
 #endif
 
-inline void run_tp_outer_ad(Exec& ex, const TpFusedArgs& a0, const Ctx& c) {
+FV3LM_LINK void run_tp_outer_ad(Exec& ex, const TpFusedArgs& a0, const Ctx& c) {
   TpFusedArgs a = a0;
   for (Fld* f : {&a.q, &a.crx, &a.cry, &a.xfx, &a.yfx, &a.rax, &a.ray, &a.mx, &a.my, &a.mass, &a.d2b, &a.fx, &a.fy, &a.fy2, &a.q_i, &a.fxo, &a.fx2, &a.q_j, &a.fyo}) *f = ex.sh(*f);
   int nbx, nby; tpf_grid(c.g, nbx, nby);
@@ -437,207 +451,5 @@ inline void run_tp_outer_ad(Exec& ex, const TpFusedArgs& a0, const Ctx& c) {
   ex.launches++;
 }
 
-// =====================================================================================================================
-// Marching form of the same routine.  One wavefront owns a strip of MW output columns (lane l <-> column I0 - 3 + l, three
-// halo columns on either side) and walks down the rows of its chunk.  Every input row is read from HBM exactly once per strip, as
-// one coalesced row piece; the y-direction stencils live in per-lane register windows (the last six rows of q and of q_j), the
-// x-direction stencils go through three 64-entry LDS row buffers (q, fx2, q_i).  Nothing but the row buffers is staged, so the
-// launch is not limited by LDS and needs no large tile: per step a lane issues all its loads first, then computes
-//    row r:    fx2 = xppm(q(., r)),  q_j(r)                      (inner x-sweep, one row at a time)
-//    row r-2:  fy2 = yppm(q(r-5..r)),  fyo = yppm(q_j(r-5..r)),  fy
-//    row r-3:  q_i from fy2(r-3), fy2(r-2);  fxo = xppm(q_i(., r-3));  fx
-// Same arithmetic, same order as the staged stages and the tiled kernel above.
-// =====================================================================================================================
-#ifndef FV3LM_TPM_ROWS
-#define FV3LM_TPM_ROWS 64
-#endif
-constexpr int TPM_LANES = 64, TPM_MAXW = TPM_LANES - 6, TPM_ROWS = FV3LM_TPM_ROWS;
-inline int tpm_width(int nx) { const int nb = (nx + TPM_MAXW - 1) / TPM_MAXW; return (nx + nb - 1) / nb; }   // equal strips, <= 58 wide
-
-#ifdef FV3LM_HOST_EMUL
-#define TPM_NST TPM_LANES
-#define TPM_FOR(l) for (int l = 0; l < TPM_LANES; ++l)
-#define TPM_S(l) (l)
-#else
-#define TPM_NST 1
-#define TPM_FOR(l) for (int l = lane0; l == lane0; ++l)
-#define TPM_S(l) 0
-#endif
-
-template <class T>
-struct TpmState {
-  T qw[6], qjw[6], fx2q[4], fy2p, yfxp;
-};
-
-template <class T, bool STORE>
-DEV void tp_march_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx, int by, int mw, double* lds, int lane0) {
-  typedef TpfIO<T> IO;
-  (void)lane0;
-  const Geom& g = c.g;
-  const int nx = g.nx, ny = g.ny;
-  const bool face = g.face != 0;
-  const int I0 = 1 + bx * mw, I1 = (I0 + mw - 1 < nx) ? I0 + mw - 1 : nx;
-  const int J0 = 1 + by * TPM_ROWS, J1 = (J0 + TPM_ROWS - 1 < ny) ? J0 + TPM_ROWS - 1 : ny;
-  const bool firstx = bx == 0, lastx = I1 == nx, firsty = by == 0, lasty = J1 == ny;
-  const size_t base = (size_t)(tile * a.nk + k - 1) * g.plane;
-  auto at = [&](int i, int j) -> size_t { return base + g.idx(i, j); };
-  const int iord = hord_of(c.lev[k - 1], a.hsel);
-  int nord; double dc; damp_of(c.lev[k - 1], a.dsel, nord, dc);
-  const bool dmp = (a.dsel != DAMP_NONE) && (dc > 1.e-4);
-  double damp = 0.;
-  if (dmp) { damp = dc * c.m.da_min; if (nord == 1) damp = damp * damp; }
-  auto own_i = [&](int i) { return (i >= I0 && i <= I1) || (firstx && i < I0) || (lastx && i > I1); };
-  auto own_j = [&](int j) { return (j >= J0 && j <= J1) || (firsty && j < J0) || (lasty && j > J1); };
-  // row buffers: value plane, then tangent plane (TPF_NT apart, as TpfIO expects)
-  double* rq = lds; double* rfx2 = lds + TPM_LANES; double* rqi = lds + 2 * TPM_LANES;
-  constexpr int NTP = 3 * TPM_LANES;
-  auto rget = [&](const double* b, int l) -> T { if constexpr (IO::NC == 2) return Dual(b[l], b[NTP + l]); else return b[l]; };
-  auto rset = [&](double* b, int l, const T& x) { if constexpr (IO::NC == 2) { b[l] = x.v; b[NTP + l] = x.d; } else b[l] = x; };
-  TpmState<T> st[TPM_NST];
-  TPM_FOR(l) { TpmState<T>& s = st[TPM_S(l)]; for (int n = 0; n < 6; ++n) { s.qw[n] = T(0.); s.qjw[n] = T(0.); } for (int n = 0; n < 4; ++n) s.fx2q[n] = T(0.); s.fy2p = T(0.); s.yfxp = T(0.); }
-
-  for (int r = J0 - 3; r <= J1 + 3; ++r) {
-    const int j2 = r - 2, j3 = r - 3;
-    const bool do2 = j2 >= J0 && j2 <= J1 + 1, do3 = j3 >= J0 && j3 <= J1;
-    // ---- A: the new row of q (y-sweep view into the window, x-sweep view into the row buffer)
-    TPM_FOR(l) {
-      TpmState<T>& s = st[TPM_S(l)];
-      const int i = I0 - 3 + l;
-      for (int n = 0; n < 5; ++n) s.qw[n] = s.qw[n + 1];
-      if (i <= I1 + 3) {
-        int iy = i, jy = r, ix = i, jx = r;
-        if (face) { corner_map(g, 2, iy, jy); corner_map(g, 1, ix, jx); }
-        const T qy = IO::ld(a.q, at(iy, jy));
-        s.qw[5] = qy;
-        rset(rq, l, (ix == iy && jx == jy) ? qy : IO::ld(a.q, at(ix, jx)));
-      }
-    }
-    TPF_SYNC();
-    // ---- B: inner x-sweep of row r
-    TPM_FOR(l) {
-      TpmState<T>& s = st[TPM_S(l)];
-      const int i = I0 - 3 + l;
-      for (int n = 0; n < 3; ++n) s.fx2q[n] = s.fx2q[n + 1];
-      if (i >= I0 && i <= I1 + 1) {
-        auto line = [&](int ii) -> T { return rget(rq, ii - (I0 - 3)); };
-        const MetX da{c.m.dxa, c, tile, r};
-        const T cc = IO::ld(a.crx, at(i, r));
-        const T f = ppm_flux<T>(iord, face, i, nx + 1, line, da, cc);
-        s.fx2q[3] = f;
-        rset(rfx2, l, f);
-        if (STORE && own_j(r) && (i <= I1 || lastx)) a.fx2.t[at(i, r)] = val(f);
-        if (a.do_acc && own_j(r) && (i <= I1 || lastx)) IO::st(a.acx, at(i, r), IO::ld(a.acx, at(i, r)) + cc);
-      }
-    }
-    TPF_SYNC();
-    // ---- C: q_j of row r
-    TPM_FOR(l) {
-      TpmState<T>& s = st[TPM_S(l)];
-      const int i = I0 - 3 + l;
-      for (int n = 0; n < 5; ++n) s.qjw[n] = s.qjw[n + 1];
-      if (i >= I0 && i <= I1) {
-        const T f0 = IO::ld(a.xfx, at(i, r)) * s.fx2q[3], f1 = IO::ld(a.xfx, at(i + 1, r)) * rget(rfx2, l + 1);
-        const T x = (rget(rq, l) * MET(area, i, r) + f0 - f1) / IO::ld(a.rax, at(i, r));
-        s.qjw[5] = x;
-        if (STORE && own_j(r)) a.q_j.t[at(i, r)] = val(x);
-      }
-    }
-    // ---- D: row j2 = r - 2: inner y-sweep on every column of the strip, outer y-sweep and fy on its own columns
-    T fy2n = T(0.);
-    if (do2) {
-      TPM_FOR(l) {
-        TpmState<T>& s = st[TPM_S(l)];
-        const int i = I0 - 3 + l;
-        if (i > I1 + 3) continue;
-        const T cc = IO::ld(a.cry, at(i, j2));
-        const MetY da{c.m.dya, c, tile, i};
-        auto line = [&](int jj) -> T { return s.qw[jj - (r - 5)]; };
-        const T f = ppm_flux<T>(iord, face, j2, ny + 1, line, da, cc);
-        if (STORE && own_i(i) && (j2 <= J1 || lasty)) a.fy2.t[at(i, j2)] = val(f);
-        if (a.do_acc && own_i(i) && (j2 <= J1 || lasty)) IO::st(a.acy, at(i, j2), IO::ld(a.acy, at(i, j2)) + cc);
-        if (i >= I0 && i <= I1 && (j2 <= J1 || lasty)) {
-          auto linej = [&](int jj) -> T { return s.qjw[jj - (r - 5)]; };
-          const T fo = ppm_flux<T>(iord, face, j2, ny + 1, linej, da, cc);
-          if (STORE) a.fyo.t[at(i, j2)] = val(fo);
-          T ff = 0.5 * (fo + f) * IO::ld(a.my, at(i, j2));
-          if (dmp) {
-            T f2;
-            if (nord == 0) { f2 = MET(del6_u, i, j2) * (s.qw[2] - s.qw[3]); if (!a.use_mass) f2 = damp * f2; }
-            else f2 = MET(del6_u, i, j2) * (IO::ld(a.d2b, at(i, j2)) - IO::ld(a.d2b, at(i, j2 - 1)));
-            if (a.use_mass) ff = ff + (0.5 * damp) * (IO::ld(a.mass, at(i, j2 - 1)) + IO::ld(a.mass, at(i, j2))) * f2;
-            else ff = ff + f2;
-          }
-          IO::st(a.fy, at(i, j2), ff);
-          if (a.do_acc) IO::st(a.amfy, at(i, j2), IO::ld(a.amfy, at(i, j2)) + ff);
-        }
-        // ---- E (first half): q_i of row j3 from fy2(j3) (kept from the previous step) and fy2(j3 + 1) = f
-        const T yfxn = IO::ld(a.yfx, at(i, j2));
-        if (do3) {
-          const T f0 = s.yfxp * s.fy2p, f1 = yfxn * f;
-          const T x = (s.qw[2] * MET(area, i, j3) + f0 - f1) / IO::ld(a.ray, at(i, j3));
-          rset(rqi, l, x);
-          if (STORE && own_i(i)) a.q_i.t[at(i, j3)] = val(x);
-        }
-        s.fy2p = f; s.yfxp = yfxn;
-      }
-    }
-    (void)fy2n;
-    TPF_SYNC();
-    // ---- E (second half): outer x-sweep of row j3 and fx
-    if (do3) {
-      TPM_FOR(l) {
-        TpmState<T>& s = st[TPM_S(l)];
-        const int i = I0 - 3 + l;
-        if (!(i >= I0 && (i <= I1 || (lastx && i == I1 + 1)))) continue;
-        auto line = [&](int ii) -> T { return rget(rqi, ii - (I0 - 3)); };
-        const MetX da{c.m.dxa, c, tile, j3};
-        const T fo = ppm_flux<T>(iord, face, i, nx + 1, line, da, IO::ld(a.crx, at(i, j3)));
-        if (STORE) a.fxo.t[at(i, j3)] = val(fo);
-        T ff = 0.5 * (fo + s.fx2q[0]) * IO::ld(a.mx, at(i, j3));
-        if (dmp) {
-          T f2;
-          if (nord == 0) { f2 = MET(del6_v, i, j3) * (IO::ld(a.q, at(i - 1, j3)) - IO::ld(a.q, at(i, j3))); if (!a.use_mass) f2 = damp * f2; }
-          else f2 = MET(del6_v, i, j3) * (IO::ld(a.d2b, at(i, j3)) - IO::ld(a.d2b, at(i - 1, j3)));
-          if (a.use_mass) ff = ff + (0.5 * damp) * (IO::ld(a.mass, at(i - 1, j3)) + IO::ld(a.mass, at(i, j3))) * f2;
-          else ff = ff + f2;
-        }
-        IO::st(a.fx, at(i, j3), ff);
-        if (a.do_acc) IO::st(a.amfx, at(i, j3), IO::ld(a.amfx, at(i, j3)) + ff);
-      }
-    }
-    TPF_SYNC();
-  }
-}
-
-#ifndef FV3LM_HOST_EMUL
-template <class T, bool STORE>
-__global__ void __launch_bounds__(TPM_LANES) k_tp_march(TpFusedArgs a, Ctx c, int mw) {
-  __shared__ double tpm_lds[6 * TPM_LANES];
-  tp_march_block<T, STORE>(a, c, blockIdx.z / a.nk, 1 + blockIdx.z % a.nk, blockIdx.x, blockIdx.y, mw, tpm_lds, threadIdx.x);
-}
-#endif
-
-inline void run_tp_march(Exec& ex, int mode, const TpFusedArgs& a0, const Ctx& c) {
-  TpFusedArgs a = a0;
-  for (Fld* f : {&a.q, &a.crx, &a.cry, &a.xfx, &a.yfx, &a.rax, &a.ray, &a.mx, &a.my, &a.mass, &a.d2b, &a.fx, &a.fy, &a.fy2, &a.q_i, &a.fxo, &a.fx2, &a.q_j, &a.fyo, &a.acx, &a.acy, &a.amfx, &a.amfy}) *f = ex.sh(*f);
-  a.do_acc = (a.acx.t && !ex.skip_accum) ? 1 : 0;
-  const int mw = tpm_width(c.g.nx), nbx = (c.g.nx + mw - 1) / mw, nby = (c.g.ny + TPM_ROWS - 1) / TPM_ROWS;
-  ex.mark_begin("TpMarch", mode == MODE_TL ? ".tl" : ".nl", tpf_bytes(a, c.g, mode));
-#ifdef FV3LM_HOST_EMUL
-  std::vector<double> lds(6 * TPM_LANES);
-  for (int z = 0; z < c.g.ntile * a.nk; ++z)
-    for (int by = 0; by < nby; ++by)
-      for (int bx = 0; bx < nbx; ++bx) {
-        if (mode == MODE_TL) tp_march_block<Dual, false>(a, c, z / a.nk, 1 + z % a.nk, bx, by, mw, lds.data(), 0);
-        else tp_march_block<double, true>(a, c, z / a.nk, 1 + z % a.nk, bx, by, mw, lds.data(), 0);
-      }
-#else
-  const dim3 grid(nbx, nby, c.g.ntile * a.nk);
-  if (mode == MODE_TL) hipLaunchKernelGGL((k_tp_march<Dual, false>), grid, dim3(TPM_LANES), 0, ex.stream, a, c, mw);
-  else hipLaunchKernelGGL((k_tp_march<double, true>), grid, dim3(TPM_LANES), 0, ex.stream, a, c, mw);
-#endif
-  ex.mark_end();
-  ex.launches++;
-}
-
 }  // namespace fv3
+#endif

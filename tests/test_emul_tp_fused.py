@@ -19,9 +19,3 @@ def test_fused_tp_nonhydrostatic_interfaces():
     check_fused_equals_staged(lambda: Case(nx=66, ny=18, npz=10, n_split=1, k_split=1, dt=300.0, backend="emul", oracle=False, hydrostatic=0))
 
 
-def test_marching_form_equals_staged(monkeypatch):
-    """the marching form of the fused routine (FV3LM_TP_FUSED=3: one wavefront per column strip walking down the rows) is kept beside
-    the tiled default; same bit-for-bit check on a face with edges and corners"""
-    import tp_fused_checks
-    monkeypatch.setattr(tp_fused_checks, "FUSED_VALUE", "3")
-    check_fused_equals_staged(lambda: CubeCase(n=66, npz=3, n_split=1, k_split=1, dt=225.0, backend="emul", nq=1))
