@@ -31,10 +31,21 @@ FV3LM_LINK void run_tp_ad(Exec& ex, const TpFusedArgs& a0, const Ctx& c);
 namespace fv3 {
 
 #ifndef FV3LM_TPD_H
-#define FV3LM_TPD_H 16
+#define FV3LM_TPD_H 32
+#endif
+// FV3LM_TPD_NOUNROLL: the element loops of a phase as real loops (code size / 4: the unrolled kernel is 350 KB of straight-line code);
+// the area term of q_ad then goes to q_ad at once instead of waiting in a register for the inner sweep's term
+#if defined(FV3LM_TPD_NOUNROLL) && !defined(FV3LM_HOST_EMUL)
+#define TPD_LOOP(e, n) _Pragma("nounroll") for (int e = tid; e < (n); e += NTH)
+#define TPD_LOOPU(e, u, n, E) _Pragma("nounroll") for (int e = tid, u = 0; e < (n); e += NTH)
+#define TPD_QACC_DIRECT 1
+#else
+#define TPD_LOOP(e, n) TPF_LOOP(e, n)
+#define TPD_LOOPU(e, u, n, E) TPF_LOOPU(e, u, n, E)
+#define TPD_QACC_DIRECT 0
 #endif
 #ifndef FV3LM_TPD_THREADS
-#define FV3LM_TPD_THREADS 512
+#define FV3LM_TPD_THREADS 1024
 #endif
 constexpr int TPD_W = 64, TPD_H = FV3LM_TPD_H;
 constexpr int TPD_QW = TPD_W + 6, TPD_QH = TPD_H + 6;        // halo'd tile
@@ -42,7 +53,7 @@ constexpr int TPD_AW = TPD_W + 12, TPD_AH = TPD_H + 12;      // flux-adjoint til
 constexpr int TPD_NQ = TPD_QW * TPD_QH;                      // q; q_i / q_j values, later gi / gj
 constexpr int TPD_NF2 = TPD_QW * (TPD_QH + 1);               // inner flux values, later (in place) their adjoints
 constexpr int TPD_NFA = (TPD_AW * TPD_QH > TPD_AH * TPD_QW ? TPD_AW * TPD_QH : TPD_AH * TPD_QW);    // outer-flux adjoint tile (either orientation)
-constexpr int TPD_NT = 2 * TPD_NQ + TPD_NF2 + 2 * TPD_NFA;   // 8,610 doubles = 69 KB: two blocks per CU
+constexpr int TPD_NT = 2 * TPD_NQ + TPD_NF2 + 2 * TPD_NFA;   // 64 x 32 cells: 14,210 doubles = 114 KB, one 1024-thread block per CU (measured: 4.55 ms per launch at C192L127 x 6; 64 x 16 / 512 threads / two blocks: 4.81)
 constexpr int TPD_THREADS = FV3LM_TPD_THREADS;
 
 // Transposed 1-D sweep in two stages.  flux(m) of iord 2 is  q_up c'(3 -+ 2c) + al(m) (1 -+ c)^2 -+ al(m -+ 1) c (1 -+ c)  (upper signs: c > 0,
@@ -110,7 +121,7 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
   double qacc[EQ];
 
   { constexpr int n = TPD_NQ;
-    TPF_LOOP(e, n) { const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW; Q[e] = (i <= I1 + 3 && j <= J1 + 3) ? a.q.t[at(i, j)] : 0.; } }
+    TPD_LOOP(e, n) { const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW; Q[e] = (i <= I1 + 3 && j <= J1 + 3) ? a.q.t[at(i, j)] : 0.; } }
   TPF_SYNC();
 
   // ============================== branch A: outer sweep in x, inner sweep in y ==============================
@@ -119,12 +130,12 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
     auto fae = [&](int i, int j) { return (j - (J0 - 3)) * TPD_AW + (i - (I0 - 6)); };          // columns I0-6 .. I1+6, rows J0-3 .. J1+3
     auto ale = [&](int i, int j) { return (j - (J0 - 5)) * TPD_QW + (i - (I0 - 3)); };          // inner sweep: rows J0-5 .. J1+6
     { constexpr int n = TPD_AW * TPD_QH;
-      TPF_LOOP(e, n) {
+      TPD_LOOP(e, n) {
         const int i = I0 - 6 + e % TPD_AW, j = J0 - 3 + e / TPD_AW;
         FA[e] = (i >= 1 && i <= nx + 1 && j >= 1 && j <= ny && i <= I1 + 6 && j <= J1 + 3) ? 0.5 * a.mx.t[at(i, j)] * a.fx.p[at(i, j)] : 0.;
       } }
     { constexpr int n = TPD_QW * (TPD_H + 1);       // inner flux values fy2 on rows J0 .. J1+1
-      TPF_LOOP(e, n) {
+      TPD_LOOP(e, n) {
         const int i = I0 - 3 + e % TPD_QW, j = J0 + e / TPD_QW;
         if (i > I1 + 3 || j > J1 + 1) continue;
         auto line = [&](int jj) -> double { int ii = i, j2 = jj; if (face) corner_map(g, 2, ii, j2); return Q[qe(ii, j2)]; };
@@ -133,7 +144,7 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
       } }
     TPF_SYNC();
     { constexpr int n = TPD_QW * TPD_H;             // q_i values
-      TPF_LOOP(e, n) {
+      TPD_LOOP(e, n) {
         const int i = I0 - 3 + e % TPD_QW, j = J0 + e / TPD_QW;
         if (i > I1 + 3 || j > J1) continue;
         QG[qe(i, j)] = (Q[qe(i, j)] * MET(area, i, j) + a.yfx.t[at(i, j)] * F2[f2e(i, j)] - a.yfx.t[at(i, j + 1)] * F2[f2e(i, j + 1)]) / a.ray.t[at(i, j)];
@@ -141,7 +152,7 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
     TPF_SYNC();
     auto FX = [&](int m, int j) { return FA[fae(m, j)]; };
     { constexpr int w = TPD_W + 1, n = w * TPD_H;   // own x-faces: Courant-number and mass-flux adjoints of the outer sweep
-      TPF_LOOP(e, n) {
+      TPD_LOOP(e, n) {
         const int i = I0 + e % w, j = J0 + e / w;
         if (j > J1 || !(i <= I1 || (lastx && i == I1 + 1))) continue;
         const double fo = FX(i, j), fxad = a.fx.p[at(i, j)];
@@ -155,7 +166,7 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
     auto cl = [](int m, int n1) { return m < 1 ? 1 : (m > n1 ? n1 : m); };      // flux index clamped into its range (the flux adjoint is zero outside: the value does not matter, the address must exist)
     if (iord == 2) {                                // edge-value adjoints of the outer sweep, columns I0-4 .. I1+5
       constexpr int n = TPD_AW * TPD_QH;
-      TPF_LOOP(e, n) {
+      TPD_LOOP(e, n) {
         const int x = I0 - 6 + e % TPD_AW, j = J0 - 3 + e / TPD_AW;
         double s = 0.;
         if (x >= I0 - 4 && x <= I1 + 5 && j >= 1 && j <= ny && j <= J1 + 3) {
@@ -166,7 +177,7 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
       } }
     TPF_SYNC();
     { constexpr int n = TPD_NQ;                     // gi = q_i_ad / ra_y on the owned columns; own cells: ra_y_ad, the area term of q_ad
-      TPF_LOOPU(e, u, n, EQ) {
+      TPD_LOOPU(e, u, n, EQ) {
         const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW;
         double s = 0., acc = 0.;
         if (i >= GI0 && i <= GI1 && j >= 1 && j <= ny && j <= J1 + 3) {
@@ -186,12 +197,12 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
           s = s / ry;
           if (own) { a.ray.p[at(i, j)] = rold - QG[e] * s; acc = ar * s; }
         }
-        qacc[u] = acc;
+        if (TPD_QACC_DIRECT) { if (acc != 0.) a.q.p[at(i, j)] += acc; } else qacc[u] = acc;
         QG[e] = s;
       } }
     TPF_SYNC();
     { constexpr int n = TPD_QW * (TPD_QH - 1);      // fy2_ad on rows J0-2 .. J1+3 of the owned columns, in place of the values; own y-faces: yfx_ad, my_ad (inner part)
-      TPF_LOOP(e, n) {
+      TPD_LOOP(e, n) {
         const int i = I0 - 3 + e % TPD_QW, m = J0 - 2 + e / TPD_QW;
         double s = 0.;
         if (i >= GI0 && i <= GI1 && m >= 1 && m <= ny + 1 && m <= J1 + 3) {
@@ -211,7 +222,7 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
     auto FY2 = [&](int i, int m) { return (m >= J0 - 2 && m <= J1 + 3) ? F2[f2e(i, m)] : 0.; };
     if (iord == 2) {                                // edge-value adjoints of the inner sweep, rows J0-4 .. J1+5 of the owned columns
       constexpr int n = TPD_QW * TPD_AH;
-      TPF_LOOP(e, n) {
+      TPD_LOOP(e, n) {
         const int i = I0 - 3 + e % TPD_QW, x = J0 - 5 + e / TPD_QW;
         double s = 0.;
         if (i >= GI0 && i <= GI1 && x >= J0 - 4 && x <= J1 + 5) {
@@ -222,9 +233,9 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
       } }
     TPF_SYNC();
     { constexpr int n = TPD_NQ;                     // transposed inner sweep: q_ad of the owned cells
-      TPF_LOOPU(e, u, n, EQ) {
+      TPD_LOOPU(e, u, n, EQ) {
         const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW;
-        const double acc = qacc[u];
+        const double acc = TPD_QACC_DIRECT ? 0. : qacc[u];
         if (i < GI0 || i > GI1 || j < GJ0 || j > GJ1 || corner_cell(i, j)) continue;
         const double qold = a.q.p[at(i, j)];
         const MetY da{c.m.dya, c, tile, i};
@@ -242,7 +253,7 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
         a.q.p[at(i, j)] = qold + (acc + s);
       } }
     { constexpr int n = TPD_QW * (TPD_H + 1);       // own y-faces: cry_ad of the inner sweep
-      TPF_LOOP(e, n) {
+      TPD_LOOP(e, n) {
         const int i = I0 - 3 + e % TPD_QW, m = J0 + e / TPD_QW;
         if (i < GI0 || i > GI1 || !(m <= J1 || (lasty && m == J1 + 1))) continue;
         const double f = F2[f2e(i, m)];
@@ -260,12 +271,12 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
     auto fae = [&](int i, int j) { return (j - (J0 - 6)) * TPD_QW + (i - (I0 - 3)); };          // rows J0-6 .. J1+6, columns I0-3 .. I1+3
     auto ale = [&](int i, int j) { return (j - (J0 - 3)) * TPD_AW + (i - (I0 - 5)); };          // inner sweep: columns I0-5 .. I1+6 (pitch TPD_AW)
     { constexpr int n = TPD_QW * TPD_AH;
-      TPF_LOOP(e, n) {
+      TPD_LOOP(e, n) {
         const int i = I0 - 3 + e % TPD_QW, j = J0 - 6 + e / TPD_QW;
         FA[e] = (j >= 1 && j <= ny + 1 && i >= 1 && i <= nx && j <= J1 + 6 && i <= I1 + 3) ? 0.5 * a.my.t[at(i, j)] * a.fy.p[at(i, j)] : 0.;
       } }
     { constexpr int w = TPD_W + 1, n = w * TPD_QH;  // inner flux values fx2 on columns I0 .. I1+1
-      TPF_LOOP(e, n) {
+      TPD_LOOP(e, n) {
         const int i = I0 + e % w, j = J0 - 3 + e / w;
         if (i > I1 + 1 || j > J1 + 3) continue;
         auto line = [&](int ii) -> double { int i2 = ii, jj = j; if (face) corner_map(g, 1, i2, jj); return Q[qe(i2, jj)]; };
@@ -274,7 +285,7 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
       } }
     TPF_SYNC();
     { constexpr int n = TPD_W * TPD_QH;             // q_j values
-      TPF_LOOP(e, n) {
+      TPD_LOOP(e, n) {
         const int i = I0 + e % TPD_W, j = J0 - 3 + e / TPD_W;
         if (i > I1 || j > J1 + 3) continue;
         QG[qe(i, j)] = (Q[qe(i, j)] * MET(area, i, j) + a.xfx.t[at(i, j)] * F2[f2e(i, j)] - a.xfx.t[at(i + 1, j)] * F2[f2e(i + 1, j)]) / a.rax.t[at(i, j)];
@@ -282,7 +293,7 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
     TPF_SYNC();
     auto FY = [&](int i, int m) { return FA[fae(i, m)]; };
     { constexpr int n = TPD_W * (TPD_H + 1);        // own y-faces: Courant-number and mass-flux adjoints of the outer sweep
-      TPF_LOOP(e, n) {
+      TPD_LOOP(e, n) {
         const int i = I0 + e % TPD_W, j = J0 + e / TPD_W;
         if (i > I1 || !(j <= J1 || (lasty && j == J1 + 1))) continue;
         const double fo = FY(i, j), fyad = a.fy.p[at(i, j)];
@@ -296,7 +307,7 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
     auto cl = [](int m, int n1) { return m < 1 ? 1 : (m > n1 ? n1 : m); };
     if (iord == 2) {                                // edge-value adjoints of the outer sweep, rows J0-4 .. J1+5
       constexpr int n = TPD_QW * TPD_AH;
-      TPF_LOOP(e, n) {
+      TPD_LOOP(e, n) {
         const int i = I0 - 3 + e % TPD_QW, x = J0 - 6 + e / TPD_QW;
         double s = 0.;
         if (x >= J0 - 4 && x <= J1 + 5 && i >= 1 && i <= nx && i <= I1 + 3) {
@@ -307,7 +318,7 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
       } }
     TPF_SYNC();
     { constexpr int n = TPD_NQ;                     // gj = q_j_ad / ra_x on the owned rows; own cells: ra_x_ad, the area term of q_ad
-      TPF_LOOPU(e, u, n, EQ) {
+      TPD_LOOPU(e, u, n, EQ) {
         const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW;
         double s = 0., acc = 0.;
         if (j >= GJ0 && j <= GJ1 && i >= 1 && i <= nx && i <= I1 + 3) {
@@ -327,12 +338,12 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
           s = s / rx;
           if (own) { a.rax.p[at(i, j)] = rold - QG[e] * s; acc = ar * s; }
         }
-        qacc[u] = acc;
+        if (TPD_QACC_DIRECT) { if (acc != 0.) a.q.p[at(i, j)] += acc; } else qacc[u] = acc;
         QG[e] = s;
       } }
     TPF_SYNC();
     { constexpr int w = TPD_QW - 1, n = w * TPD_QH; // fx2_ad on columns I0-2 .. I1+3 of the owned rows, in place of the values; own x-faces: xfx_ad, mx_ad (inner part)
-      TPF_LOOP(e, n) {
+      TPD_LOOP(e, n) {
         const int m = I0 - 2 + e % w, j = J0 - 3 + e / w;
         double s = 0.;
         if (j >= GJ0 && j <= GJ1 && m >= 1 && m <= nx + 1 && m <= I1 + 3) {
@@ -352,7 +363,7 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
     auto FX2 = [&](int m, int j) { return (m >= I0 - 2 && m <= I1 + 3) ? F2[f2e(m, j)] : 0.; };
     if (iord == 2) {                                // edge-value adjoints of the inner sweep, columns I0-4 .. I1+5 of the owned rows
       constexpr int n = TPD_AW * TPD_QH;
-      TPF_LOOP(e, n) {
+      TPD_LOOP(e, n) {
         const int x = I0 - 5 + e % TPD_AW, j = J0 - 3 + e / TPD_AW;
         double s = 0.;
         if (j >= GJ0 && j <= GJ1 && x >= I0 - 4 && x <= I1 + 5) {
@@ -363,9 +374,9 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
       } }
     TPF_SYNC();
     { constexpr int n = TPD_NQ;                     // transposed inner sweep: q_ad of the owned cells
-      TPF_LOOPU(e, u, n, EQ) {
+      TPD_LOOPU(e, u, n, EQ) {
         const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW;
-        const double acc = qacc[u];
+        const double acc = TPD_QACC_DIRECT ? 0. : qacc[u];
         if (i < GI0 || i > GI1 || j < GJ0 || j > GJ1 || corner_cell(i, j)) continue;
         const double qold = a.q.p[at(i, j)];
         const MetX da{c.m.dxa, c, tile, j};
@@ -383,7 +394,7 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
         a.q.p[at(i, j)] = qold + (acc + s);
       } }
     { constexpr int w = TPD_W + 1, n = w * TPD_QH;  // own x-faces: crx_ad of the inner sweep
-      TPF_LOOP(e, n) {
+      TPD_LOOP(e, n) {
         const int m = I0 + e % w, j = J0 - 3 + e / w;
         if (j < GJ0 || j > GJ1 || j > J1 + 3 || !(m <= I1 || (lastx && m == I1 + 1))) continue;
         const double f = F2[f2e(m, j)];

@@ -41,7 +41,11 @@ FV3LM_LINK void run_tp_outer_ad(Exec& ex, const TpFusedArgs& a0, const Ctx& c);
 #else
 #define TPF_SYNC() __syncthreads()
 // constant trip count, unrolled: the global loads of a thread's elements of a phase are issued together
+#ifdef FV3LM_TPF_NOUNROLL      /* experiment: real loops, a quarter of the code */
+#define TPF_LOOP(e, n) _Pragma("nounroll") for (int e = tid; e < (n); e += NTH)
+#else
 #define TPF_LOOP(e, n) _Pragma("unroll") for (int e = tid; e < (n); e += NTH)
+#endif
 // the same with the slot index u of a per-thread register array (constant trip count E = ceil(n / NTH): static indices after unrolling)
 #define TPF_LOOPU(e, u, n, E) _Pragma("unroll") for (int u = 0; u < (E); ++u) if (const int e = tid + u * NTH; e < (n))
 #endif
@@ -127,7 +131,11 @@ DEV void tp_fused_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int
 
   // Tangent mode, device build: operands of the NEXT phase are fetched into registers before the barrier that ends the current one --
   // with one 1024-thread block per CU (107 KB of LDS) nothing else hides the HBM latency behind a barrier.
-  constexpr bool PRE = NTH > 1 && !TRAJ && !std::is_same<T, double>::value;      // the nonlinear kernel runs three blocks per CU: they hide each other's latency, and the registers would cost it one
+#ifdef FV3LM_TPF_NOUNROLL
+  constexpr bool PRE = false;
+#else
+  constexpr bool PRE = NTH > 1 && !TRAJ && !std::is_same<T, double>::value;
+#endif      // the nonlinear kernel runs three blocks per CU: they hide each other's latency, and the registers would cost it one
   constexpr int N2A = TPF_QW * (TPF_H + 1), N2B = (TPF_W + 1) * TPF_QH, N3A = TPF_QW * TPF_H, N3B = TPF_W * TPF_QH;
   constexpr int E2A = PRE ? (N2A + NTH - 1) / NTH : 1, E2B = PRE ? (N2B + NTH - 1) / NTH : 1, E3A = PRE ? (N3A + NTH - 1) / NTH : 1, E3B = PRE ? (N3B + NTH - 1) / NTH : 1;
   T cy_pre[E2A], cx_pre[E2B], y0_pre[E3A], y1_pre[E3A], ry_pre[E3A], x0_pre[E3B], x1_pre[E3B], rx_pre[E3B];
