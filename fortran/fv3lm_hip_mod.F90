@@ -44,6 +44,10 @@ module fv3lm_hip_mod
     integer(c_int) :: nx, ny, npz, ntile, nq, n_split, k_split
     integer(c_int) :: face   ! 1: every resident tile is a whole cube face (edge/corner branches on); 0: one edge-free periodic tile
     real(c_double) :: dt
+    ! sub-face tiles (layout > 1 x 1): cells per edge of a whole face (0: the tile is the face) and, per resident tile, (is, js) in the global
+    ! indices of its face (c_null_ptr: (1, 1)); nx, ny are then the cells of a tile
+    integer(c_int) :: nface = 0, pad_ = 0
+    type(c_ptr) :: tile_ij0 = c_null_ptr
   end type fv3lm_dims
 
   type :: fv3lm_hip_type

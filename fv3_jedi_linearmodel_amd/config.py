@@ -30,7 +30,8 @@ class Options(C.Structure):
 
 
 class Dims(C.Structure):
-    _fields_ = [(n, C.c_int) for n in "nx ny npz ntile nq n_split k_split face".split()] + [("dt", C.c_double)]
+    _fields_ = ([(n, C.c_int) for n in "nx ny npz ntile nq n_split k_split face".split()] + [("dt", C.c_double)]
+                + [("nface", C.c_int), ("pad_", C.c_int), ("tile_ij0", C.POINTER(C.c_int))])
 
 
 def default_options(**kw):

@@ -99,6 +99,7 @@ struct GeopkFn {
 };
 inline void run_geopk(Exec& ex, int mode, const GeopkArgs& a0) {
   GeopkArgs a = a0;
+  if (a.hs) a.hs += ex.cls_off;      // surface geopotential of the class's first tile (one plane per tile)
   a.delp = ex.sh(a.delp); a.pt = ex.sh(a.pt); a.pe = ex.sh(a.pe); a.peln = ex.sh(a.peln); a.pk = ex.sh(a.pk); a.gz = ex.sh(a.gz); a.pkz = ex.sh(a.pkz);
   // algorithmic bytes: delp, pt in; pe, peln, pk, gz (+pkz) out; x2 for TL; adjoint reads/updates the same set
   const double cells = double(a.R.i1 - a.R.i0 + 1) * (a.R.j1 - a.R.j0 + 1) * a.g.ntile * a.g.npz;

@@ -109,21 +109,29 @@ template <int N> HD DualV<N> combine(const DualV<N>& a, const DualV<N>& b) { Dua
 template <int N> HD void set_val(DualV<N>& a, double x) { a.v = x; }
 
 // ------------------------------------------------------------------ geometry
-// All 2-D planes share one padded index map: (isd:ied+1, jsd:jed+1), isd = 1-ng, ng = 3.
+// All 2-D planes share one padded index map: (isd:ied+1, jsd:jed+1), isd = is-ng, ng = 3.
+// Indices are the reference's GLOBAL face indices: a tile is the window is..ie x js..je of a face of nx x ny cells (the whole face:
+// is = js = 1, ie = nx; a sub-face tile of `layout` > 1x1, fv_control_nlm.F90:556: any window).  Every `is .EQ. 1`, `i .EQ. npx`, corner
+// test of the reference compares global indices with nx, ny; storage and loops use the window.
 struct Geom {
-  int nx, ny, ng, npz, ntile;
-  int face;            // 1: every tile is a whole cube face (is=1, ie=npx-1: edge and corner branches on)
+  int nx, ny;          // cells per FACE edge (npx-1, npy-1); the doubly-periodic tile: the tile itself
+  int ng, npz, ntile;
+  int face;            // 1: tiles of cube faces (edge and corner branches where a tile touches a cube edge)
+  int i0 = 1, j0 = 1;  // is, js of the tile(s) the launch covers (one class of resident tiles at a time: dycore.h set_class)
+  int tx = 0, ty = 0;  // cells of a tile (ie-is+1, je-js+1)
   int pi, pj;          // padded plane dims
   int plane;           // pi*pj
-  HD int idx(int i, int j) const { return (j + ng - 1) * pi + (i + ng - 1); }   // local i,j (1-based)
-  HD int is() const { return 1; }
-  HD int ie() const { return nx; }
-  HD int js() const { return 1; }
-  HD int je() const { return ny; }
-  HD int isd() const { return 1 - ng; }
-  HD int ied() const { return nx + ng; }
-  HD int jsd() const { return 1 - ng; }
-  HD int jed() const { return ny + ng; }
+  HD int idx(int i, int j) const { return (j - j0 + ng) * pi + (i - i0 + ng); }   // global i, j
+  HD int is() const { return i0; }
+  HD int ie() const { return i0 + tx - 1; }
+  HD int js() const { return j0; }
+  HD int je() const { return j0 + ty - 1; }
+  HD int isd() const { return i0 - ng; }
+  HD int ied() const { return i0 + tx - 1 + ng; }
+  HD int jsd() const { return j0 - ng; }
+  HD int jed() const { return j0 + ty - 1 + ng; }
+  HD bool in_plane(int i, int j) const { return i >= isd() && i <= ied() + 1 && j >= jsd() && j <= jed() + 1; }
+  HD bool whole_face() const { return i0 == 1 && j0 == 1 && tx == nx && ty == ny; }
 };
 
 // A 3-D field: trajectory and perturbation(TL)/adjoint(AD) buffers, [ntile*nk][pj][pi].

@@ -53,7 +53,7 @@ struct DampTPass {
     const int tile = z / g.npz, k = 1 + z % g.npz;
     const int nord = a.lev[k - 1].nord, nt = nord - pass;
     if (nt < 0) return;
-    if (i < 1 - nt || i > g.nx + 1 + nt || j < 1 - nt || j > g.ny + 1 + nt) return;
+    if (i < g.is() - nt || i > g.ie() + 1 + nt || j < g.js() - nt || j > g.je() + 1 + nt) return;
     const bool fill = nt != 0 && g.face;
     const size_t base = (size_t)z * g.plane, mb = (size_t)tile * g.plane;
     const int npx = g.nx + 1, npy = g.ny + 1;
@@ -137,10 +137,10 @@ inline void run_damp_t(Exec& ex, const DampTArgs& a, int max_nord) {
   for (int pass = 1; pass <= max_nord; ++pass) {
     const int nt = max_nord - pass;
     DampTPass p{a, pass, pass == 1 ? a.divgd : (pass & 1) ? a.s2 : a.s1, (pass & 1) ? a.s1 : a.s2};
-    for_points(ex, Rect{1 - nt, g.nx + 1 + nt, 1 - nt, g.ny + 1 + nt}, nz, p, "DampT.pass", 0.);
+    for_points(ex, Rect{g.is() - nt, g.ie() + 1 + nt, g.js() - nt, g.je() + 1 + nt}, nz, p, "DampT.pass", 0.);
   }
   DampTFinal f{a};
-  for_points(ex, Rect{1, g.nx + 1, 1, g.ny + 1}, nz, f, "DampT.final", 0.);
+  for_points(ex, Rect{g.is(), g.ie() + 1, g.js(), g.je() + 1}, nz, f, "DampT.final", 0.);
 }
 
 // ---- del6_vt_flux of the trajectory with nord_v = 2 (sw_core_tlm.F90:3719-3801), values only: the two inner Laplacians, corner halo

@@ -149,10 +149,19 @@ struct Op {
   std::vector<Rect> ad_out_rect;               // where the op writes each ad_out in the forward direction (empty: unknown -> whole plane)
   std::vector<double*> ad_store;               // adjoints the op's adjoint STORES over everything read later (hand-written fused adjoints)
   std::string name;                            // stage name (diagnostics)
+  bool global = false;                         // an exchange: runs once over all resident tiles, between the classes' segments
   Op() = default;
   Op(std::string g_, std::function<void(Exec&, int)> f_, bool acc_ = false) : group(std::move(g_)), fn(std::move(f_)), accum(acc_) {}
 };
 typedef std::vector<Op> Program;
+// One program per tile class (Dycore::classes): the builders run once per class, in that class's global face indices, and leave the same
+// sequence of exchanges (Op::global) in each.  Converts to the program of the class being built / run.
+struct Progs {
+  std::vector<Program> c; const int* cur = nullptr;
+  Program& now() { return c[(size_t)(*cur < 0 ? 0 : *cur)]; }
+  operator Program&() { return now(); }
+  void clear() { now().clear(); }
+};
 
 struct Dycore {
   Geom g{}; Options opt; Exec ex; Ctx ctx{};
@@ -163,7 +172,14 @@ struct Dycore {
   double* hs_dev = nullptr;
   Arena state, work;
   std::map<std::string, Fld> F;       // field registry (debug/test access + driver)
-  Program acoustic;                   // one acoustic step
+  // Tile classes: runs of resident tiles with the same window of their face (one class when every tile is a whole face).
+  struct TileClass { int t0, n, i0, j0; };
+  std::vector<TileClass> classes;
+  int ntile_all = 0, cur_cls = -1; Metrics m_all{};
+  bool subtile = false;               // some resident tile is a window of its face (fv_control_nlm.F90:556 layout > 1 x 1)
+  void set_class(int c);              // c = -1: all tiles, no shift (exchanges, whole-field copies)
+  template <class F_> void each_class(const F_& fn) { for (int c = 0; c < (int)classes.size(); ++c) { set_class(c); fn(); } set_class(-1); }
+  Progs acoustic;                     // one acoustic step
   double* ckpt = nullptr;             // [n_split*k_split][step state: u v delp pt (+ w delz zh)]
   std::vector<const char*> st_in, st_out;   // per-step prognostic fields and the work buffers the step writes them to
   size_t ck_stride = 0;
@@ -193,9 +209,14 @@ struct Dycore {
     if (it == F.end()) { set_sticky(std::string("internal error: unknown field ") + n); static Fld none; none = Fld{}; return none; }
     return it->second;
   }
-  Fld S(const char* n, int nk) { (nk == g.npz ? nS3 : nS3p)++; Fld x = state.take((size_t)g.ntile * nk * g.plane, nk); F[n] = x; return x; }
+  bool reuse_fields = false;          // building the program of a class after the first: the fields exist
+  Fld S(const char* n, int nk) {
+    if (reuse_fields) { auto it = F.find(n); if (it != F.end()) return it->second; }
+    (nk == g.npz ? nS3 : nS3p)++; Fld x = state.take((size_t)ntile_all * nk * g.plane, nk); F[n] = x; return x; }
   int nW3 = 0, nW3p = 0, nS3 = 0, nS3p = 0;
-  Fld W(const char* n, int nk) { (nk == g.npz ? nW3 : nW3p)++; Fld x = work.take((size_t)g.ntile * nk * g.plane, nk); F[n] = x; return x; }
+  Fld W(const char* n, int nk) {
+    if (reuse_fields) { auto it = F.find(n); if (it != F.end()) return it->second; }
+    (nk == g.npz ? nW3 : nW3p)++; Fld x = work.take((size_t)ntile_all * nk * g.plane, nk); F[n] = x; return x; }
 
   Rect R(int i0, int i1, int j0, int j1) const { return Rect{i0, i1, j0, j1}; }
   static Rect empty_in(const Rect& r) { return Rect{r.i0 + 1, r.i0, r.j0 + 1, r.j0}; }   // contains nothing, leaves the union with r alone
@@ -207,7 +228,7 @@ struct Dycore {
   template <class D>
   void add_face(Program& P, const char* grp, const D& s, int W) {
     if (!g.face) { add(P, grp, Edged<D, false>(s)); return; }
-    const int lo = 1 + W, hi = g.nx - W, BIG = 1 << 20;
+    const int lo = 1 + W, hi = g.nx - W, BIG = 1 << 20;       // global face indices: a tile away from every cube edge gets the bulk launch only
     const Rect regs[5] = {{lo, hi, lo, hi}, {-BIG, BIG, -BIG, lo - 1}, {-BIG, BIG, hi + 1, BIG}, {-BIG, lo - 1, lo, hi}, {hi + 1, BIG, lo, hi}};
     // program order: strips first, bulk last -- the backward sweep then runs the bulk launch first, which is the one that can
     // store the input adjoints instead of accumulating them (plan_adjoint); the five launches are independent of each other
@@ -275,7 +296,7 @@ struct Dycore {
       self->halo(mode, kind, f0, f1);
     }};
     op.ad_in = {f0.p, f1.p};          // the adjoint exchange moves halo adjoints onto their source elements: both must hold defined values
-    op.name = "halo";
+    op.name = "halo"; op.global = true;
     P.push_back(op);
   }
   // Exchange beside compute.  A halo exchange whose field no launch touches between its producer and its first consumer is split
@@ -315,7 +336,7 @@ struct Dycore {
     Dycore* self = this;
     Op a{group, [self, kind, f0, f1, win](Exec&, int mode) { self->halo_window(mode, mode != MODE_AD, win, kind, f0, f1); }};
     Op b{group, [self, kind, f0, f1, win](Exec&, int mode) { self->halo_window(mode, mode == MODE_AD, win, kind, f0, f1); }};
-    a.ad_in = b.ad_in = {f0.p, f1.p}; a.name = "halo_start"; b.name = "halo_join";
+    a.ad_in = b.ad_in = {f0.p, f1.p}; a.name = "halo_start"; b.name = "halo_join"; a.global = b.global = true;
     P.insert(P.begin() + at, a);
     P.push_back(b);
   }
@@ -337,7 +358,7 @@ struct Dycore {
   // preset: work arrays whose adjoint the driver sets before the backward pass (the step outputs u_o .. receive the incoming adjoint).
   std::vector<std::pair<double*, size_t>> plan_adjoint(Program& P, const Arena& A, const std::vector<double*>& preset = {}) {
     std::map<double*, size_t> size;
-    for (auto& kv : F) if (kv.second.p >= A.p && kv.second.p < A.p + A.cap) size[kv.second.p] = (size_t)g.ntile * kv.second.nk * g.plane;
+    for (auto& kv : F) if (kv.second.p >= A.p && kv.second.p < A.p + A.cap) size[kv.second.p] = (size_t)ntile_all * kv.second.nk * g.plane;
     auto inA = [&](double* q_) { return q_ && q_ >= A.p && q_ < A.p + A.cap; };
     std::set<double*> written(preset.begin(), preset.end()), zero;
     // A stored adjoint must be defined wherever somebody reads it later in the sweep: where its producer wrote the field (the
@@ -394,7 +415,7 @@ struct Dycore {
   // fv_tp_2d as a stage sequence (tp_core_tlm.F90:83-236): q -> fx, fy.  mx/my = xfx/yfx or mass fluxes.
   void build_tp(Program& P, const char* grp, const std::string& pre, Fld q, Fld crx, Fld cry, Fld xfx, Fld yfx, Fld rax,
                 Fld ray, Fld mx, Fld my, Fld mass, int hsel, int dsel, bool use_mass, Fld fx, Fld fy, int nk = 0, const Fld* acc4 = nullptr) {
-    const int is = 1, ie = g.nx, js = 1, je = g.ny, isd = g.isd(), ied = g.ied(), jsd = g.jsd(), jed = g.jed(), npz = nk ? nk : g.npz;
+    const int is = g.is(), ie = g.ie(), js = g.js(), je = g.je(), isd = g.isd(), ied = g.ied(), jsd = g.jsd(), jed = g.jed(), npz = nk ? nk : g.npz;
     // nonlinear and tangent modes: the whole routine as one LDS-tiled launch (tpfused.h); the staged launches below then serve the
     // adjoint only (FV3LM_TP_FUSED=0 runs them in every mode -- the two forms agree bit for bit)
     const char* fenv = std::getenv("FV3LM_TP_FUSED");
@@ -417,26 +438,24 @@ struct Dycore {
     auto ppm_y = [&](Fld qq, Fld out, Rect r, int cdir) {
       TpPpmY_<false> a; a.in[0] = qq; a.in[1] = cry; a.out[0] = out; a.k1 = npz; a.hsel = hsel;
       if (!g.face) { a.orect[0] = r; add(P, grp, a); return; }
-      const int npy = g.ny + 1;
-      a.orect[0] = R(r.i0, r.i1, 4, npy - 3);
+      const int npy = g.ny + 1;          // global: the three flux points next to a cube edge take the one-sided edge values
+      a.orect[0] = isect(r, R(r.i0, r.i1, 4, npy - 3));
       TpPpmY_<true> e; e.in[0] = qq; e.in[1] = cry; e.out[0] = out; e.k1 = npz; e.hsel = hsel; e.cdir = cdir;
       std::vector<TpPpmY_<true>> ev;
-      e.orect[0] = R(r.i0, r.i1, r.j0, 3); ev.push_back(e);
-      e.orect[0] = R(r.i0, r.i1, npy - 2, r.j1); ev.push_back(e);
+      for (const Rect& er : {isect(r, R(r.i0, r.i1, r.j0, 3)), isect(r, R(r.i0, r.i1, npy - 2, r.j1))}) if (!is_empty(er)) { e.orect[0] = er; ev.push_back(e); }
       add_multi(P, grp, ev);
-      add(P, grp, a);          // bulk last: first in the backward sweep (plan_adjoint)
+      if (!is_empty(a.orect[0])) add(P, grp, a);          // bulk last: first in the backward sweep (plan_adjoint)
     };
     auto ppm_x = [&](Fld qq, Fld out, Rect r, int cdir) {
       TpPpmX_<false> a; a.in[0] = qq; a.in[1] = crx; a.out[0] = out; a.k1 = npz; a.hsel = hsel;
       if (!g.face) { a.orect[0] = r; add(P, grp, a); return; }
       const int npx = g.nx + 1;
-      a.orect[0] = R(4, npx - 3, r.j0, r.j1);
+      a.orect[0] = isect(r, R(4, npx - 3, r.j0, r.j1));
       TpPpmX_<true> e; e.in[0] = qq; e.in[1] = crx; e.out[0] = out; e.k1 = npz; e.hsel = hsel; e.cdir = cdir;
       std::vector<TpPpmX_<true>> ev;
-      e.orect[0] = R(r.i0, 3, r.j0, r.j1); ev.push_back(e);
-      e.orect[0] = R(npx - 2, r.i1, r.j0, r.j1); ev.push_back(e);
+      for (const Rect& er : {isect(r, R(r.i0, 3, r.j0, r.j1)), isect(r, R(npx - 2, r.i1, r.j0, r.j1))}) if (!is_empty(er)) { e.orect[0] = er; ev.push_back(e); }
       add_multi(P, grp, ev);
-      add(P, grp, a);
+      if (!is_empty(a.orect[0])) add(P, grp, a);
     };
     ppm_y(q, fy2, R(isd, ied, js, je + 1), 2);
     TpQi b; b.in[0] = q; b.in[1] = fy2; b.in[2] = yfx; b.in[3] = ray; b.out[0] = q_i; b.orect[0] = R(isd, ied, js, je); b.k1 = npz;
@@ -536,7 +555,7 @@ struct Dycore {
   }
   // a2b_ord4 (a2b_edge_tlm.F90:48-542): q (nk levels) -> qb on is..ie+1, js..je+1
   void build_a2b(Program& P, const char* grp, const std::string& pre, Fld q, Fld qb, int nk) {
-    const int is = 1, ie = g.nx, js = 1, je = g.ny;
+    const int is = g.is(), ie = g.ie(), js = g.js(), je = g.je();
     Fld qx = W((pre + "_qx").c_str(), nk), qy = W((pre + "_qy").c_str(), nk);
     const int npx = g.nx + 1, npy = g.ny + 1;
     A2bA_<false> a; a.in[0] = q; a.out[0] = qx; a.out[1] = qy; a.k1 = nk;
@@ -546,58 +565,126 @@ struct Dycore {
       b.orect[0] = R(is, ie + 1, js, je + 1); add(P, grp, b);
       return;
     }
-    // face: the 4-point formulas away from the edges, the edge formulas on strips two points wide (column strips run
-    // with the wave along j, exec.h strip_tr)
-    a.orect[0] = R(3, npx - 2, 1, npy - 1); a.orect[1] = R(1, npx - 1, 3, npy - 2);
+    // faces: the 4-point formulas away from the cube edges, the edge formulas on strips two points wide (column strips run with the wave
+    // along j, exec.h strip_tr).  Global indices: a sub-face tile takes what falls into its window -- rows / columns beyond a cube edge
+    // are not interpolated (the edge formulas stand in), the ones beyond an interior tile boundary are (like the periodic tile).
+    const Rect qxr = R(is, ie + 1, std::max(1, js - 2), std::min(npy - 1, je + 2)), qyr = R(std::max(1, is - 2), std::min(npx - 1, ie + 2), js, je + 1);
+    a.orect[0] = isect(qxr, R(3, npx - 2, qxr.j0, qxr.j1)); a.orect[1] = isect(qyr, R(qyr.i0, qyr.i1, 3, npy - 2));
+    const bool a0 = !is_empty(a.orect[0]), a1 = !is_empty(a.orect[1]);
+    if (a0 && !a1) a.orect[1] = empty_in(a.orect[0]);
+    if (a1 && !a0) a.orect[0] = empty_in(a.orect[1]);
     A2bA_<true> ae; ae.in[0] = q; ae.out[0] = qx; ae.out[1] = qy; ae.k1 = nk;
     std::vector<A2bA_<true>> av;
     for (int e = 0; e < 4; ++e) {
-      const Rect r = e == 0 ? R(1, 2, 1, npy - 1) : e == 1 ? R(npx - 1, npx, 1, npy - 1) : e == 2 ? R(1, npx - 1, 1, 2) : R(1, npx - 1, npy - 1, npy);
+      const Rect r = e == 0 ? isect(qxr, R(1, 2, qxr.j0, qxr.j1)) : e == 1 ? isect(qxr, R(npx - 1, npx, qxr.j0, qxr.j1)) : e == 2 ? isect(qyr, R(qyr.i0, qyr.i1, 1, 2)) : isect(qyr, R(qyr.i0, qyr.i1, npy - 1, npy));
+      if (is_empty(r)) continue;
       ae.orect[e < 2 ? 0 : 1] = r; ae.orect[e < 2 ? 1 : 0] = empty_in(r); av.push_back(ae);
     }
     add_multi(P, grp, av);
-    add(P, grp, a);            // bulk last: first in the backward sweep (plan_adjoint)
-    b.orect[0] = R(3, npx - 2, 3, npy - 2);
+    if (a0 || a1) add(P, grp, a);            // bulk last: first in the backward sweep (plan_adjoint)
+    const Rect qbr = R(is, ie + 1, js, je + 1);
+    b.orect[0] = isect(qbr, R(3, npx - 2, 3, npy - 2));
     A2bB_<true> be; be.in[0] = qx; be.in[1] = qy; be.in[2] = q; be.out[0] = qb; be.k1 = nk;
     std::vector<A2bB_<true>> bv;
     for (int e = 0; e < 4; ++e) {
-      be.orect[0] = e == 0 ? R(1, npx, 1, 2) : e == 1 ? R(1, npx, npy - 1, npy) : e == 2 ? R(1, 2, 3, npy - 2) : R(npx - 1, npx, 3, npy - 2);
-      bv.push_back(be);
+      const Rect r = isect(qbr, e == 0 ? R(1, npx, 1, 2) : e == 1 ? R(1, npx, npy - 1, npy) : e == 2 ? R(1, 2, 3, npy - 2) : R(npx - 1, npx, 3, npy - 2));
+      if (is_empty(r)) continue;
+      be.orect[0] = r; bv.push_back(be);
     }
     add_multi(P, grp, bv);
-    add(P, grp, b);
+    if (!is_empty(b.orect[0])) add(P, grp, b);
   }
 
   void build_acoustic();
   bool init(int nx, int ny, int npz, int ntile, int face, int nq_, double bdt_, int n_split_, int k_split_, const Options& o,
-            const double* const* metrics_host, double da_min, double da_min_c, const double* phis_host);
+            const double* const* metrics_host, double da_min, double da_min_c, const double* phis_host, int nface = 0, const int* ij0 = nullptr);
   void destroy();
 
-  void run_group(const Program& P, const char* group, int mode, bool skip_accum = false);
+  void run_group(Progs& P, const char* group, int mode, bool skip_accum = false);
   void zero_work_adjoint() { dev_zero(ex, work.p, work.used * 8); }
   void dyn_core(int mode);
 };
 
-inline void Dycore::run_group(const Program& P, const char* group, int mode, bool skip_accum) {
+// One pass over a program.  The classes' programs hold the same exchanges in the same order; between two exchanges every class runs its
+// own launches (any order: they touch disjoint tiles), then the exchange runs once over all tiles.  Adjoint: the same backwards.
+inline void Dycore::run_group(Progs& PS, const char* group, int mode, bool skip_accum) {
   const bool all = (group == nullptr) || (group[0] == 0);
   ex.skip_accum = skip_accum;
-  if (mode != MODE_AD) {
-    for (const Op& op : P) if ((all || op.group == group) && !(skip_accum && op.accum) && ((op.modes >> mode) & 1u)) op.fn(ex, mode);
-  } else {
-    for (auto it = P.rbegin(); it != P.rend(); ++it) if ((all || it->group == group) && ((it->modes >> mode) & 1u)) it->fn(ex, mode);
+  const int nc = (int)PS.c.size();
+  auto take = [&](const Op& op) { return (all || op.group == group) && !(mode != MODE_AD && skip_accum && op.accum) && ((op.modes >> mode) & 1u); };
+  if (nc == 1) {
+    set_class(0);
+    const Program& P = PS.c[0];
+    if (mode != MODE_AD) { for (const Op& op : P) if (take(op)) { if (op.global) set_class(-1); op.fn(ex, mode); if (op.global) set_class(0); } }
+    else for (auto it = P.rbegin(); it != P.rend(); ++it) if (take(*it)) { if (it->global) set_class(-1); it->fn(ex, mode); if (it->global) set_class(0); }
+    set_class(-1);
+    ex.skip_accum = false;
+    return;
   }
+  // segment boundaries: positions of the global ops in each class's program
+  std::vector<std::vector<size_t>> gl(nc);
+  for (int c = 0; c < nc; ++c) for (size_t n = 0; n < PS.c[c].size(); ++n) if (PS.c[c][n].global) gl[c].push_back(n);
+  for (int c = 1; c < nc; ++c) if (gl[c].size() != gl[0].size()) { set_sticky("internal error: the tile classes' programs hold different exchange sequences"); ex.skip_accum = false; return; }
+  const size_t nseg = gl[0].size() + 1;
+  auto seg = [&](int c, size_t sg, size_t& a, size_t& b) { a = sg == 0 ? 0 : gl[c][sg - 1] + 1; b = sg < gl[c].size() ? gl[c][sg] : PS.c[c].size(); };
+  if (mode != MODE_AD) {
+    for (size_t sg = 0; sg < nseg; ++sg) {
+      for (int c = 0; c < nc; ++c) { size_t a, b; seg(c, sg, a, b); set_class(c); for (size_t n = a; n < b; ++n) if (take(PS.c[c][n])) PS.c[c][n].fn(ex, mode); }
+      if (sg < gl[0].size()) { const Op& op = PS.c[0][gl[0][sg]]; set_class(-1); if (take(op)) op.fn(ex, mode); }
+    }
+  } else {
+    for (size_t sg = nseg; sg-- > 0;) {
+      if (sg < gl[0].size()) { const Op& op = PS.c[0][gl[0][sg]]; set_class(-1); if (take(op)) op.fn(ex, mode); }
+      for (int c = 0; c < nc; ++c) { size_t a, b; seg(c, sg, a, b); set_class(c); for (size_t n = b; n-- > a;) if (take(PS.c[c][n])) PS.c[c][n].fn(ex, mode); }
+    }
+  }
+  set_class(-1);
   ex.skip_accum = false;
+}
+
+inline void Dycore::set_class(int c) {
+  cur_cls = c;
+  g.ntile = ntile_all; g.i0 = 1; g.j0 = 1; ctx.m = m_all; ex.cls_off = 0;
+  if (c >= 0 && c < (int)classes.size()) {
+    const TileClass& k = classes[(size_t)c];
+    g.ntile = k.n; g.i0 = k.i0; g.j0 = k.j0;
+    const size_t op = (size_t)k.t0 * g.plane;
+    Metrics& M = ctx.m;
+    const double** slots[] = {&M.area, &M.rarea, &M.rarea_c, &M.dx, &M.dy, &M.dxa, &M.dya, &M.dxc, &M.dyc, &M.rdx, &M.rdy, &M.rdxa,
+                              &M.rdya, &M.rdxc, &M.rdyc, &M.cosa, &M.sina, &M.rsina, &M.cosa_u, &M.cosa_v, &M.cosa_s, &M.sina_u,
+                              &M.sina_v, &M.rsin_u, &M.rsin_v, &M.rsin2, &M.f0, &M.fC, &M.del6_u, &M.del6_v, &M.divg_u, &M.divg_v};
+    for (auto sl : slots) *sl += op;
+    for (int n = 1; n <= 9; ++n) { M.sin_sg[n] += op; M.cos_sg[n] += op; }
+    if (M.edge) M.edge += (size_t)k.t0 * 4 * g.pj;
+    if (M.ecorner) M.ecorner += (size_t)k.t0 * 12;
+    ex.cls_off = op;
+  }
+  ctx.g = g;
 }
 
 inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, double bdt_, int n_split_, int k_split_,
                          const Options& o, const double* const* metrics_host, double da_min, double da_min_c,
-                         const double* phis_host) {
-  g.nx = nx; g.ny = ny; g.ng = 3; g.npz = npz; g.ntile = ntile; g.face = face ? 1 : 0; g.pi = nx + 2 * g.ng + 1; g.pj = ny + 2 * g.ng + 1;
-  g.plane = g.pi * g.pj;
+                         const double* phis_host, int nface, const int* ij0) {
+  // nx, ny: cells of a resident tile; nface: cells per face edge (0: the tile is the whole face); ij0: (is, js) of each resident tile in
+  // the global indices of its face (null: 1, 1)
+  g.tx = nx; g.ty = ny; g.nx = (face && nface > 0) ? nface : nx; g.ny = (face && nface > 0) ? nface : ny;
+  g.ng = 3; g.npz = npz; g.ntile = ntile; g.face = face ? 1 : 0; g.pi = nx + 2 * g.ng + 1; g.pj = ny + 2 * g.ng + 1;
+  g.plane = g.pi * g.pj; g.i0 = g.j0 = 1;
+  ntile_all = ntile;
+  classes.clear();
+  for (int t = 0; t < ntile; ++t) {
+    const int i0 = ij0 ? ij0[2 * t] : 1, j0 = ij0 ? ij0[2 * t + 1] : 1;
+    if (i0 < 1 || j0 < 1 || i0 + nx - 1 > g.nx || j0 + ny - 1 > g.ny) { err = "tile window outside its face"; return false; }
+    if (!classes.empty() && classes.back().i0 == i0 && classes.back().j0 == j0) classes.back().n++;
+    else classes.push_back(TileClass{t, 1, i0, j0});
+  }
+  subtile = face && !(g.tx == g.nx && g.ty == g.ny);
+  if (!subtile) for (const TileClass& k : classes) if (k.i0 != 1 || k.j0 != 1) { err = "a whole-face tile starts at (1, 1)"; return false; }
+  if (subtile && g.nx != g.ny) { err = "cube faces are square"; return false; }
   opt = o; bdt = bdt_; n_split = n_split_; k_split = k_split_; nq = nq_;
   if (nx < 8 || ny < 8 || npz < 1) { err = "tile too small (need nx,ny >= 8)"; return false; }
   if (!face && ntile != 1) { err = "ntile > 1 needs face = 1 (whole cube faces); face = 0 is the single doubly-periodic tile"; return false; }
-  if (face && nx != ny) { err = "cube faces are square: nx must equal ny"; return false; }
+  if (face && nx != ny) { err = "cube faces (and their tiles) are square: nx must equal ny"; return false; }
   if (ntile < 1) { err = "ntile < 1"; return false; }
   nh = !o.hydrostatic;
   if (o.nord_pert > 1 || o.nord_pert < 0) { err = "nord_pert in {0,1} only (the divergence damping whose tangent / adjoint is taken; the trajectory's nord may be 2 or 3 with split_damp)"; return false; }
@@ -668,6 +755,7 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
   M.da_min = da_min; M.da_min_c = da_min_c;
   edge_dev = (double*)dev_alloc((size_t)ntile * 4 * g.pj * 8); ecorner_dev = (double*)dev_alloc((size_t)ntile * 12 * 8);
   M.edge = edge_dev; M.ecorner = ecorner_dev;
+  m_all = M;
   hs_dev = (double*)dev_alloc(np * 8);
   if (phis_host) h2d(ex, hs_dev, phis_host, np * 8);
   ctx.g = g; ctx.lev = lev_dev; ctx.nlev = npz;
@@ -694,17 +782,26 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
     nh_tape.adj = (double*)dev_alloc((size_t)nh_tape.cap * nh_tape.stride * 8);
     nh_tape.overflow = (int*)dev_alloc(8);
   }
+  acoustic.c.assign(classes.size(), Program{}); acoustic.cur = &cur_cls;
   {   // the work arena is sized by a dry run of the builder: which fields exist depends on the options
     const size_t state_mark = state.used;
+    const std::map<std::string, Fld> F_mark = F;
     work.measure();
+    set_class(0);
     build_acoustic();
     const size_t need = work.used;
-    acoustic.clear(); n_win = 0; state.used = state_mark; nW3 = nW3p = nS3 = nS3p = 0;
+    acoustic.clear(); n_win = 0; state.used = state_mark; nW3 = nW3p = nS3 = nS3p = 0; F = F_mark;
     work.init(need);
   }
-  build_acoustic();
-  { std::vector<double*> pre; for (const char* n_ : st_out) pre.push_back(f(n_).p);
-    acoustic_zero = plan_adjoint(acoustic, work, pre); }
+  std::map<double*, size_t> zero_ranges;
+  for (int c = 0; c < (int)classes.size(); ++c) {       // one program per tile class, the fields shared
+    set_class(c); reuse_fields = c > 0; n_win = 0;
+    build_acoustic();
+    std::vector<double*> pre; for (const char* n_ : st_out) pre.push_back(f(n_).p);
+    for (auto& zr : plan_adjoint(acoustic, work, pre)) { auto it = zero_ranges.find(zr.first); if (it == zero_ranges.end() || it->second < zr.second) zero_ranges[zr.first] = zr.second; }
+  }
+  reuse_fields = false; set_class(-1);
+  acoustic_zero.assign(zero_ranges.begin(), zero_ranges.end());
   ck_stride = 0;
   for (const char* n_ : st_in) ck_stride += (size_t)f(n_).nk * np;
   ckpt = (double*)dev_alloc((size_t)n_split * k_split * ck_stride * 8);
@@ -801,7 +898,7 @@ inline void Dycore::destroy() {
 
 inline NhColArgs Dycore::nh_args(double dt_) const {
   NhColArgs a{};
-  a.g = g; a.ws = nh_ws; a.ws_stride = (size_t)g.ntile * g.plane; a.tape = nh_tape; a.hs = hs_dev; a.lev = lev_dev;
+  a.g = g; a.ws = nh_ws; a.ws_stride = (size_t)ntile_all * g.plane; a.tape = nh_tape; a.hs = hs_dev; a.lev = lev_dev;
   a.zvir = opt.zvir; a.cp_air = opt.cp_air;
   a.kord_tm = opt.kord_tm; a.kord_tr = opt.kord_tr; a.kord_wz = opt.kord_wz;
   { const char* e = std::getenv("FV3LM_NH_TAPE"); a.use_tape = (e && e[0] == '1') ? 1 : 0; }
@@ -837,7 +934,7 @@ inline bool Dycore::nh_overflow() {
 // One acoustic step (dyn_core_tlm.F90:1736-2466).  Inputs u,v,delp,pt (halos valid);
 // outputs u_o,v_o,delp_o,pt_o (halos valid) + accumulated mfx,mfy,cx,cy + pe,peln,pk,pkz.
 inline void Dycore::build_acoustic() {
-  const int is = 1, ie = g.nx, js = 1, je = g.ny, isd = g.isd(), ied = g.ied(), jsd = g.jsd(), jed = g.jed(), npz = g.npz;
+  const int is = g.is(), ie = g.ie(), js = g.js(), je = g.je(), isd = g.isd(), ied = g.ied(), jsd = g.jsd(), jed = g.jed(), npz = g.npz;
   const double dt = bdt / double(n_split) / double(k_split), dt2 = 0.5 * dt;
   Program& P = acoustic;
   // prognostic state (step input / output) and accumulators
@@ -858,7 +955,10 @@ inline void Dycore::build_acoustic() {
   { CswInterpAD s; s.in[0] = u; s.in[1] = v; s.out[0] = utmp; s.out[1] = vtmp; s.out[2] = ua; s.out[3] = va;
     s.orect[0] = R(isd, ied, js - 1, je + 1); s.orect[1] = R(is - 1, ie + 1, jsd, jed);
     s.orect[2] = s.orect[3] = R(is - 1, ie + 1, js - 1, je + 1);
-    if (g.face) for (int n = 0; n < 4; ++n) s.orect[n] = R(isd, ied, jsd, jed);   // 2-point bands + corner views reach the whole halo
+    if (g.face) {   // next to a cube edge the 2-point bands + corner views reach the whole halo; beyond an interior tile boundary: as the periodic tile
+      const int il = is == 1 ? isd : is - 1, ih = ie == g.nx ? ied : ie + 1, jl = js == 1 ? jsd : js - 1, jh = je == g.ny ? jed : je + 1;
+      s.orect[0] = R(isd, ied, jl, jh); s.orect[1] = R(il, ih, jsd, jed); s.orect[2] = s.orect[3] = R(il, ih, jl, jh);
+    }
     s.k1 = npz; add_face(P, "c_sw", s, 3); }
   Fld uc0 = W("uc0", npz), utf = W("utf", npz), vc0 = W("vc0", npz), vtf = W("vtf", npz);
   const Fld none{};
@@ -866,18 +966,23 @@ inline void Dycore::build_acoustic() {
     s.dt2 = dt2; s.k1 = npz;
     if (!g.face) {
       s.orect[0] = s.orect[1] = R(is - 1, ie + 2, js - 1, je + 1); s.orect[2] = s.orect[3] = R(is - 1, ie + 1, js - 1, je + 2); add(P, "c_sw", s);
-    } else {   // 4-point interpolation away from the edges; one-sided / edge formulas and corner views on 3-wide strips
+    } else {   // 4-point interpolation away from the cube edges; one-sided / edge formulas and corner views on 3-wide strips (global indices)
       const int npx = g.nx + 1, npy = g.ny + 1;
-      s.orect[0] = s.orect[1] = R(3, npx - 2, js - 1, je + 1); s.orect[2] = s.orect[3] = R(is - 1, ie + 1, 3, npy - 2);
+      const Rect ur = R(is - 1, ie + 2, js - 1, je + 1), vr = R(is - 1, ie + 1, js - 1, je + 2);
+      s.orect[0] = s.orect[1] = isect(ur, R(3, npx - 2, ur.j0, ur.j1)); s.orect[2] = s.orect[3] = isect(vr, R(vr.i0, vr.i1, 3, npy - 2));
+      const bool b0 = !is_empty(s.orect[0]), b2 = !is_empty(s.orect[2]);
+      if (b0 && !b2) s.orect[2] = s.orect[3] = empty_in(s.orect[0]);
+      if (b2 && !b0) s.orect[0] = s.orect[1] = empty_in(s.orect[2]);
       CswInterpC_<true> e; for (int n = 0; n < 4; ++n) { e.in[n] = s.in[n]; e.out[n] = s.out[n]; }
       e.in[4] = ua; e.in[5] = va; e.dt2 = dt2; e.k1 = npz;
       std::vector<CswInterpC_<true>> ev;
       for (int m = 0; m < 4; ++m) {
-        const Rect r = m == 0 ? R(0, 2, js - 1, je + 1) : m == 1 ? R(npx - 1, npx + 1, js - 1, je + 1) : m == 2 ? R(is - 1, ie + 1, 0, 2) : R(is - 1, ie + 1, npy - 1, npy + 1);
+        const Rect r = m == 0 ? isect(ur, R(ur.i0, 2, ur.j0, ur.j1)) : m == 1 ? isect(ur, R(npx - 1, ur.i1, ur.j0, ur.j1)) : m == 2 ? isect(vr, R(vr.i0, vr.i1, vr.j0, 2)) : isect(vr, R(vr.i0, vr.i1, npy - 1, vr.j1));
+        if (is_empty(r)) continue;
         e.orect[0] = e.orect[1] = m < 2 ? r : empty_in(r); e.orect[2] = e.orect[3] = m < 2 ? empty_in(r) : r; ev.push_back(e);
       }
       add_multi(P, "c_sw", ev);
-      add(P, "c_sw", s);       // bulk last: first in the backward sweep (plan_adjoint)
+      if (b0 || b2) add(P, "c_sw", s);       // bulk last: first in the backward sweep (plan_adjoint)
     } }
   Fld divgd = W("divgd", npz);
   if (opt.nord > 0) {
@@ -939,8 +1044,10 @@ inline void Dycore::build_acoustic() {
     const int npx = g.nx + 1, npy = g.ny + 1;
     DswWindsE se; se.in[0] = ut_a; se.in[1] = vt_a; se.in[2] = uc; se.in[3] = vc; se.out[0] = ut_e; se.out[1] = vt_e; se.k1 = npz;
     std::vector<DswWindsE> sv;
-    for (int e = 0; e < 4; ++e) {
-      const Rect r = e == 0 ? R(is - 1, ie + 2, 0, 1) : e == 1 ? R(is - 1, ie + 2, npy - 1, npy) : e == 2 ? R(0, 1, js - 1, je + 2) : R(npx - 1, npx, js - 1, je + 2);
+    for (int e = 0; e < 4; ++e) {      // the rows / columns next to a cube edge that fall into this tile's range (global indices)
+      const Rect r = e == 0 ? isect(R(is - 1, ie + 2, jsd, jed), R(is - 1, ie + 2, 0, 1)) : e == 1 ? isect(R(is - 1, ie + 2, jsd, jed), R(is - 1, ie + 2, npy - 1, npy))
+                   : e == 2 ? isect(R(isd, ied, js - 1, je + 2), R(0, 1, js - 1, je + 2)) : isect(R(isd, ied, js - 1, je + 2), R(npx - 1, npx, js - 1, je + 2));
+      if (is_empty(r)) continue;
       se.orect[e < 2 ? 0 : 1] = r; se.orect[e < 2 ? 1 : 0] = empty_in(r); sv.push_back(se);
     }
     add_multi(P, "d_sw", sv);
@@ -1023,9 +1130,9 @@ inline void Dycore::build_acoustic() {
       Op op{"d_sw", [self, wk, l1, l2](Exec& e, int) {
         const Geom& g_ = self->g;
         LapTArgs a{g_, self->ctx.m, self->lev_dev, e.sh(wk).t, e.sh(l1).t, 1};
-        for_points(e, Rect{-1, g_.nx + 2, -1, g_.ny + 2}, g_.ntile * g_.npz, LapTPass{a}, "LapT.1", 0.);
+        for_points(e, Rect{g_.is() - 2, g_.ie() + 2, g_.js() - 2, g_.je() + 2}, g_.ntile * g_.npz, LapTPass{a}, "LapT.1", 0.);
         a.src = e.sh(l1).t; a.dst = e.sh(l2).t; a.pass = 2;
-        for_points(e, Rect{0, g_.nx + 1, 0, g_.ny + 1}, g_.ntile * g_.npz, LapTPass{a}, "LapT.2", 0.);
+        for_points(e, Rect{g_.is() - 1, g_.ie() + 1, g_.js() - 1, g_.je() + 1}, g_.ntile * g_.npz, LapTPass{a}, "LapT.2", 0.);
       }};
       op.modes = (1u << MODE_NL) | (1u << MODE_TL); op.name = "LapT";
       P.push_back(op);
@@ -1100,8 +1207,9 @@ inline void Dycore::dyn_core(int mode) {
   auto zh_init = [&](int md) {
     NhColArgs a = nh_args(0.); a.f[0] = f("delz"); a.f[1] = f("zh");
     halo(md, H_CELL, f("w"));
-    if (md != MODE_AD) { run_nh_col(ex, md, a, NHC_ZH_INIT, R(1, g.nx, 1, g.ny), R(1, 0, 1, 0), "zh_init"); halo(md, H_CELL, f("zh")); }
-    else { halo(md, H_CELL, f("zh")); run_nh_col(ex, md, a, NHC_ZH_INIT, R(1, g.nx, 1, g.ny), R(1, 0, 1, 0), "zh_init"); }
+    auto cols = [&]() { each_class([&]() { NhColArgs b = a; b.g = g; run_nh_col(ex, md, b, NHC_ZH_INIT, R(g.is(), g.ie(), g.js(), g.je()), R(1, 0, 1, 0), "zh_init"); }); };
+    if (md != MODE_AD) { cols(); halo(md, H_CELL, f("zh")); }
+    else { halo(md, H_CELL, f("zh")); cols(); }
   };
   auto slot_io = [&](int a, bool save) {      // pe, peln, pk, pkz trajectory of step a <-> its slot
     double* q_ = traj_slot_p[a];

@@ -56,7 +56,7 @@ struct CmaxFn {
   HD void operator()(int i, int, int z) const {            // one thread per (i, tile, level): column over j, coalesced in i
     const int tile = z / g.npz, k = 1 + z % g.npz;
     double cm = 0.;
-    for (int j = 1; j <= g.ny; ++j) {
+    for (int j = g.js(); j <= g.je(); ++j) {
       const size_t n = (size_t)z * g.plane + g.idx(i, j);
       double ax = fabs(cx.t[n]), ay = fabs(cy.t[n]);
       double c = ax > ay ? ax : ay;
@@ -100,8 +100,8 @@ struct CompactFn {
   Geom g; double* pad; double* cmp; int nk, dir;      // dir 0: unpack (pad <- cmp, zeros outside), 1: pack (cmp <- pad)
   HD void operator()(int i, int j, int z) const {
     const size_t n = (size_t)z * g.plane + g.idx(i, j);
-    const bool in = i >= 1 && i <= g.nx && j >= 1 && j <= g.ny;
-    const size_t m = ((size_t)z * g.ny + (j - 1)) * g.nx + (i - 1);
+    const bool in = i >= g.is() && i <= g.ie() && j >= g.js() && j <= g.je();
+    const size_t m = ((size_t)z * g.ty + (j - g.j0)) * g.tx + (i - g.i0);
     if (dir == 0) pad[n] = in ? cmp[m] : 0.0;
     else if (in) cmp[m] = pad[n];
   }
@@ -112,7 +112,7 @@ inline AllReduce& allreduce_max_hook() { static AllReduce a; return a; }
 
 struct Dynamics : Dycore {
   Arena tshared, twork;
-  Program tracer_scale, tracer_pre, tracer_q, pt_in;
+  Progs tracer_scale, tracer_pre, tracer_q, pt_in;
   Fld tr_dp2;
   int cur_km = 0;                                   // k_split iteration being run (tracer checkpoints are per iteration)
   std::vector<std::vector<int>> tr_ksplt_km;        // per k_split iteration: sub-steps per level, from the forward sweep
@@ -123,10 +123,10 @@ struct Dynamics : Dycore {
   double *ak_dev = nullptr, *bk_dev = nullptr, *remap_ws = nullptr, *cmax_dev = nullptr;
   bool remap_ws_own = false;
   // non-hydrostatic vertical remap (nh.h): column operators into the staging fields, handed back to the state afterwards
-  Program remap_nh;
+  Progs remap_nh;
   Fld t_m, w_m, dz_m; std::vector<Fld> q_m;
   double* ck_nh = nullptr;     // per k_split step: delp, w, delz before the remap + ws
-  double* cknh(int km, int n) { return ck_nh + (size_t)km * (3 * n3 + (size_t)g.ntile * g.plane) + (size_t)n * n3; }
+  double* cknh(int km, int n) { return ck_nh + (size_t)km * (3 * n3 + (size_t)ntile_all * g.plane) + (size_t)n * n3; }
   void build_remap_nh();
   void remap_nh_run(int mode, int km);
   double* ck_k = nullptr;      // per-k_split checkpoints
@@ -139,15 +139,23 @@ struct Dynamics : Dycore {
   double* stage_dev = nullptr;   // compact staging buffer of the boundary copies (one field)
   // one field between the host's compact array and the device state.  which: 0 trajectory, 1 perturbation / adjoint
   void compact_in(const Fld& f, int which, const double* host) {
-    const size_t n = (size_t)g.ntile * f.nk * g.nx * g.ny;
-    if (!stage_dev) stage_dev = (double*)dev_alloc((size_t)g.ntile * (g.npz + 1) * g.nx * g.ny * 8);
+    const size_t n = (size_t)ntile_all * f.nk * g.tx * g.ty;
+    if (!stage_dev) stage_dev = (double*)dev_alloc((size_t)ntile_all * (g.npz + 1) * g.tx * g.ty * 8);
     h2d(ex, stage_dev, host, n * 8);
-    for_points(ex, Rect{g.isd(), g.ied() + 1, g.jsd(), g.jed() + 1}, g.ntile * f.nk, CompactFn{g, which ? f.p : f.t, stage_dev, f.nk, 0}, "boundary_unpack");
+    each_class([&]() {
+      const Fld fc = ex.sh(f);
+      double* cmp = stage_dev + (size_t)classes[(size_t)cur_cls].t0 * f.nk * g.tx * g.ty;
+      for_points(ex, Rect{g.isd(), g.ied() + 1, g.jsd(), g.jed() + 1}, g.ntile * f.nk, CompactFn{g, which ? fc.p : fc.t, cmp, f.nk, 0}, "boundary_unpack");
+    });
   }
   void compact_out(const Fld& f, int which, double* host) {
-    const size_t n = (size_t)g.ntile * f.nk * g.nx * g.ny;
-    if (!stage_dev) stage_dev = (double*)dev_alloc((size_t)g.ntile * (g.npz + 1) * g.nx * g.ny * 8);
-    for_points(ex, Rect{1, g.nx, 1, g.ny}, g.ntile * f.nk, CompactFn{g, which ? f.p : f.t, stage_dev, f.nk, 1}, "boundary_pack");
+    const size_t n = (size_t)ntile_all * f.nk * g.tx * g.ty;
+    if (!stage_dev) stage_dev = (double*)dev_alloc((size_t)ntile_all * (g.npz + 1) * g.tx * g.ty * 8);
+    each_class([&]() {
+      const Fld fc = ex.sh(f);
+      double* cmp = stage_dev + (size_t)classes[(size_t)cur_cls].t0 * f.nk * g.tx * g.ty;
+      for_points(ex, Rect{g.is(), g.ie(), g.js(), g.je()}, g.ntile * f.nk, CompactFn{g, which ? fc.p : fc.t, cmp, f.nk, 1}, "boundary_pack");
+    });
     d2h(ex, host, stage_dev, n * 8);
   }
   bool traj_to_fv3(const double* u, const double* v, const double* t, const double* delp, const double* const* qs, const double* w,
@@ -206,23 +214,33 @@ inline bool Dynamics::init2(const double* ak, const double* bk) {
   pe2 = S("pe2", npz + 1); pu_ad = S("pu_ad", npz + 1); pv_ad = S("pv_ad", npz + 1);
   {   // the column workspace of the remap lives in the perturbation side of the acoustic work arena when it fits: every work
       // array is dead between acoustic steps (each step's first touch of a work tangent / adjoint is a store or a planned clear)
-    const size_t need = (size_t)remap_ws_slots(nq) * (npz + 2) * g.ntile * g.plane;
+    const size_t need = (size_t)remap_ws_slots(nq) * (npz + 2) * ntile_all * g.plane;
     remap_ws_own = need > work.cap;
     remap_ws = remap_ws_own ? (double*)dev_alloc(need * 8) : work.p;
   }
-  cmax_dev = (double*)dev_alloc((size_t)g.ntile * npz * 8);
+  cmax_dev = (double*)dev_alloc((size_t)ntile_all * npz * 8);
   tshared.init(n3 * 9);       // build_tracer's nine shared fields; its per-tracer work arena is sized by a dry run
   tr_ksplt_km.assign(k_split, std::vector<int>(npz, 1)); tr_nsplt_km.assign(k_split, 1);
-  build_tracer();
-  if (nh) {
-    DynPtInNh s; s.in[0] = f("pt"); s.in[1] = nq > 0 ? q[0] : Fld{}; if (!s.in[1].t) s.in[1].nk = npz; s.in[2] = f("delp"); s.in[3] = f("delz");
-    s.out[0] = f("pt_o"); s.out[1] = f("pkz"); s.orect[0] = s.orect[1] = R(1, g.nx, 1, g.ny); s.k1 = npz; s.zvir = opt.zvir; s.akap = opt.akap;
-    s.rdg = -opt.rdgas / opt.grav; s.has_q = nq > 0; add(pt_in, "pt_in", s);
-    build_remap_nh();
-    ck_nh = (double*)dev_alloc((3 * n3 + (size_t)g.ntile * g.plane) * k_split * 8);
-  } else
-  { DynPtIn s; s.in[0] = f("pt"); s.in[1] = nq > 0 ? q[0] : Fld{}; if (!s.in[1].t) s.in[1].nk = npz; s.in[2] = f("pkz"); s.out[0] = f("pt_o");
-    s.orect[0] = R(1, g.nx, 1, g.ny); s.k1 = npz; s.zvir = opt.zvir; s.has_q = nq > 0; add(pt_in, "pt_in", s); }
+  for (Progs* P_ : {&tracer_scale, &tracer_pre, &tracer_q, &pt_in, &remap_nh}) { P_->c.assign(classes.size(), Program{}); P_->cur = &cur_cls; }
+  std::map<double*, size_t> tzero;
+  for (int c = 0; c < (int)classes.size(); ++c) {      // one set of programs per tile class, the fields shared
+    set_class(c); reuse_fields = c > 0;
+    build_tracer();
+    for (auto& zr : tracer_zero) { auto it = tzero.find(zr.first); if (it == tzero.end() || it->second < zr.second) tzero[zr.first] = zr.second; }
+    const Rect A = R(g.is(), g.ie(), g.js(), g.je());
+    if (nh) {
+      DynPtInNh s; s.in[0] = f("pt"); s.in[1] = nq > 0 ? q[0] : Fld{}; if (!s.in[1].t) s.in[1].nk = npz; s.in[2] = f("delp"); s.in[3] = f("delz");
+      s.out[0] = f("pt_o"); s.out[1] = f("pkz"); s.orect[0] = s.orect[1] = A; s.k1 = npz; s.zvir = opt.zvir; s.akap = opt.akap;
+      s.rdg = -opt.rdgas / opt.grav; s.has_q = nq > 0; add(pt_in, "pt_in", s);
+      build_remap_nh();
+    } else {
+      DynPtIn s; s.in[0] = f("pt"); s.in[1] = nq > 0 ? q[0] : Fld{}; if (!s.in[1].t) s.in[1].nk = npz; s.in[2] = f("pkz"); s.out[0] = f("pt_o");
+      s.orect[0] = A; s.k1 = npz; s.zvir = opt.zvir; s.has_q = nq > 0; add(pt_in, "pt_in", s);
+    }
+  }
+  reuse_fields = false; set_class(-1);
+  tracer_zero.assign(tzero.begin(), tzero.end());
+  if (nh) ck_nh = (double*)dev_alloc((3 * n3 + (size_t)ntile_all * g.plane) * k_split * 8);
   ck_k_stride = (size_t)(2 * nq + 7) * n3 + 3 * n3p;
   ck_k = (double*)dev_alloc(ck_k_stride * k_split * 8);
   ck_0 = (double*)dev_alloc(2 * n3 * 8);
@@ -277,8 +295,9 @@ inline bool Dynamics::fv3_to_pert(double* u, double* v, double* t, double* delp,
 
 inline void Dynamics::build_remap_nh() {
   const int npz = g.npz;
-  const Rect A = R(1, g.nx, 1, g.ny);
+  const Rect A = R(g.is(), g.ie(), g.js(), g.je());
   t_m = S("remap_t", npz); w_m = S("remap_w", npz); dz_m = S("remap_dz", npz);
+  q_m.clear();
   for (int n = 0; n < nq; ++n) { char nm[24]; std::snprintf(nm, sizeof nm, "remap_q%d", n + 1); q_m.push_back(S(nm, npz)); }
   // split_kord: the column kernels that also run the trajectory's limited profile (instantiations of their own)
   const bool anylim = kord_limited(opt.kord_tm) || kord_limited(opt.kord_tr) || kord_limited(opt.kord_wz);
@@ -291,26 +310,31 @@ inline void Dynamics::build_remap_nh() {
   for (int n = 0; n < nq; ++n) { NhColArgs a = args(3); a.f[0] = f("pe"); a.f[1] = q[n]; a.f[2] = q_m[n]; add_col(remap_nh, "remap", kfield, a, A, Rect{1, 0, 1, 0}, 3); }
   { NhColArgs a = args(nq > 0 ? 1 : 0); a.f[0] = f("pe"); a.f[1] = f("peln"); a.f[2] = f("pk"); a.f[3] = t_m; a.f[4] = dz_m; a.f[5] = nq > 0 ? q_m[0] : Fld{};
     a.f[6] = f("delp"); a.f[7] = f("pkz"); a.f[8] = f("pt"); a.f[9] = pe2; add_col(remap_nh, "remap", NHC_RM_PRESS, a, A, Rect{1, 0, 1, 0}, 3);
-    remap_nh.back().accum = true; }     // overwrites delp, peln, pk: left out of the adjoint's trajectory recompute
+    remap_nh.now().back().accum = true; }     // overwrites delp, peln, pk: left out of the adjoint's trajectory recompute
 }
 // Vertical remap, non-hydrostatic: scalars by the column operators above, winds by the kernels of remap.h.
 // Adjoint: the pre-remap trajectory (pt u v q pe peln pk delp w delz ws) must be in place.
 inline void Dynamics::remap_nh_run(int mode, int km) {
   const size_t b3 = n3 * 8;
-  RemapArgs ra = remap_args(km == k_split - 1);
-  const Rect A{1, g.nx, 1, g.ny}, H{0, g.nx + 1, 0, g.ny + 1};
-  remap_last = (km == k_split - 1);
+  const bool last = km == k_split - 1;
+  remap_last = last;
   std::vector<std::pair<Fld, Fld>> back{{f("w"), w_m}, {f("delz"), dz_m}};
   for (int n = 0; n < nq; ++n) back.push_back({q[n], q_m[n]});
   if (mode != MODE_AD) {
     run_group(remap_nh, nullptr, mode);
     for (auto& pr : back) { dev_copy(ex, pr.first.t, pr.second.t, b3); if (mode == MODE_TL) dev_copy(ex, pr.first.p, pr.second.p, b3); }
-    run_remap_winds(ex, mode, ra);
-    for_points(ex, A, g.ntile, RemapPeFn{ra, mode}, "remap_pe");
+    each_class([&]() {
+      RemapArgs ra = remap_args(last);
+      run_remap_winds(ex, mode, ra);
+      for_points(ex, Rect{g.is(), g.ie(), g.js(), g.je()}, g.ntile, RemapPeFn{ra, mode}, "remap_pe");
+    });
     return;
   }
-  run_remap_winds(ex, MODE_AD, ra);
-  for_points(ex, H, g.ntile, RemapGatherFn{ra}, "remap_gather.ad");
+  each_class([&]() {
+    RemapArgs ra = remap_args(last);
+    run_remap_winds(ex, MODE_AD, ra);
+    for_points(ex, Rect{g.is() - 1, g.ie() + 1, g.js() - 1, g.je() + 1}, g.ntile, RemapGatherFn{ra}, "remap_gather.ad");
+  });
   run_group(remap_nh, nullptr, MODE_NL, true);      // trajectory of the staging fields
   dev_zero(ex, t_m.p, b3); dev_zero(ex, pe2.p, n3p * 8);     // pe after the remap is not read again (pe2 is only copied into it)
   for (auto& pr : back) { dev_copy(ex, pr.second.p, pr.first.p, b3); dev_zero(ex, pr.first.p, b3); }
@@ -318,8 +342,8 @@ inline void Dynamics::remap_nh_run(int mode, int km) {
 }
 
 inline void Dynamics::build_tracer() {
-  const int is = 1, ie = g.nx, js = 1, je = g.ny, isd = g.isd(), ied = g.ied(), jsd = g.jsd(), jed = g.jed(), npz = g.npz;
-  auto TS = [&](const char* n) { Fld x = tshared.take((size_t)g.ntile * npz * g.plane, npz); F[n] = x; return x; };
+  const int is = g.is(), ie = g.ie(), js = g.js(), je = g.je(), isd = g.isd(), ied = g.ied(), jsd = g.jsd(), jed = g.jed(), npz = g.npz;
+  auto TS = [&](const char* n) { if (reuse_fields) { auto it = F.find(n); if (it != F.end()) return it->second; } Fld x = tshared.take((size_t)ntile_all * npz * g.plane, npz); F[n] = x; return x; };
   Fld xfx = TS("tr_xfx"), yfx = TS("tr_yfx"), dp2 = TS("tr_dp2"), rax = TS("tr_rax"), ray = TS("tr_ray");
   Fld cxs = TS("tr_cxs"), cys = TS("tr_cys"), mfxs = TS("tr_mfxs"), mfys = TS("tr_mfys");
   tr_dp2 = dp2;
@@ -342,8 +366,11 @@ inline void Dynamics::build_tracer() {
       add(tracer_q, "tracer", s); }
     twork = work; work = save;
   };
-  twork.measure(); build_q();
-  { const size_t need = twork.used; tracer_q.clear(); twork.init(need); }
+  if (!reuse_fields) {       // first class: size the per-tracer work arena by a dry run
+    const std::map<std::string, Fld> F_mark = F;
+    twork.measure(); build_q();
+    const size_t need = twork.used; tracer_q.clear(); F = F_mark; twork.init(need);
+  }
   build_q();
   tracer_zero = plan_adjoint(tracer_q, twork);
 }
@@ -353,19 +380,21 @@ inline void Dynamics::set_tracer_levels(const std::vector<int>& ksplt) {
   h2d(ex, lev_dev, lev_host.data(), sizeof(LevelParams) * g.npz);
 }
 
-inline RemapArgs Dynamics::remap_args(bool last_step) {
-  RemapArgs a; a.g = g; a.pe = f("pe"); a.peln = f("peln"); a.pk = f("pk"); a.pkz = f("pkz"); a.pt = f("pt"); a.delp = f("delp");
-  a.u = f("u"); a.v = f("v"); a.pe2 = pe2; a.nq = nq;
-  for (int n = 0; n < nq; ++n) a.q[n] = q[n];
+inline RemapArgs Dynamics::remap_args(bool last_step) {      // for the class being run: its geometry, its tiles' fields and workspace columns
+  RemapArgs a; a.g = g; a.pe = ex.sh(f("pe")); a.peln = ex.sh(f("peln")); a.pk = ex.sh(f("pk")); a.pkz = ex.sh(f("pkz")); a.pt = ex.sh(f("pt")); a.delp = ex.sh(f("delp"));
+  a.u = ex.sh(f("u")); a.v = ex.sh(f("v")); a.pe2 = ex.sh(pe2); a.nq = nq;
+  for (int n = 0; n < nq; ++n) a.q[n] = ex.sh(q[n]);
   a.ak = ak_dev; a.bk = bk_dev; a.akap = opt.akap; a.zvir = opt.zvir; a.ptop = opt.ptop; a.last_step = last_step;
   a.kord_tm = opt.kord_tm; a.kord_mt = opt.kord_mt; a.kord_tr = opt.kord_tr;
-  a.ws = remap_ws; a.ws_stride = (size_t)g.ntile * g.plane; a.pu_ad = pu_ad; a.pv_ad = pv_ad;
+  a.ws = remap_ws + ex.cls_off; a.ws_stride = (size_t)ntile_all * g.plane; a.pu_ad = ex.sh(pu_ad); a.pv_ad = ex.sh(pv_ad);
   return a;
 }
 
 inline void Dynamics::pressures(int mode) {
-  PressArgs a{g, f("delp"), f("pe"), f("peln"), f("pk"), f("pkz"), opt.akap, opt.ptop};
-  for_points(ex, Rect{1, g.nx, 1, g.ny}, g.ntile, PressFn{a, mode}, "pressures");
+  each_class([&]() {
+    PressArgs a{g, ex.sh(f("delp")), ex.sh(f("pe")), ex.sh(f("peln")), ex.sh(f("pk")), ex.sh(f("pkz")), opt.akap, opt.ptop};
+    for_points(ex, Rect{g.is(), g.ie(), g.js(), g.je()}, g.ntile, PressFn{a, mode}, "pressures");
+  });
 }
 
 // tracer_2d forward (nonlinear or tangent); q halos must be valid.  The sub-step count comes from the trajectory's maximum
@@ -374,12 +403,12 @@ inline void Dynamics::tracer_fwd(int mode) {
   const size_t b3 = n3 * 8;
   const int npz = g.npz, km = cur_km;
   {
-    dev_zero(ex, cmax_dev, (size_t)g.ntile * npz * 8);
-    for_points(ex, Rect{1, g.nx, 1, 1}, g.ntile * npz, CmaxFn{g, f("cx"), f("cy"), ctx.m.sin_sg[5], cmax_dev}, "tracer_cmax");
+    dev_zero(ex, cmax_dev, (size_t)ntile_all * npz * 8);
+    each_class([&]() { for_points(ex, Rect{g.is(), g.ie(), g.js(), g.js()}, g.ntile * npz, CmaxFn{g, ex.sh(f("cx")), ex.sh(f("cy")), ctx.m.sin_sg[5], cmax_dev + (size_t)classes[(size_t)cur_cls].t0 * npz}, "tracer_cmax"); });
     // mp_reduce_max (fv_tracer2d_tlm.F90:1306): over the resident tiles on the device, over the ranks by ncclAllReduce(max) on the
     // library stream when an RCCL communicator is up (the one collective of the path: npz doubles per k_split step); the host hook
     // serves transports without RCCL (gloo rehearsals, host emulation)
-    for_points(ex, Rect{0, npz - 1, 0, 0}, 1, CmaxTilesFn{g.ntile, npz, cmax_dev}, "tracer_cmax_tiles");
+    for_points(ex, Rect{0, npz - 1, 0, 0}, 1, CmaxTilesFn{ntile_all, npz, cmax_dev}, "tracer_cmax_tiles");
 #ifndef FV3LM_HOST_EMUL
     { Transport& T = transport();
       if (T.comm && !allreduce_max_hook().cb) {
@@ -416,7 +445,7 @@ inline void Dynamics::tracer_fwd(int mode) {
       if (mode == MODE_TL) dev_copy(ex, q[n].p, qc_o.p, b3);
     }
     if (it != nsplt) {
-      for_points(ex, Rect{1, g.nx, 1, g.ny}, g.ntile * npz, TrDp1Fn{g, dp1, tr_dp2, lev_dev, it, mode}, "tracer_dp1");
+      each_class([&]() { for_points(ex, Rect{g.is(), g.ie(), g.js(), g.je()}, g.ntile * npz, TrDp1Fn{g, ex.sh(dp1), ex.sh(tr_dp2), lev_dev, it, mode}, "tracer_dp1"); });
       for (int n = 0; n < nq; ++n) halo(mode, H_CELL, q[n]);
     }
   }
@@ -434,7 +463,7 @@ inline void Dynamics::tracer_ad() {
     ctx.tr_it = it;
     if (it != nsplt) {
       for (int n = nq - 1; n >= 0; --n) halo(MODE_AD, H_CELL, q[n]);
-      for_points(ex, Rect{1, g.nx, 1, g.ny}, g.ntile * npz, TrDp1Fn{g, dp1, tr_dp2, lev_dev, it, MODE_AD}, "tracer_dp1");
+      each_class([&]() { for_points(ex, Rect{g.is(), g.ie(), g.js(), g.je()}, g.ntile * npz, TrDp1Fn{g, ex.sh(dp1), ex.sh(tr_dp2), lev_dev, it, MODE_AD}, "tracer_dp1"); });
     }
     if (nsplt > 1) dev_copy(ex, dp1.t, subck(km, it, nq), b3);
     run_group(tracer_pre, nullptr, MODE_NL);
@@ -484,11 +513,11 @@ inline void Dynamics::fv_dynamics(int mode) {
           if (nh) {
             const char* r4[3] = {"delp", "w", "delz"};
             for (int n = 0; n < 3; ++n) dev_copy(ex, cknh(km, n), f(r4[n]).t, b3);
-            dev_copy(ex, cknh(km, 3), f("ws").t, (size_t)g.ntile * g.plane * 8);
+            dev_copy(ex, cknh(km, 3), f("ws").t, (size_t)ntile_all * g.plane * 8);
           }
         }
         if (nh) remap_nh_run(mode, km); else
-        run_remap(ex, mode, remap_args(km == k_split - 1));
+        each_class([&]() { run_remap(ex, mode, remap_args(km == k_split - 1)); });
       }
     }
     return;
@@ -497,7 +526,7 @@ inline void Dynamics::fv_dynamics(int mode) {
   // entry: u,v,pt,delp,q[n] .p = adjoint of the step outputs.  pe..pkz after the last remap are dead.
   for (const char* n : {"pe", "peln", "pk"}) dev_zero(ex, f(n).p, b3p);
   dev_zero(ex, f("pkz").p, b3);
-  if (nh) dev_zero(ex, f("ws").p, (size_t)g.ntile * g.plane * 8);
+  if (nh) dev_zero(ex, f("ws").p, (size_t)ntile_all * g.plane * 8);
   for (int km = k_split - 1; km >= 0; --km) {
     if (g.npz > 4) {
       const char* r3[3] = {"pt", "u", "v"}; const char* rp[3] = {"pe", "peln", "pk"};
@@ -508,10 +537,10 @@ inline void Dynamics::fv_dynamics(int mode) {
       if (nh) {
         const char* r4[3] = {"delp", "w", "delz"};
         for (int n = 0; n < 3; ++n) dev_copy(ex, f(r4[n]).t, cknh(km, n), b3);
-        dev_copy(ex, f("ws").t, cknh(km, 3), (size_t)g.ntile * g.plane * 8);
+        dev_copy(ex, f("ws").t, cknh(km, 3), (size_t)ntile_all * g.plane * 8);
         remap_nh_run(MODE_AD, km);
       } else
-      run_remap(ex, MODE_AD, remap_args(km == k_split - 1));
+      each_class([&]() { run_remap(ex, MODE_AD, remap_args(km == k_split - 1)); });
     }
     const char* mf[4] = {"mfx", "mfy", "cx", "cy"};
     for (int n = 0; n < 4; ++n) dev_zero(ex, f(mf[n]).p, b3);
@@ -526,7 +555,7 @@ inline void Dynamics::fv_dynamics(int mode) {
     }
     ck_base = km * n_split;
     dyn_core(MODE_AD);
-    for_points(ex, Rect{g.isd(), g.ied() + 1, g.jsd(), g.jed() + 1}, g.ntile * g.npz, AccumFn{g, dp1, f("delp"), MODE_AD}, "accum");   // delp.p += dp1.p
+    each_class([&]() { for_points(ex, Rect{g.isd(), g.ied() + 1, g.jsd(), g.jed() + 1}, g.ntile * g.npz, AccumFn{g, ex.sh(dp1), ex.sh(f("delp")), MODE_AD}, "accum"); });   // delp.p += dp1.p
     halo(MODE_AD, H_CELL, f("pt")); halo(MODE_AD, H_CELL, f("delp")); halo(MODE_AD, H_DVEC, f("u"), f("v"));
   }
   // pt_in: pt(theta_v) = T (1 + zvir qv) / pkz

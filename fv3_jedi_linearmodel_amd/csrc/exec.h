@@ -45,7 +45,17 @@ struct Exec {
   // to the slot of the acoustic step being run, so that the backward sweep finds that step's intermediates without
   // recomputing them.
   double* wlo = nullptr; double* whi = nullptr; std::ptrdiff_t tshift = 0;
-  Fld sh(const Fld& f) const { Fld r = f; if (tshift && f.t >= wlo && f.t < whi) r.t = f.t + tshift; return r; }
+  // Tile classes (dycore.h set_class): the resident tiles are run one class at a time -- runs of tiles that share a window is..ie x
+  // js..je of their face (one class when every tile is a whole face).  Each class has its own program, built in the reference's global
+  // face indices; what moves at run time is every field pointer, to the class's first tile (cls_off doubles into a one-level field).
+  // Exchanges run once, over all tiles, with the shift off.
+  size_t cls_off = 0;
+  Fld sh(const Fld& f) const {
+    Fld r = f;
+    if (tshift && f.t >= wlo && f.t < whi) r.t = f.t + tshift;
+    if (cls_off) { if (r.t) r.t += cls_off * (size_t)f.nk; if (r.p) r.p += cls_off * (size_t)f.nk; }
+    return r;
+  }
   long launches = 0;
   bool profiling = false;
   std::vector<ProfRec> recs;
@@ -474,6 +484,7 @@ __global__ void __launch_bounds__(64) k_stage_ad_alias(S s, Ctx c, Rect R) {
   if ((int)threadIdx.x >= 4 * c.g.ng * c.g.ng) return;
   int i, j;
   corner_block_point(c.g, blockIdx.x, threadIdx.x, i, j);
+  if (!c.g.in_plane(i, j)) return;            // a sub-face tile holds at most one face corner
   AdAliasLoop<S, 0>::run(s, c, R, i, j, blockIdx.y);
 }
 inline int strip_tr(const Rect& R) {
@@ -684,7 +695,8 @@ void run_multi(Exec& ex, int mode, const S* s0, int n, const Ctx& c) {
   for (int r = 0; r < MAXSTRIP; ++r) {
     const int q = r < n ? r : n - 1;
     S t = s0[q];
-    if (ex.tshift) { for (int k = 0; k < S::NIN; ++k) t.in[k] = ex.sh(t.in[k]); for (int k = 0; k < S::NOUT; ++k) t.out[k] = ex.sh(t.out[k]); }
+    for (int k = 0; k < S::NIN; ++k) t.in[k] = ex.sh(t.in[k]);
+    for (int k = 0; k < S::NOUT; ++k) t.out[k] = ex.sh(t.out[k]);
     m.s[r] = t; m.R[r] = rect_union(t.orect, S::NOUT); Q[r] = ad_input_rect(t, c, m.R[r]);
     if (r < n) bytes += stage_bytes(t, c, m.R[r], mode);
   }
@@ -767,6 +779,7 @@ void run_ad(Exec& ex, const S& s, const Ctx& c) {
         for (int n = 0; n < 4 * c.g.ng * c.g.ng; ++n) {
           int i, j;
           corner_block_point(c.g, cn, n, i, j);
+          if (!c.g.in_plane(i, j)) continue;
           AdAliasLoop<S, 0>::run(s, c, R, i, j, z);
         }
   ex.launches++;
@@ -790,10 +803,8 @@ template <class S>
 void run(Exec& ex, int mode, const S& s0, const Ctx& c) {
   S s = s0;
   if (ex.no_wmask) s.wmask = 0;
-  if (ex.tshift) {
-    for (int m = 0; m < S::NIN; ++m) s.in[m] = ex.sh(s.in[m]);
-    for (int n = 0; n < S::NOUT; ++n) s.out[n] = ex.sh(s.out[n]);
-  }
+  for (int m = 0; m < S::NIN; ++m) s.in[m] = ex.sh(s.in[m]);
+  for (int n = 0; n < S::NOUT; ++n) s.out[n] = ex.sh(s.out[n]);
   if (mode == MODE_NL) run_nl(ex, s, c);
   else if (mode == MODE_TL) run_tl(ex, s, c);
   else run_ad(ex, s, c);

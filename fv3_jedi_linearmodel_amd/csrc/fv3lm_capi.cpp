@@ -42,7 +42,7 @@ int fv3lm_create(fv3lm_handle** out, const fv3lm_dims* dm, const fv3lm_options* 
   // every failure path releases what was allocated so far (destroy2 / destroy accept a partly built object); the failure is reported here, once
   auto bail = [&](std::string e) { h->d.destroy2(); h->d.destroy(); delete h; sticky_error().clear(); return fail("fv3lm_create: " + e); };   // e by value: it may live in *h
   if (!h->d.init(dm->nx, dm->ny, dm->npz, dm->ntile, dm->face, dm->nq, dm->dt, dm->n_split, dm->k_split, *opt, metrics, da_min,
-                 da_min_c, phis)) return bail(h->d.err);
+                 da_min_c, phis, dm->nface, dm->tile_ij0)) return bail(h->d.err);
   if (!sticky_error().empty()) return bail(sticky_error());
   if (!h->d.init2(ak, bk)) return bail(h->d.err);
   if (!sticky_error().empty()) return bail(sticky_error());
@@ -170,7 +170,7 @@ int fv3lm_tracer_2d(fv3lm_handle* h, int mode) {
 }
 int fv3lm_traj_slots(fv3lm_handle* h) { return (int)h->d.traj_slot.size(); }   /* acoustic steps whose intermediates stay resident */
 int fv3lm_tracer_nsplt(fv3lm_handle* h) { return h->d.nsplt_max; }   /* largest sub-step count tracer_2d has used so far */
-int fv3lm_remap(fv3lm_handle* h, int mode, int last_step) { run_remap(h->d.ex, mode, h->d.remap_args(last_step != 0)); return status(h); }
+int fv3lm_remap(fv3lm_handle* h, int mode, int last_step) { h->d.each_class([&]() { run_remap(h->d.ex, mode, h->d.remap_args(last_step != 0)); }); return status(h); }
 int fv3lm_fv_dynamics(fv3lm_handle* h, int mode) { h->d.fv_dynamics(mode); return status(h); }
 int fv3lm_step_tl(fv3lm_handle* h) { h->d.step_tl(); return status(h); }
 int fv3lm_step_nl(fv3lm_handle* h) { h->d.step_nl(); return status(h); }

@@ -704,6 +704,8 @@ inline void run_nh_col_k(Exec& ex, int mode, const NhColArgs& a, const Rect& R, 
 inline void run_nh_col(Exec& ex, int mode, const NhColArgs& a0, int kind, const Rect& R, const Rect& skip, const char* tag) {
   NhColArgs a = a0;
   for (int n = 0; n < NH_NF; ++n) a.f[n] = ex.sh(a.f[n]);
+  if (a.hs) a.hs += ex.cls_off;
+  if (a.ws) a.ws += ex.cls_off;      // column workspace: columns of the class's first tile (ws_stride counts the columns of ALL resident tiles)
   switch (kind) {
     case NHC_RIEM_C: run_nh_col_k<NHC_RIEM_C>(ex, mode, a, R, skip, tag); break;
     case NHC_RIEM3: run_nh_col_k<NHC_RIEM3>(ex, mode, a, R, skip, tag); break;

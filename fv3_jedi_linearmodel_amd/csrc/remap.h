@@ -718,8 +718,9 @@ HD void remap_wind_col_ad(const RemapArgs& a, int dir, int i, int j, int tile, s
 // gather of the wind-map pressure adjoints into pe.p on is-1..ie+1, js-1..je+1
 HD void remap_pe_gather_ad(const RemapArgs& a, int i, int j, int tile) {
   const Geom& g = a.g; const int km = g.npz;
-  const bool u0 = (i >= 1 && i <= g.nx && j >= 1 && j <= g.ny + 1), u1 = (i >= 1 && i <= g.nx && j + 1 >= 1 && j + 1 <= g.ny + 1);
-  const bool v0 = (i >= 1 && i <= g.nx + 1 && j >= 1 && j <= g.ny), v1 = (i + 1 >= 1 && i + 1 <= g.nx + 1 && j >= 1 && j <= g.ny);
+  const int is = g.is(), ie = g.ie(), js = g.js(), je = g.je();
+  const bool u0 = (i >= is && i <= ie && j >= js && j <= je + 1), u1 = (i >= is && i <= ie && j + 1 >= js && j + 1 <= je + 1);
+  const bool v0 = (i >= is && i <= ie + 1 && j >= js && j <= je), v1 = (i + 1 >= is && i + 1 <= ie + 1 && j >= js && j <= je);
   for (int k = 1; k <= km + 1; ++k) {
     double acc = 0.;
     // u point (i,j) uses pe(i,j-1) and pe(i,j); u point (i,j+1) uses pe(i,j) and pe(i,j+1)
@@ -919,7 +920,7 @@ struct RemapWindFn {
 };
 inline void run_remap_winds(Exec& ex, int mode, const RemapArgs& a, double bytes = 0.) {
   const Geom& g = a.g;
-  const Rect U{1, g.nx, 1, g.ny + 1}, V{1, g.nx + 1, 1, g.ny};
+  const Rect U{g.is(), g.ie(), g.js(), g.je() + 1}, V{g.is(), g.ie() + 1, g.js(), g.je()};
   if (kord_limited(a.kord_mt) && mode != MODE_AD) {      // split_kord: the kernels that also run the trajectory's limited profile
     if (mode == MODE_NL) { for_points(ex, U, g.ntile, RemapWindFn<MODE_NL, true>{a, 0}, "remap_wind_lim.nl", bytes); for_points(ex, V, g.ntile, RemapWindFn<MODE_NL, true>{a, 1}, "remap_wind_lim.nl", bytes); }
     else { for_points(ex, U, g.ntile, RemapWindFn<MODE_TL, true>{a, 0}, "remap_wind_lim.tl", bytes); for_points(ex, V, g.ntile, RemapWindFn<MODE_TL, true>{a, 1}, "remap_wind_lim.tl", bytes); }
@@ -948,9 +949,9 @@ struct RemapPeFn {
 inline int remap_ws_slots(int nq) { return RemapAdSlots::FBASE + RemapAdSlots::FN * (1 + nq); }
 inline void run_remap(Exec& ex, int mode, const RemapArgs& a) {
   const Geom& g = a.g;
-  const Rect A{1, g.nx, 1, g.ny}, H{0, g.nx + 1, 0, g.ny + 1};
+  const Rect A{g.is(), g.ie(), g.js(), g.je()}, H{g.is() - 1, g.ie() + 1, g.js() - 1, g.je() + 1};
   if (mode != MODE_AD) {
-    const double cells = double(g.nx) * g.ny * g.ntile * g.npz, w = mode == MODE_TL ? 2. : 1.;
+    const double cells = double(g.tx) * g.ty * g.ntile * g.npz, w = mode == MODE_TL ? 2. : 1.;
     // algorithmic bytes: scalars read pe,peln,pk,pt,q[nq]; write pt,q[nq],delp,pk,peln,pkz,pe2; winds read pe x2, u|v; write u|v
     const int nf = 1 + a.nq;
     const bool lim = kord_limited(a.kord_tm) || kord_limited(a.kord_tr);
@@ -970,7 +971,7 @@ inline void run_remap(Exec& ex, int mode, const RemapArgs& a) {
     run_remap_winds(ex, mode, a, 8. * w * 4. * cells);
     for_points(ex, A, g.ntile, RemapPeFn{a, mode}, "remap_pe");
   } else {
-    const double cells = double(g.nx) * g.ny * g.ntile * g.npz;
+    const double cells = double(g.tx) * g.ty * g.ntile * g.npz;
     run_remap_winds(ex, MODE_AD, a, 8. * 7. * cells);
     for_points(ex, H, g.ntile, RemapGatherFn{a}, "remap_gather.ad", 8. * 4. * cells);
     const int nf = 1 + a.nq;

@@ -1039,14 +1039,14 @@ struct A2bB_ {
   HD T edge_x(const A& a, const Ctx& c, int tile, int i, int j) const {   // qout(1|npx, j): :179-187, :211-219
     const int ii = i - 1;     // cells ii, ii+1 straddle the edge
     auto q2 = [&](int jj) -> T { return (IN(2, ii, jj) * MET(dxa, ii + 1, jj) + IN(2, ii + 1, jj) * MET(dxa, ii, jj)) / (MET(dxa, ii, jj) + MET(dxa, ii + 1, jj)); };
-    const double w = c.m.edge[((size_t)tile * 4 + (i == 1 ? 0 : 1)) * c.g.pj + (j + c.g.ng - 1)];
+    const double w = c.m.edge[((size_t)tile * 4 + (i == 1 ? 0 : 1)) * c.g.pj + (j - c.g.j0 + c.g.ng)];
     return w * q2(j - 1) + (1. - w) * q2(j);
   }
   template <class T, class A>
   HD T edge_y(const A& a, const Ctx& c, int tile, int i, int j) const {   // qout(i, 1|npy): :294-302, :326-334
     const int jj = j - 1;
     auto q1 = [&](int ii) -> T { return (IN(2, ii, jj) * MET(dya, ii, jj + 1) + IN(2, ii, jj + 1) * MET(dya, ii, jj)) / (MET(dya, ii, jj) + MET(dya, ii, jj + 1)); };
-    const double w = c.m.edge[((size_t)tile * 4 + (j == 1 ? 2 : 3)) * c.g.pj + (i + c.g.ng - 1)];
+    const double w = c.m.edge[((size_t)tile * 4 + (j == 1 ? 2 : 3)) * c.g.pj + (i - c.g.i0 + c.g.ng)];
     return w * q1(i - 1) + (1. - w) * q1(i);
   }
   template <class T, class A>

@@ -107,9 +107,10 @@ DEV void tp_fused_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int
   const Geom& g = c.g;
   const int nx = g.nx, ny = g.ny;
   const bool face = g.face != 0;
-  const int I0 = 1 + bx * TPF_W, I1 = (I0 + TPF_W - 1 < nx) ? I0 + TPF_W - 1 : nx;
-  const int J0 = 1 + by * TPF_H, J1 = (J0 + TPF_H - 1 < ny) ? J0 + TPF_H - 1 : ny;
-  const bool firstx = bx == 0, lastx = I1 == nx, firsty = by == 0, lasty = J1 == ny;
+  const int is = g.is(), ie = g.ie(), js = g.js(), je = g.je();      // the tile's window of the face (nx, ny: the FACE, for the edge formulas)
+  const int I0 = is + bx * TPF_W, I1 = (I0 + TPF_W - 1 < ie) ? I0 + TPF_W - 1 : ie;
+  const int J0 = js + by * TPF_H, J1 = (J0 + TPF_H - 1 < je) ? J0 + TPF_H - 1 : je;
+  const bool firstx = bx == 0, lastx = I1 == ie, firsty = by == 0, lasty = J1 == je;
   const size_t base = (size_t)(tile * a.nk + k - 1) * g.plane;
   auto at = [&](int i, int j) -> size_t { return base + g.idx(i, j); };
   // constant row pitches (the full block's), whatever the block's own width: index arithmetic by compile-time constants
@@ -252,11 +253,11 @@ DEV void tp_fused_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int
     } }
 }
 
-inline void tpf_grid(const Geom& g, int& nbx, int& nby) { nbx = (g.nx + TPF_W - 1) / TPF_W; nby = (g.ny + TPF_H - 1) / TPF_H; }
+inline void tpf_grid(const Geom& g, int& nbx, int& nby) { nbx = (g.tx + TPF_W - 1) / TPF_W; nby = (g.ty + TPF_H - 1) / TPF_H; }
 // algorithmic bytes of one launch: 9 inputs (+ d2b, mass) read and 2 outputs written per cell (x2 in the tangent mode), + the six stored
 // trajectory intermediates of the nonlinear mode
 inline double tpf_bytes(const TpFusedArgs& a, const Geom& g, int mode) {
-  const double cells = double(g.nx) * g.ny * g.ntile * a.nk, nin = 9. + (a.d2b.t ? 1. : 0.) + (a.mass.t ? 1. : 0.);
+  const double cells = double(g.tx) * g.ty * g.ntile * a.nk, nin = 9. + (a.d2b.t ? 1. : 0.) + (a.mass.t ? 1. : 0.);
   return 8. * cells * (mode == MODE_TL ? 2. * (nin + 2.) : (nin + 2.) + (a.store_mid ? (a.store_fo ? 6. : 4.) : 0.));
 }
 
@@ -325,9 +326,10 @@ DEV void tp_outer_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, 
   const Geom& g = c.g;
   const int nx = g.nx, ny = g.ny;
   const bool face = g.face != 0;
-  const int I0 = 1 + bx * TPF_W, I1 = (I0 + TPF_W - 1 < nx) ? I0 + TPF_W - 1 : nx;
-  const int J0 = 1 + by * TPF_H, J1 = (J0 + TPF_H - 1 < ny) ? J0 + TPF_H - 1 : ny;
-  const bool firstx = bx == 0, lastx = I1 == nx, firsty = by == 0, lasty = J1 == ny;
+  const int is = g.is(), ie = g.ie(), js = g.js(), je = g.je();      // the tile's window of the face (nx, ny: the FACE, for the edge formulas)
+  const int I0 = is + bx * TPF_W, I1 = (I0 + TPF_W - 1 < ie) ? I0 + TPF_W - 1 : ie;
+  const int J0 = js + by * TPF_H, J1 = (J0 + TPF_H - 1 < je) ? J0 + TPF_H - 1 : je;
+  const bool firstx = bx == 0, lastx = I1 == ie, firsty = by == 0, lasty = J1 == je;
   const size_t base = (size_t)(tile * a.nk + k - 1) * g.plane;
   auto at = [&](int i, int j) -> size_t { return base + g.idx(i, j); };
   const int iord = hord_of(c.lev[k - 1], a.hsel);
@@ -342,7 +344,7 @@ DEV void tp_outer_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, 
       double f = 0., cc = 0., q = 0.;
       if (i <= I1 + 3 && j <= J1) {
         q = a.q_i.t[at(i, j)];
-        if (i >= 1 && i <= nx + 1) { cc = a.crx.t[at(i, j)]; f = 0.5 * a.mx.t[at(i, j)] * a.fx.p[at(i, j)]; }
+        if (i >= is && i <= ie + 1) { cc = a.crx.t[at(i, j)]; f = 0.5 * a.mx.t[at(i, j)] * a.fx.p[at(i, j)]; }
       }
       fxa[e] = f; cxt[e] = cc; qit[e] = q;
     } }
@@ -352,7 +354,7 @@ DEV void tp_outer_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, 
       double f = 0., cc = 0., q = 0.;
       if (i <= I1 && j <= J1 + 3) {
         q = a.q_j.t[at(i, j)];
-        if (j >= 1 && j <= ny + 1) { cc = a.cry.t[at(i, j)]; f = 0.5 * a.my.t[at(i, j)] * a.fy.p[at(i, j)]; }
+        if (j >= js && j <= je + 1) { cc = a.cry.t[at(i, j)]; f = 0.5 * a.my.t[at(i, j)] * a.fy.p[at(i, j)]; }
       }
       fya[e] = f; cyt[e] = cc; qjt[e] = q;
     } }
@@ -387,16 +389,16 @@ DEV void tp_outer_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, 
     TPF_LOOP(e, n) {
       const int i = I0 + e % w, r = e / w;
       if (i > I1 + 1 || !(i <= I1 || lastx)) continue;
-      if (firsty && r < 3) a.fx2.p[at(i, r - 2)] = 0.;             // rows -2 .. 0
-      if (lasty && r >= 3) a.fx2.p[at(i, ny + r - 2)] = 0.;        // rows ny+1 .. ny+3
+      if (firsty && r < 3) a.fx2.p[at(i, js + r - 3)] = 0.;        // rows js-3 .. js-1
+      if (lasty && r >= 3) a.fx2.p[at(i, je + r - 2)] = 0.;        // rows je+1 .. je+3
     } }
   if (firstx || lastx) {
     constexpr int n = 6 * (TPF_H + 1);
     TPF_LOOP(e, n) {
       const int r = e % 6, j = J0 + e / 6;
       if (j > J1 + 1 || !(j <= J1 || lasty)) continue;
-      if (firstx && r < 3) a.fy2.p[at(r - 2, j)] = 0.;
-      if (lastx && r >= 3) a.fy2.p[at(nx + r - 2, j)] = 0.;
+      if (firstx && r < 3) a.fy2.p[at(is + r - 3, j)] = 0.;
+      if (lastx && r >= 3) a.fy2.p[at(ie + r - 2, j)] = 0.;
     } }
   // ---- transposed outer sweeps: q_i_ad on the halo'd columns, q_j_ad on the halo'd rows (stored)
   { constexpr int n = TPA_NA;
@@ -408,7 +410,7 @@ DEV void tp_outer_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, 
       double s = 0.;
 #pragma unroll
       for (int m = i - 2; m <= i + 3; ++m) {
-        if (m < 1 || m > nx + 1 || m < I0 - 3 || m > I1 + 3) continue;
+        if (m < is || m > ie + 1 || m < I0 - 3 || m > I1 + 3) continue;
         const double f = fxa[ex_(m, j)];
         if (f != 0.) s += ppm_dq(iord, face, m, nx + 1, i, da, cxt[ex_(m, j)]) * f;
       }
@@ -423,7 +425,7 @@ DEV void tp_outer_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, 
       double s = 0.;
 #pragma unroll
       for (int m = j - 2; m <= j + 3; ++m) {
-        if (m < 1 || m > ny + 1 || m < J0 - 3 || m > J1 + 3) continue;
+        if (m < js || m > je + 1 || m < J0 - 3 || m > J1 + 3) continue;
         const double f = fya[ey_(i, m)];
         if (f != 0.) s += ppm_dq(iord, face, m, ny + 1, j, da, cyt[ey_(i, m)]) * f;
       }
@@ -445,7 +447,7 @@ FV3LM_LINK void run_tp_outer_ad(Exec& ex, const TpFusedArgs& a0, const Ctx& c) {
   int nbx, nby; tpf_grid(c.g, nbx, nby);
   // algorithmic bytes: trajectory q_i, q_j, crx, cry, mx, my, fx2, fy2 and the adjoints fx, fy read; q_i, q_j, fx2, fy2 adjoints written;
   // crx, cry, mx, my adjoints read-modify-written
-  const double cells = double(c.g.nx) * c.g.ny * c.g.ntile * a.nk;
+  const double cells = double(c.g.tx) * c.g.ty * c.g.ntile * a.nk;
   ex.mark_begin("TpOuter", ".ad", 8. * cells * (8. + 2. + 4. + 8.));
 #ifdef FV3LM_HOST_EMUL
   std::vector<double> lds((size_t)TPA_NT);

@@ -64,6 +64,12 @@ typedef struct fv3lm_dims {
                            1: every resident tile is a whole cube face (is = 1, ie = npx-1; all edge and corner branches on);
                            needs fv3lm_set_face_data and, for anything that exchanges halos, fv3lm_set_exchange. */
   double dt;            /* create(self,dt,...) src/fv3jedi_lm_mod.F90:44 */
+  /* Sub-face tiles (fv_flags_type%layout > 1 x 1, NLM/fv_control_nlm.F90:556; rank -> tile map tools/fv_mp_nlm_mod.F90:452-453).  face = 1 only.
+     nface: cells per edge of a whole face (npx-1); 0 or nx: every resident tile is a whole face.  tile_ij0: for each resident tile its (is, js)
+     in the global indices of its face, 2*ntile ints (NULL: (1, 1) for all).  nx, ny are then the cells of a tile (ie-is+1); all resident
+     tiles have the same size.  Exchange tables (fv3lm_set_exchange*) index the padded plane of a TILE. */
+  int nface, pad_;
+  const int* tile_ij0;
 } fv3lm_dims;
 
 /* Number and order of the metric planes handed to fv3lm_create (fv_grid_type,

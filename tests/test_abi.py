@@ -52,6 +52,7 @@ def test_struct_layouts_match_header():
         for decl in body.split(";"):
             decl = decl.strip()
             if decl:
+                decl = decl.replace("const int*", "intptr")
                 ty, rest = decl.split(None, 1)
                 out += [(n.strip(), ty) for n in rest.split(",")]
         return out
@@ -59,7 +60,7 @@ def test_struct_layouts_match_header():
         c_fields = fields(struct)
         assert [n for n, _ in c_fields] == [n for n, _ in cls._fields_], struct
         for (n, ty), (_, ct) in zip(c_fields, cls._fields_):
-            assert (ty == "int" and ct is C.c_int) or (ty == "double" and ct is C.c_double), (struct, n)
+            assert (ty == "int" and ct is C.c_int) or (ty == "double" and ct is C.c_double) or (ty == "intptr" and ct is C.POINTER(C.c_int)), (struct, n)
 
 
 def test_metric_names_and_loud_failure_without_gpu(lib):
