@@ -190,6 +190,9 @@ def main():
     ap.add_argument("--kord-traj", type=int, default=0, help="trajectory remap profile (9, 10 or 11) with the linear perturbation profile: split_kord, hydrostatic only")
     ap.add_argument("--nord-traj", type=int, default=0, help="trajectory divergence-damping order (2 or 3) beside nord_pert = 1: split_damp (not the headline configuration)")
     ap.add_argument("--split-damp", action="store_true", help="split_damp = .true. (the reference's default) with equal namelist values: the perturbation sponge rules differ")
+    ap.add_argument("--layout", type=int, default=0,
+                    help="tiles per face edge (fv_flags_type%%layout): 1 = whole faces, 2 = 24 sub-face tiles ... Default: 1 up to 6 GPUs (a face or more "
+                         "per GPU), 2 beyond (24 tiles, three per GPU at 8: all of the node works; six whole faces would idle two GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-host-transport", action="store_true",
                     help="multi-rank rehearsal on ONE GPU (RCCL refuses two ranks per device): gloo process group, halo messages staged "
@@ -259,8 +262,9 @@ def main():
                 for r, h in stage:
                     assert hip.hipMemcpy(r.ctypes.data, h.data_ptr(), r.size * 8, 1) == 0
             set_transport_callback(lib, transport)
-            grp = dist.new_group(ranks=list(range(min(world, 6))))
-            if rank < min(world, 6):
+            layout_ = args.layout if args.layout > 0 else (1 if world <= 6 else 2)
+            grp = dist.new_group(ranks=list(range(min(world, 6 * layout_ * layout_))))
+            if rank < min(world, 6 * layout_ * layout_):
                 def allmax(buf):
                     t = torch.from_numpy(buf.copy())
                     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=grp)
@@ -273,13 +277,16 @@ def main():
                     t.copy_(torch.tensor(list(data), dtype=torch.uint8))
                 dist.broadcast(t, src=0)
                 return bytes(t.cpu().tolist())
-            nact = min(world, 6)                          # ranks beyond the sixth have no face and stay out of the communicator
+            layout_ = args.layout if args.layout > 0 else (1 if world <= 6 else 2)
+            nact = min(world, 6 * layout_ * layout_)      # ranks without a tile stay out of the communicator
             if rank < nact:
                 comm_init_rccl(lib, rank, nact, bcast)
             else:
                 bcast(None)
             # tracer_2d's per-level max Courant number over all faces: ncclAllReduce(max) inside the library, on the same communicator
-        active = len(cube.faces_of(rank, world)) > 0
+        layout = args.layout if args.layout > 0 else (1 if world <= 6 else 2)
+        ntiles = 6 * layout * layout
+        active = len(cube.faces_of(rank, world, ntiles)) > 0
         if active:
             nhkw = dict(hydrostatic=0) if args.nonhydrostatic else {}
             if args.kord_traj:
@@ -291,7 +298,7 @@ def main():
             if args.hord_traj:
                 nhkw.update(hord_mt=args.hord_traj, hord_vt=args.hord_traj, hord_tm=args.hord_traj, hord_dp=args.hord_traj, hord_tr=args.hord_traj)
             c = CubeCase(n=args.nx, npz=args.npz, n_split=args.n_split, k_split=args.k_split, dt=args.dt, backend="hip", nq=args.nq,
-                         rank=rank, world=world, **nhkw)
+                         rank=rank, world=world, layout=layout, **nhkw)
             T, P = cube_step_state(c)
             if args.nonhydrostatic:
                 Tn, Pn = cube_nh_state(c)
@@ -337,7 +344,7 @@ def main():
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
     if cube_mode:      # the cube is fixed: strong scaling, faces dealt over ranks
-        cols_rank = args.nx * args.nx * len(cube.faces_of(0, world))
+        cols_rank = (args.nx // layout) ** 2 * len(cube.faces_of(0, world, ntiles))
         value = 6 * args.nx * args.nx / (elapsed / args.steps)
     else:
         cols_rank = args.nx * args.nx
@@ -361,8 +368,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong" if cube_mode else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C%dL%d %s TL+AD, %s (%d columns per GPU), k_split=%d n_split=%d dt=%gs nq=%d, %s"
-                                   % (args.nx, args.npz, "non-hydrostatic" if args.nonhydrostatic else "hydrostatic", ("six cube faces dealt over %d GPU(s) (%s faces per rank), table-driven face exchange%s"
-                                                           % (world, "/".join(str(len(cube.faces_of(r, world))) for r in range(world)),
+                                   % (args.nx, args.npz, "non-hydrostatic" if args.nonhydrostatic else "hydrostatic", ("six cube faces%s dealt over %d GPU(s) (%s per rank), table-driven exchange%s"
+                                                           % ("" if layout == 1 else " cut into %d sub-face tiles (layout %d x %d)" % (ntiles, layout, layout), world,
+                                                              "/".join(str(len(cube.faces_of(r, world, ntiles))) for r in range(world)),
                                                               "" if world == 1 else (", halo messages staged through host memory over gloo (rehearsal on one GPU, NOT RCCL)"
                                                                                     if args.rehearse_host_transport else ", RCCL point-to-point between ranks"))) if cube_mode
                                       else "1 doubly-periodic tile per GPU", cols_rank, args.k_split, args.n_split, args.dt, args.nq, scheme_string(c.opt, args.nonhydrostatic)),

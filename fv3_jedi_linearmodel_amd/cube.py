@@ -176,6 +176,100 @@ def adjoint_table(tab):
     return src, ptr, np.ascontiguousarray(dst)
 
 
+# --------------------------------------------------------------------------------- sub-face tiles (layout > 1 x 1)
+# fv_flags_type%layout (NLM/fv_control_nlm.F90:556) cuts every face into layout x layout tiles; rank -> tile map as in
+# tools/fv_mp_nlm_mod.F90:452-453 (face-major, then rows of tiles).  A tile is the window is..ie x js..je of its face in the face's global
+# indices; its padded plane is indexed like a face's, relative to (is, js).
+def tiles(n, layout, order="position"):
+    """[(face0, is, js)] of the 6 * layout^2 tiles of a C<n> cube, nt = n // layout cells each.  order "face": the reference's rank order
+    (face-major, tools/fv_mp_nlm_mod.F90:452-453: what a host with one tile per MPI rank hands over); "position" (default of the harness):
+    the six tiles at the same place of their faces next to each other -- tiles with the same window form one class of launches in the
+    library (dycore.h set_class), so a GPU holding several tiles runs each stage once per position, not once per tile."""
+    assert layout >= 1 and n % layout == 0, (n, layout)
+    nt = n // layout
+    if order == "face":
+        return [(f, 1 + bi * nt, 1 + bj * nt) for f in range(6) for bj in range(layout) for bi in range(layout)]
+    return [(f, 1 + bi * nt, 1 + bj * nt) for bj in range(layout) for bi in range(layout) for f in range(6)]
+
+
+def tile_window(a, tl, nt):
+    """the padded-plane windows [ntile, ..., nt+7, nt+7] of face arrays a[6, ..., n+7, n+7] (halo included: global smooth fields)"""
+    return np.ascontiguousarray(np.stack([a[f][..., j0 - 1:j0 - 1 + nt + 2 * NG + 1, i0 - 1:i0 - 1 + nt + 2 * NG + 1] for (f, i0, j0) in tl]))
+
+
+def tile_gather(w, tl, n, nt, lead=()):
+    """inverse of tile_window on the compute domains: face arrays [6, ..., n+7, n+7] with every cell from the tile that owns it (rest zero)"""
+    out = np.zeros((6,) + tuple(w.shape[1:-2]) + (n + 2 * NG + 1, n + 2 * NG + 1))
+    for t, (f, i0, j0) in enumerate(tl):
+        out[f][..., j0 + NG - 1:j0 + NG - 1 + nt, i0 + NG - 1:i0 + NG - 1 + nt] = w[t][..., NG:NG + nt, NG:NG + nt]
+    return out
+
+
+_STAG = {"center": (0, 0), "corner": (1, 1), "yedge": (0, 1), "xedge": (1, 0)}      # extra points of the compute domain in i, j
+
+
+def tiled_tables(n, layout):
+    """The five exchange tables for the 6 * layout^2 tiles.  A point of a tile's padded plane outside the tile's own compute domain
+    takes the value of the tile that owns it: the same face point where it lies inside the face, the face-level table's source
+    (the neighbour face, component swap and sign included) where it lies beyond a cube edge; the corner squares beyond a cube
+    corner hold no data.  'dedge': the D-grid edge rows u(is:ie, je+1), v(ie+1, js:je) from the tile whose low edge they are."""
+    nt = n // layout
+    tl = tiles(n, layout)
+    pn, pt = n + 2 * NG + 1, nt + 2 * NG + 1
+    face_tabs = all_tables(n)
+    tidx = {(f, i0, j0): t for t, (f, i0, j0) in enumerate(tl)}
+
+    def owner(f, kind, i, j):       # tile that holds face point (i, j) of a field at `kind` in its compute domain (low edge of shared points)
+        bi = min((i - 1) // nt, layout - 1); bj = min((j - 1) // nt, layout - 1)
+        return tidx[(f, 1 + bi * nt, 1 + bj * nt)]
+
+    def pidx(t, i, j):
+        _, i0, j0 = tl[t]
+        return (j - j0 + NG) * pt + (i - i0 + NG)
+    out = {}
+    for kname, fields in EXCHANGE_FIELDS.items():
+        canon = {}
+        for r in face_tabs[kname]:
+            canon[(int(r[0]), int(r[1]), int(r[2]))] = (int(r[3]), int(r[4]), int(r[5]), int(r[6]))
+        rows = []
+        for t, (f, i0, j0) in enumerate(tl):
+            for fi, (kind, _) in enumerate(fields):
+                ei, ej = _STAG[kind]
+                for j in range(j0 - NG, j0 + nt + NG + 1):
+                    for i in range(i0 - NG, i0 + nt + NG + 1):
+                        if i0 <= i <= i0 + nt - 1 + ei and j0 <= j <= j0 + nt - 1 + ej:
+                            continue                                  # own compute domain
+                        if i < 1 - NG or i > n + NG + 1 or j < 1 - NG or j > n + NG + 1:
+                            continue
+                        if 1 <= i <= n + ei and 1 <= j <= n + ej:     # inside the face: the owning tile's copy
+                            sf, sface, si, sj, sg = fi, f, i, j, 1
+                        else:
+                            c = canon.get((fi, f, (j + NG - 1) * pn + (i + NG - 1)))
+                            if c is None:
+                                continue                              # beyond a cube corner, or not part of this exchange
+                            sf, sface, sidx, sg = c
+                            sj, si = divmod(sidx, pn); si += 1 - NG; sj += 1 - NG
+                        ts = owner(sface, fields[sf][0], si, sj)
+                        rows.append((fi, t, pidx(t, i, j), sf, ts, pidx(ts, si, sj), sg))
+        out[kname] = np.array(rows, dtype=np.int32).reshape(-1, 7)
+    # shared edge rows
+    canon = {(int(r[0]), int(r[1]), int(r[2])): (int(r[3]), int(r[4]), int(r[5]), int(r[6])) for r in face_tabs["dedge"]}
+    fields = EXCHANGE_FIELDS["dvec"]
+    rows = []
+    for t, (f, i0, j0) in enumerate(tl):
+        for fi, pts in ((0, [(i, j0 + nt) for i in range(i0, i0 + nt)]), (1, [(i0 + nt, j) for j in range(j0, j0 + nt)])):
+            for (i, j) in pts:
+                if (fi == 0 and j <= n) or (fi == 1 and i <= n):      # interior tile boundary: the neighbour's low edge, same face point
+                    sf, sface, si, sj, sg = fi, f, i, j, 1
+                else:
+                    sf, sface, sidx, sg = canon[(fi, f, (j + NG - 1) * pn + (i + NG - 1))]
+                    sj, si = divmod(sidx, pn); si += 1 - NG; sj += 1 - NG
+                ts = owner(sface, fields[sf][0], si, sj)
+                rows.append((fi, t, pidx(t, i, j), sf, ts, pidx(ts, si, sj), sg))
+    out["dedge"] = np.array(rows, dtype=np.int32).reshape(-1, 7)
+    return out
+
+
 # --------------------------------------------------------------------------------------------- grid
 def _norm(v):
     return v / np.linalg.norm(v, axis=-1, keepdims=True)
@@ -397,30 +491,30 @@ def cube_fields(n, npz, geo, seed, kind="traj", opt=None):
 
 
 # --------------------------------------------------------------------------------- faces over ranks
-def faces_of(rank, world):
-    """Faces (0-based) owned by `rank` when the six faces are dealt over `world` ranks in contiguous blocks
-    (6/3/2+1 faces per GPU at 1/2/4 GPUs, one each at 6, ranks >= 6 idle: SURVEY.md §8e)."""
-    if world >= 6:
-        return [rank] if rank < 6 else []
-    base, extra = divmod(6, world)
+def faces_of(rank, world, ntiles=6):
+    """Tiles (0-based; the six faces when ntiles = 6) owned by `rank` when they are dealt over `world` ranks in contiguous blocks
+    (6/3/2+1 faces per GPU at 1/2/4 GPUs, one each at 6, ranks >= 6 idle; 24 tiles of a 2 x 2 layout: 3 per GPU at 8: SURVEY.md 8e)."""
+    if world >= ntiles:
+        return [rank] if rank < ntiles else []
+    base, extra = divmod(ntiles, world)
     start = rank * base + min(rank, extra)
     return list(range(start, start + base + (1 if rank < extra else 0)))
 
 
-def face_owner(world):
+def face_owner(world, ntiles=6):
     own = {}
     for r in range(world):
-        for f in faces_of(r, world):
+        for f in faces_of(r, world, ntiles):
             own[f] = r
     return own
 
 
-def split_table(tab, rank, world):
+def split_table(tab, rank, world, ntiles=6):
     """One exchange table of the whole cube -> what `rank` needs: (local rows [n,7] with local tile numbers,
     peers, {peer: send rows [m,3] = field, local tile, index}, {peer: recv rows [m,4] = field, local tile, index, sign}).
     Both ends walk the global table in the same order, so message layouts agree without negotiation."""
-    own = face_owner(world)
-    mine = faces_of(rank, world)
+    own = face_owner(world, ntiles)
+    mine = faces_of(rank, world, ntiles)
     loc = {f: n for n, f in enumerate(mine)}
     local, send, recv = [], {}, {}
     for r in tab:

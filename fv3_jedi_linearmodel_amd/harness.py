@@ -82,32 +82,56 @@ class Case:
 
 
 class CubeCase:
-    """All six faces of a C<n> cube resident in one product instance (ntile = 6, face mode), exchange tables from
-    cube.py, smooth global fields as state."""
+    """All six faces of a C<n> cube resident in one product instance (face mode), exchange tables from cube.py, smooth global fields
+    as state.  layout = L > 1: every face cut into L x L tiles (fv_control_nlm.F90:556), 6 L^2 tiles of n/L cells; the fields of the
+    case are then the tiles' windows [ntile, nk, n/L+7, n/L+7] of the same global fields (gather() puts results back on faces)."""
 
     def __init__(self, n=12, npz=6, n_split=2, k_split=1, dt=1800.0, backend="hip", seed=20250114, nq=0, oracle=False, rank=0, world=1,
-                 **optkw):
-        """rank/world: this process holds only cube.faces_of(rank, world) (one process per GPU); state and metrics are the
+                 layout=1, **optkw):
+        """rank/world: this process holds only cube.faces_of(rank, world, ntiles) (one process per GPU); state and metrics are the
         corresponding slices of the same global fields, so results can be compared with a single-process run."""
         from . import cube
-        self.n = self.nx = self.ny = n
+        self.n = n
+        self.layout = layout
+        self.nt = self.nx = self.ny = n // layout
         self.npz, self.nq = npz, nq
         self.opt = default_options(**optkw)
         self.metrics, self.da_min, self.da_min_c, self.edge, self.ecorner, self.geo = cube.cubed_sphere_metrics(n)
-        self.tables = cube.all_tables(n)
         self.traj, self.phis, self.ak, self.bk = cube.cube_fields(n, npz, self.geo, seed, "traj", self.opt)
         self.pert = cube.cube_fields(n, npz, self.geo, seed + 1, "pert")
         aux = cube.cube_fields(n, npz, self.geo, seed + 11, "pert") if nq else None
         self.qtraj = [1e-3 * (m + 1) + 1e-2 * np.abs(aux["pt"] if m % 2 == 0 else 2e-3 * aux["delp"]) * (1.0 + 0.25 * m) for m in range(nq)]
         self.qpert = [1e-4 * (aux["delp"] if m % 2 == 0 else 500.0 * aux["pt"]) * (1.0 + 0.5 * m) for m in range(nq)]
-        self.faces = cube.faces_of(rank, world)
+        self.tiles = cube.tiles(n, layout)
+        ntiles = len(self.tiles)
+        if layout > 1:      # the tiles' windows of everything
+            nt, tl = self.nt, self.tiles
+            W = lambda a: cube.tile_window(a, tl, nt)
+            self.face_fields = dict(traj=self.traj, pert=self.pert, phis=self.phis, qtraj=self.qtraj, qpert=self.qpert)      # on whole faces (the oracle's view)
+            self.metrics = {k: W(v) for k, v in self.metrics.items()}
+            pt_ = nt + 7
+            self.edge = np.ascontiguousarray(np.stack([np.stack([self.edge[f, e, (j0 if e < 2 else i0) - 1:(j0 if e < 2 else i0) - 1 + pt_] for e in range(4)]) for (f, i0, j0) in tl]))
+            self.ecorner = np.ascontiguousarray(np.stack([self.ecorner[f] for (f, _, _) in tl]))
+            self.phis = W(self.phis)
+            self.traj = {k: W(v) for k, v in self.traj.items()}; self.pert = {k: W(v) for k, v in self.pert.items()}
+            self.qtraj = [W(v) for v in self.qtraj]; self.qpert = [W(v) for v in self.qpert]
+            self.tables = cube.tiled_tables(n, layout)
+        else:
+            self.tables = cube.all_tables(n)
+        self.faces = cube.faces_of(rank, world, ntiles)
+        self.ntiles = ntiles
         if world > 1:
             F = self.faces
             self.metrics = {k: np.ascontiguousarray(v[F]) for k, v in self.metrics.items()}
             self.edge, self.ecorner, self.phis = np.ascontiguousarray(self.edge[F]), np.ascontiguousarray(self.ecorner[F]), np.ascontiguousarray(self.phis[F])
             self.traj = {k: np.ascontiguousarray(v[F]) for k, v in self.traj.items()}; self.pert = {k: np.ascontiguousarray(v[F]) for k, v in self.pert.items()}
             self.qtraj = [np.ascontiguousarray(v[F]) for v in self.qtraj]; self.qpert = [np.ascontiguousarray(v[F]) for v in self.qpert]
-        self.dims = Dims(nx=n, ny=n, npz=npz, ntile=len(self.faces), nq=nq, n_split=n_split, k_split=k_split, face=1, dt=dt)
+        self.dims = Dims(nx=self.nt, ny=self.nt, npz=npz, ntile=len(self.faces), nq=nq, n_split=n_split, k_split=k_split, face=1, dt=dt)
+        if layout > 1:
+            import ctypes as C
+            self._ij0 = (C.c_int * (2 * len(self.faces)))(*[v for t in self.faces for v in self.tiles[t][1:]])
+            self.dims.nface = n
+            self.dims.tile_ij0 = C.cast(self._ij0, C.POINTER(C.c_int))
         self.dt_ac = dt / n_split / k_split
         self.face = "cube"
         self.oracle = self._make_oracle() if oracle else None
@@ -120,9 +144,16 @@ class CubeCase:
         self._after_create(backend)
         for k, t in self.tables.items():
             if world > 1:
-                self.dy.set_exchange_split(k, t, rank, world)
+                self.dy.set_exchange_split(k, t, rank, world, ntiles)
             else:
                 self.dy.set_exchange(k, t)
+
+    def gather(self, a):
+        """tile windows [ntile, ..., nt+7, nt+7] -> face arrays [6, ..., n+7, n+7] on the compute domains (whole faces: unchanged)"""
+        if self.layout == 1:
+            return a
+        from . import cube
+        return cube.tile_gather(a, self.tiles, self.n, self.nt)
 
     _make_oracle = Case._make_oracle
     _load_library = Case._load_library
@@ -198,6 +229,10 @@ def cube_nh_state(c):
     delz = -(o.rdgas / o.grav) * T0["pt"] * (1.0 + o.zvir * qv) * np.diff(T0["peln"], axis=1)
     aux = cube.cube_fields(c.n, c.npz, c.geo, 20250135, "pert")
     aux2 = cube.cube_fields(c.n, c.npz, c.geo, 20250136, "pert")
+    if c.layout > 1:
+        aux = {k: cube.tile_window(v, c.tiles, c.nt) for k, v in aux.items()}; aux2 = {k: cube.tile_window(v, c.tiles, c.nt) for k, v in aux2.items()}
+    if len(c.faces) != c.ntiles:
+        aux = {k: v[c.faces] for k, v in aux.items()}; aux2 = {k: v[c.faces] for k, v in aux2.items()}
     w = 0.05 * aux["pt"]; w_p = 0.01 * aux2["pt"]; dz_p = 1e-3 * aux2["delp"]
     names = ["u", "v", "pt", "delp"]
     T = [T0[n] for n in names] + [w, delz] + [T0["q%d" % (n + 1)] for n in range(c.nq)]

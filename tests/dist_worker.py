@@ -18,7 +18,8 @@ def main():
     from groups import cube_step_state, masked
     from fv3_jedi_linearmodel_amd._lib import set_transport_callback, set_allreduce_callback
     nh = os.environ.get("FV3LM_DIST_NH", "0") == "1"      # non-hydrostatic: w, delz prognostic; w / heights / pressures join the exchanges
-    kw = dict(n=8, npz=6, n_split=2, k_split=2, backend="emul", nq=2)
+    layout = int(os.environ.get("FV3LM_DIST_LAYOUT", "1"))     # > 1: sub-face tiles dealt over the ranks (24 tiles of a 2 x 2 layout: 3 per rank at 8)
+    kw = dict(n=8 * layout, npz=6 if layout == 1 else 4, n_split=2, k_split=2, backend="emul", nq=2 if layout == 1 else 1, layout=layout)
     if nh:
         kw.update(hydrostatic=0, dt=1200.0)
     ref = CubeCase(**kw)                       # whole cube in this process
@@ -61,7 +62,7 @@ def main():
     for n in names:
         for w in (0, 1):
             a, b = c.dy.get(n, w), ref.dy.get(n, w)[F]
-            r = ref.rect(1, ref.n + (1 if n == "v" else 0), 1, ref.n + (1 if n == "u" else 0))
+            r = ref.rect(1, ref.nx + (1 if n == "v" else 0), 1, ref.nx + (1 if n == "u" else 0))
             worst = max(worst, float(np.max(np.abs(a[r] - b[r])) / max(1e-300, np.max(np.abs(b[r])))))
     # adjoint step
     for case, sl in ((ref, slice(None)), (c, F)):
@@ -73,7 +74,7 @@ def main():
         case.dy.step_ad()
     for n in names:
         a, b = c.dy.get(n, 1), ref.dy.get(n, 1)[F]
-        r = ref.rect(1, ref.n + (1 if n == "v" else 0), 1, ref.n + (1 if n == "u" else 0))
+        r = ref.rect(1, ref.nx + (1 if n == "v" else 0), 1, ref.nx + (1 if n == "u" else 0))
         worst = max(worst, float(np.max(np.abs(a[r] - b[r])) / max(1e-300, np.max(np.abs(b[r])))))
     t = torch.tensor([worst], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
