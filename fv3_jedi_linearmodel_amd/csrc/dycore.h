@@ -715,7 +715,7 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
     if (ak <= 16 && !(ak >= 9 && ak <= 11)) { err = "kord_tm/kord_mt/kord_wz/kord_tr: the linear profile (|kord| > 16) or, for the trajectory, the limited profiles 9, 10, 11"; return false; }
     if (ak <= 16 && npz < 6) { err = "kord: limited trajectory profiles need npz >= 6"; return false; }
   }
-  //   tracer advection: the perturbation runs with the trajectory scheme (no split_hord recompute); hord_tr_ks_* are read by the
+  //   tracer advection: hord_tr / hord_tr_pert split like the others (fv_tracer2d_tlm.F90:1047-1110); hord_tr_ks_* are read by the
   //   reference's namelist but used nowhere on the path (fv_control_tlmadm.F90:166-172), so they are accepted and ignored here too
   //   advection schemes: the tangent / adjoint exists for 1, 2, 333 (tp_core_tlm.F90:2393-2487); a trajectory scheme that differs
   //   (split_hord) gives the values -- a second pass of fv_tp_2d, a second evaluation inside the xtp_u / ytp_v stage -- and may
@@ -1005,7 +1005,6 @@ inline void Dycore::build_acoustic() {
   Fld uc1 = W("uc1", npz), vc1 = W("vc1", npz);
   { CswUpdateD s; s.in[0] = uc0; s.in[1] = vc0; s.in[2] = u; s.in[3] = v; s.in[4] = vort_c; s.in[5] = ke_c; s.out[0] = uc1; s.out[1] = vc1;
     s.orect[0] = R(is, ie + 1, js, je); s.orect[1] = R(is, ie, js, je + 1); s.dt2 = dt2; s.k1 = npz; add_face(P, "c_sw", s, 1); }
-  if (opt.nord > 0) add_halo_async(P, "halo_divgd", H_CORNER, divgd);     // first needed by the divergence damping of d_sw: runs beside geopk / p_grad_c / the transports
   // ---- geopk (C grid) + p_grad_c
   Fld pe_c = W("pe_c", npz + 1), peln_c = W("peln_c", npz + 1), pkc = W("pkc", npz + 1), gz = W("gz", npz + 1);
   Fld uc = W("uc", npz), vc = W("vc", npz);
@@ -1092,6 +1091,9 @@ inline void Dycore::build_acoustic() {
   Fld wk = W("wk", npz), vorta = W("vort_abs", npz);
   { DswVort s; s.in[0] = u; s.in[1] = v; s.out[0] = wk; s.out[1] = vorta; s.orect[0] = s.orect[1] = R(isd, ied, jsd, jed); s.k1 = npz; add(P, "d_sw", s); }
   Fld da = W("dd_a", npz), db = W("dd_b", npz), dc = W("dd_c", npz), vortb = W("vort_b", npz), ke2 = W("ke2", npz);
+  // the corner-scalar exchange of divg_d is first needed here: its start is hoisted to right after the last launch that touches the field
+  // (CswDivg in c_sw), so it runs beside the rest of c_sw, geopk, p_grad_c and the transports of d_sw (the join used to sit in c_sw)
+  if (opt.nord > 0) add_halo_async(P, "halo_divgd", H_CORNER, divgd);
   { DdAD s; s.in[0] = divgd; s.in[1] = u; s.in[2] = v; s.in[3] = ua; s.in[4] = va; s.in[5] = g.face ? uc : none; s.in[6] = g.face ? vc : none; s.out[0] = da; s.out[1] = db;
     s.orect[0] = R(is - 1, ie + 1, js, je + 1); s.orect[1] = R(is, ie + 1, js - 1, je + 1); s.k1 = npz; add_face(P, "d_sw", s, 1); }
   { DdBD s; s.in[0] = da; s.in[1] = db; s.out[0] = dc; s.orect[0] = R(is, ie + 1, js, je + 1); s.k1 = npz; add_face(P, "d_sw", s, 1); }

@@ -30,6 +30,10 @@ def short(name):
     m = re.search(r"k_tp_(fused|march)<(fv3::Dual|double)", name)
     if m:       # fv_tp_2d as one launch (tpfused.h): tiled or marching form; Dual = tangent, double = nonlinear (stores the intermediates)
         return "%s.%s" % ("TpFused" if m.group(1) == "fused" else "TpMarch", "tl" if "Dual" in m.group(2) else "nl")
+    if "k_tp_ad_corner" in name:   # corner-alias contributions of the fused adjoint (tpad.h)
+        return "TpAd.ad_corner"
+    if "k_tp_ad" in name:          # the whole adjoint of fv_tp_2d as one launch (tpad.h)
+        return "TpAd.ad"
     if "k_tp_outer_ad" in name:    # hand-written adjoint of the outer sweeps + flux assembly of fv_tp_2d (tpfused.h)
         return "TpOuter.ad"
     m = re.search(r"k_points<fv3::([A-Za-z0-9_]+(?:<[^>]*>)?)", name)
