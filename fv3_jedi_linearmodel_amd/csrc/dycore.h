@@ -1222,46 +1222,77 @@ inline void Dycore::dyn_core(int mode) {
       q_ += (n < 3 ? n3p : n3);
     }
   };
+  // State rotation.  The prognostic fields are not copied between the acoustic steps: the step's program is pointed (exec.h Redir) at
+  // where its inputs already are and at where its outputs are wanted.
+  //   NL  the outputs (*_o, work arena) of a step with a trajectory slot stay in that slot; the next step reads them there, and so does
+  //       the backward sweep (no checkpoint copy for that step).  pe, peln, pk, pkz are written straight into the slot (hydrostatic;
+  //       the non-hydrostatic step does not write pkz).  The last step's outputs are copied to the state fields.
+  //   TL  inputs and outputs swap roles every step (both sides); one copy at the end when n_split is odd.
+  //   AD  the adjoint of a step's inputs is accumulated where the next (earlier) step expects the adjoint of its outputs.
+  const bool p_in_slot = !nh;
+  auto slot_out = [&](int a, int n) { return f(onames[n]).t + (traj_slot[a] - work.t); };      // step a's output n inside its slot
+  auto point_p_at_slot = [&](int a) {
+    double* q_ = traj_slot_p[a];
+    for (int n = 0; n < 4; ++n) { ex.redirect_t(f(pnames[n]).t, q_); q_ += (n < 3 ? n3p : n3); }
+  };
   if (mode != MODE_AD) {
     for (const char* a : {"mfx", "mfy", "cx", "cy"}) { dev_zero(ex, f(a).t, b3); if (mode == MODE_TL) dev_zero(ex, f(a).p, b3); }
     if (nh) zh_init(mode);
     for (int it = 0; it < n_split; ++it) {
       const int a = ck_base + it;
+      const bool last = it == n_split - 1;
+      ex.nrt = ex.nrp = 0;
       if (mode == MODE_NL) {
-        for (int n = 0; n < ns; ++n) dev_copy(ex, ck(a, n), f(names[n]).t, bytes(n));
+        if (it > 0 && has_slot(a - 1)) { for (int n = 0; n < ns; ++n) ex.redirect_t(f(names[n]).t, slot_out(a - 1, n)); }
+        else for (int n = 0; n < ns; ++n) dev_copy(ex, ck(a, n), f(names[n]).t, bytes(n));
         ex.tshift = has_slot(a) ? traj_slot[a] - work.t : 0;
+        if (has_slot(a) && p_in_slot) point_p_at_slot(a);
+      } else if (it & 1) {
+        for (int n = 0; n < ns; ++n) {
+          ex.redirect_t(f(names[n]).t, f(onames[n]).t); ex.redirect_t(f(onames[n]).t, f(names[n]).t);
+          ex.redirect_p(f(names[n]).p, f(onames[n]).p); ex.redirect_p(f(onames[n]).p, f(names[n]).p);
+        }
       }
-      last_acoustic = (it == n_split - 1);
+      last_acoustic = last;
       run_group(acoustic, nullptr, mode);
-      for (int n = 0; n < ns; ++n) {
-        dev_copy(ex, f(names[n]).t, ex.sh(f(onames[n])).t, bytes(n));
-        if (mode == MODE_TL) dev_copy(ex, f(names[n]).p, f(onames[n]).p, bytes(n));
+      if (mode == MODE_NL) {
+        if (last || !has_slot(a)) for (int n = 0; n < ns; ++n) dev_copy(ex, f(names[n]).t, f(onames[n]).t + ex.tshift, bytes(n));
+        if (has_slot(a)) {
+          if (!p_in_slot) slot_io(a, true);
+          else if (last) { ex.nrt = 0; slot_io(a, false); }         // what follows dyn_core reads the pressures in their own fields
+        }
+      } else if (last && !(it & 1)) {
+        for (int n = 0; n < ns; ++n) { dev_copy(ex, f(names[n]).t, f(onames[n]).t, bytes(n)); dev_copy(ex, f(names[n]).p, f(onames[n]).p, bytes(n)); }
       }
-      if (mode == MODE_NL && has_slot(a)) slot_io(a, true);
-      ex.tshift = 0;
+      ex.tshift = 0; ex.nrt = ex.nrp = 0;
     }
   } else {
-    // incoming adjoint lives in the input-named buffers; move it to the *_o side of the last step
+    // the incoming adjoint lives in the input-named buffers, which stand for the *_o side of the last step
     if (nh) dev_zero(ex, f("zh").p, n3p * 8);      // the heights leave dyn_core unused: no incoming adjoint
     for (int it = n_split - 1; it >= 0; --it) {
-      const int a = ck_base + it;
-      for (int n = 0; n < ns; ++n) dev_copy(ex, f(names[n]).t, ck(a, n), bytes(n));
+      const int a = ck_base + it, r = n_split - 1 - it;
+      ex.nrt = ex.nrp = 0;
+      if (it > 0 && has_slot(a - 1)) { for (int n = 0; n < ns; ++n) ex.redirect_t(f(names[n]).t, slot_out(a - 1, n)); }
+      else for (int n = 0; n < ns; ++n) dev_copy(ex, f(names[n]).t, ck(a, n), bytes(n));
       last_acoustic = (it == n_split - 1);
       if (has_slot(a)) {       // this step's intermediates were kept by the forward sweep
         ex.tshift = traj_slot[a] - work.t;
-        slot_io(a, false);
+        if (p_in_slot) point_p_at_slot(a); else slot_io(a, false);
       } else {                 // recompute this step's nonlinear intermediates (flux capacitors left alone)
         ex.tshift = 0;
         run_group(acoustic, nullptr, MODE_NL, true);
       }
       for (auto& zr : acoustic_zero) dev_zero(ex, zr.first, zr.second * 8);      // the few work adjoints no stage launch stores first (plan_adjoint)
-      for (int n = 0; n < ns; ++n) { dev_copy(ex, f(onames[n]).p, f(names[n]).p, bytes(n)); dev_zero(ex, f(names[n]).p, bytes(n)); }
+      if (!(r & 1)) {          // adjoint of the outputs in the input-named buffers: swap the two sides
+        for (int n = 0; n < ns; ++n) { ex.redirect_p(f(names[n]).p, f(onames[n]).p); ex.redirect_p(f(onames[n]).p, f(names[n]).p); dev_zero(ex, f(onames[n]).p, bytes(n)); }
+      } else for (int n = 0; n < ns; ++n) dev_zero(ex, f(names[n]).p, bytes(n));
       run_group(acoustic, nullptr, MODE_AD);
       // pe, peln, pk, pkz of earlier steps are overwritten by later ones: their adjoint is zero there
       for (const char* a_ : {"pe", "peln", "pk"}) dev_zero(ex, f(a_).p, n3p * 8);
       dev_zero(ex, f("pkz").p, b3);
-      ex.tshift = 0;
+      ex.tshift = 0; ex.nrt = ex.nrp = 0;
     }
+    if (n_split & 1) for (int n = 0; n < ns; ++n) dev_copy(ex, f(names[n]).p, f(onames[n]).p, bytes(n));      // an odd number of swaps
     if (nh) zh_init(MODE_AD);
   }
 }

@@ -438,9 +438,10 @@ inline void Dynamics::tracer_fwd(int mode) {
     }
     run_group(tracer_pre, nullptr, mode);
     for (int n = 0; n < nq; ++n) {
-      dev_copy(ex, qc.t, q[n].t, b3);
-      if (mode == MODE_TL) dev_copy(ex, qc.p, q[n].p, b3);
+      ex.nrt = ex.nrp = 0;             // the transport program reads tracer n where it is (exec.h Redir); its output cannot go there (neighbours' halos)
+      ex.redirect_t(qc.t, q[n].t); ex.redirect_p(qc.p, q[n].p);
       run_group(tracer_q, nullptr, mode);
+      ex.nrt = ex.nrp = 0;
       dev_copy(ex, q[n].t, qc_o.t, b3);
       if (mode == MODE_TL) dev_copy(ex, q[n].p, qc_o.p, b3);
     }
@@ -468,11 +469,13 @@ inline void Dynamics::tracer_ad() {
     if (nsplt > 1) dev_copy(ex, dp1.t, subck(km, it, nq), b3);
     run_group(tracer_pre, nullptr, MODE_NL);
     for (int n = nq - 1; n >= 0; --n) {
-      dev_copy(ex, qc.t, nsplt > 1 ? subck(km, it, n) : q[n].t, b3);
+      ex.nrt = ex.nrp = 0;             // trajectory of tracer n read where it is, the incoming adjoint likewise; the result is built in qc.p
+      ex.redirect_t(qc.t, nsplt > 1 ? subck(km, it, n) : q[n].t); ex.redirect_p(qc_o.p, q[n].p);
       run_group(tracer_q, nullptr, MODE_NL);
       for (auto& zr : tracer_zero) dev_zero(ex, zr.first, zr.second * 8);       // plan_adjoint: the rest is stored by its first stage launch
-      dev_copy(ex, qc_o.p, q[n].p, b3); dev_zero(ex, qc.p, b3);
+      dev_zero(ex, qc.p, b3);
       run_group(tracer_q, nullptr, MODE_AD);
+      ex.nrt = ex.nrp = 0;
       dev_copy(ex, q[n].p, qc.p, b3);
     }
     run_group(tracer_pre, nullptr, MODE_AD);

@@ -50,9 +50,18 @@ struct Exec {
   // face indices; what moves at run time is every field pointer, to the class's first tile (cls_off doubles into a one-level field).
   // Exchanges run once, over all tiles, with the shift off.
   size_t cls_off = 0;
+  // State rotation (dycore.h dyn_core): instead of copying the prognostic fields between the acoustic steps, the step's programs are
+  // pointed at where the values already are -- whole fields, matched by their base pointer (trajectory side rt, perturbation side rp).
+  struct Redir { const double* from; double* to; };
+  static constexpr int NREDIR = 24;
+  Redir rt[NREDIR], rp[NREDIR]; int nrt = 0, nrp = 0;
+  void redirect_t(const double* from, double* to) { if (nrt < NREDIR) rt[nrt++] = Redir{from, to}; else set_sticky("internal error: redirect table full"); }
+  void redirect_p(const double* from, double* to) { if (nrp < NREDIR) rp[nrp++] = Redir{from, to}; else set_sticky("internal error: redirect table full"); }
   Fld sh(const Fld& f) const {
     Fld r = f;
     if (tshift && f.t >= wlo && f.t < whi) r.t = f.t + tshift;
+    for (int k = 0; k < nrt; ++k) if (f.t == rt[k].from) { r.t = rt[k].to; break; }
+    for (int k = 0; k < nrp; ++k) if (f.p == rp[k].from) { r.p = rp[k].to; break; }
     if (cls_off) { if (r.t) r.t += cls_off * (size_t)f.nk; if (r.p) r.p += cls_off * (size_t)f.nk; }
     return r;
   }

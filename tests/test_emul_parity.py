@@ -122,7 +122,7 @@ def test_tracer_subcycling(case_q):
     assert case_q.dy.lib.L.fv3lm_tracer_nsplt(case_q.dy.h) >= 2
 
 
-@pytest.mark.parametrize("slots", ["0", "1"])
+@pytest.mark.parametrize("slots", ["0", "1", "2"])
 def test_trajectory_slots(slots, monkeypatch):
     """The backward sweep either finds a step's intermediates in a trajectory slot or recomputes them from the 4-field
     checkpoint (FV3LM_TRAJ_SLOTS caps the number of slots; default: as many as fit): same adjoint either way."""
