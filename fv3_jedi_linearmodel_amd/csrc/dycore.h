@@ -16,6 +16,7 @@
 #include "nh_ad.h"
 #include "tpfused.h"
 #include "tpad.h"
+#include "tp2.h"
 #include "dampt.h"
 #include <functional>
 #include <map>

@@ -26,12 +26,16 @@ struct TpFusedArgs {
   // (t == nullptr: none).  do_acc is cleared for the adjoint's trajectory recompute, which must leave the accumulators alone.
   Fld acx, acy, amfx, amfy; int do_acc;
   int store_fo = 1;                              // fxo, fyo are arrays of their own (0: the names alias fx2 / fy2 and nothing may write them)
+  int exp = 0;                                   // tp2.h timing experiments (never set in the product build)
   int store_mid = 1;                             // fy2, q_i, fx2, q_j likewise (0: the fused adjoint of tpad.h recomputes them; the nonlinear launch stores nothing)
 };
 // nonlinear / tangent-linear launch (the adjoint runs the staged launches of build_tp); traj: the values-only trajectory pass of
 // the levels with split schemes, in the nonlinear and the tangent mode alike
 FV3LM_LINK void run_tp_fused(Exec& ex, int mode, const TpFusedArgs& a0, const Ctx& c, bool traj = false);
 FV3LM_LINK void run_tp_outer_ad(Exec& ex, const TpFusedArgs& a0, const Ctx& c);
+// the same routine laid out for the wavefront (tp2.h): takes the nonlinear and tangent launches that store nothing for the staged adjoint
+FV3LM_LINK void run_tp2(Exec& ex, int mode, const TpFusedArgs& a0, const Ctx& c);
+inline bool tp2_enabled() { static const bool on = [] { const char* e = std::getenv("FV3LM_TP2"); return !(e && e[0] == '0'); }(); return on; }
 }  // namespace fv3
 
 #ifdef FV3LM_HOST_EMUL
@@ -49,6 +53,31 @@ FV3LM_LINK void run_tp_outer_ad(Exec& ex, const TpFusedArgs& a0, const Ctx& c);
 // the same with the slot index u of a per-thread register array (constant trip count E = ceil(n / NTH): static indices after unrolling)
 #define TPF_LOOPU(e, u, n, E) _Pragma("unroll") for (int u = 0; u < (E); ++u) if (const int e = tid + u * NTH; e < (n))
 #endif
+
+namespace fv3 {
+template <class T> struct TpfIO;
+template <> struct TpfIO<double> {
+  static constexpr int NC = 1;
+  DEV static double ld(const Fld& f, size_t n) { return f.t[n]; }
+  DEV static void st(const Fld& f, size_t n, double x) { f.t[n] = x; }
+  DEV static double lget(const double* v, int, int e) { return v[e]; }
+  DEV static void lset(double* v, int, int e, double x) { v[e] = x; }
+};
+template <> struct TpfIO<Dual> {
+  static constexpr int NC = 2;
+  DEV static Dual ld(const Fld& f, size_t n) { return Dual(f.t[n], f.p ? f.p[n] : 0.0); }
+  DEV static void st(const Fld& f, size_t n, const Dual& x) { f.t[n] = x.v; f.p[n] = x.d; }
+  DEV static Dual lget(const double* v, int nt, int e) { return Dual(v[e], v[nt + e]); }
+  DEV static void lset(double* v, int nt, int e, const Dual& x) { v[e] = x.v; v[nt + e] = x.d; }
+};
+// algorithmic bytes of one launch: 9 inputs (+ d2b, mass) read and 2 outputs written per cell (x2 in the tangent mode), + the six stored
+// trajectory intermediates of the nonlinear mode
+inline double tpf_bytes(const TpFusedArgs& a, const Geom& g, int mode) {
+  const double cells = double(g.tx) * g.ty * g.ntile * a.nk, nin = 9. + (a.d2b.t ? 1. : 0.) + (a.mass.t ? 1. : 0.);
+  return 8. * cells * (mode == MODE_TL ? 2. * (nin + 2.) : (nin + 2.) + (a.store_mid ? (a.store_fo ? 6. : 4.) : 0.));
+}
+
+}  // namespace fv3
 
 #if !defined(FV3LM_SPLIT_BUILD) || defined(FV3LM_IMPL_TPFUSED)
 namespace fv3 {
@@ -70,21 +99,6 @@ constexpr int TPF_NQ = TPF_QW * TPF_QH, TPF_NFY2 = TPF_QW * (TPF_H + 1), TPF_NQI
 constexpr int TPF_THREADS_NL = FV3LM_TPF_THREADS_NL, TPF_THREADS_TL = FV3LM_TPF_THREADS_TL;
 
 
-template <class T> struct TpfIO;
-template <> struct TpfIO<double> {
-  static constexpr int NC = 1;
-  DEV static double ld(const Fld& f, size_t n) { return f.t[n]; }
-  DEV static void st(const Fld& f, size_t n, double x) { f.t[n] = x; }
-  DEV static double lget(const double* v, int, int e) { return v[e]; }
-  DEV static void lset(double* v, int, int e, double x) { v[e] = x; }
-};
-template <> struct TpfIO<Dual> {
-  static constexpr int NC = 2;
-  DEV static Dual ld(const Fld& f, size_t n) { return Dual(f.t[n], f.p ? f.p[n] : 0.0); }
-  DEV static void st(const Fld& f, size_t n, const Dual& x) { f.t[n] = x.v; f.p[n] = x.d; }
-  DEV static Dual lget(const double* v, int nt, int e) { return Dual(v[e], v[nt + e]); }
-  DEV static void lset(double* v, int nt, int e, const Dual& x) { v[e] = x.v; v[nt + e] = x.d; }
-};
 // an LDS array of T over the rectangle [i0, i0+w) x [j0, ...)
 template <class T>
 struct TpfTile {
@@ -254,13 +268,6 @@ DEV void tp_fused_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int
 }
 
 inline void tpf_grid(const Geom& g, int& nbx, int& nby) { nbx = (g.tx + TPF_W - 1) / TPF_W; nby = (g.ty + TPF_H - 1) / TPF_H; }
-// algorithmic bytes of one launch: 9 inputs (+ d2b, mass) read and 2 outputs written per cell (x2 in the tangent mode), + the six stored
-// trajectory intermediates of the nonlinear mode
-inline double tpf_bytes(const TpFusedArgs& a, const Geom& g, int mode) {
-  const double cells = double(g.tx) * g.ty * g.ntile * a.nk, nin = 9. + (a.d2b.t ? 1. : 0.) + (a.mass.t ? 1. : 0.);
-  return 8. * cells * (mode == MODE_TL ? 2. * (nin + 2.) : (nin + 2.) + (a.store_mid ? (a.store_fo ? 6. : 4.) : 0.));
-}
-
 #ifndef FV3LM_HOST_EMUL
 template <class T, bool STORE, int NTH, bool TRAJ = false>
 __global__ void __launch_bounds__(NTH) k_tp_fused(TpFusedArgs a, Ctx c) {
@@ -271,6 +278,7 @@ __global__ void __launch_bounds__(NTH) k_tp_fused(TpFusedArgs a, Ctx c) {
 #endif
 
 FV3LM_LINK void run_tp_fused(Exec& ex, int mode, const TpFusedArgs& a0, const Ctx& c, bool traj) {
+  if (!traj && (mode == MODE_TL || !a0.store_mid) && tp2_enabled()) { run_tp2(ex, mode, a0, c); return; }
   TpFusedArgs a = a0;
   for (Fld* f : {&a.q, &a.crx, &a.cry, &a.xfx, &a.yfx, &a.rax, &a.ray, &a.mx, &a.my, &a.mass, &a.d2b, &a.d2b_t, &a.fx, &a.fy, &a.fy2, &a.q_i, &a.fxo, &a.fx2, &a.q_j, &a.fyo, &a.acx, &a.acy, &a.amfx, &a.amfy}) *f = ex.sh(*f);
   a.do_acc = (a.acx.t && !ex.skip_accum) ? 1 : 0;

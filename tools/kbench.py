@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--grep", default="")
     ap.add_argument("--top", type=int, default=25)
     ap.add_argument("--nh", action="store_true")
+    ap.add_argument("--group", default="", help="after one ordinary step: time this kernel group alone (TL and NL), e.g. d_sw")
+    ap.add_argument("--experiment", default="", help="comma list of FV3LM_TP2_EXPERIMENT values to time the group with (experiment builds only)")
     args = ap.parse_args()
     if args.lib:
         os.environ["FV3LM_LIB"] = os.path.abspath(args.lib)
@@ -37,6 +39,19 @@ def main():
     def step():
         c.dy.state_restore(); c.dy.step_tl(); c.dy.state_restore(); c.dy.step_nl(); c.dy.step_ad()
     step(); c.dy.sync()
+    if args.group:
+        for ex_ in [e for e in (args.experiment.split(",") if args.experiment else ["0"])]:
+            os.environ["FV3LM_TP2_EXPERIMENT"] = ex_
+            c.dy.run_group(args.group, 1); c.dy.run_group(args.group, 0); c.dy.sync()
+            c.dy.profile_begin()
+            for _ in range(3):
+                c.dy.run_group(args.group, 1); c.dy.run_group(args.group, 0)
+            prof = c.dy.profile_end()
+            print("group %s, experiment %s:" % (args.group, ex_))
+            for k, (n_, m_, b_) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+                if not args.grep or any(g in k for g in args.grep.split(",")):
+                    print("  %-22s %5d %10.3f ms %8.4f ms/launch %9.1f GB/s" % (k, n_, m_, m_ / n_, (b_ / 1e9) / (m_ * 1e-3) if m_ > 0 else 0))
+        return
     t0 = time.perf_counter(); step(); step(); c.dy.sync(); dt = (time.perf_counter() - t0) / 2
     c.dy.profile_begin(); step(); prof = c.dy.profile_end()
     tot = sum(v[1] for v in prof.values())
