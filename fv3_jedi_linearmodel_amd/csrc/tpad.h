@@ -44,6 +44,13 @@ namespace fv3 {
 #define TPD_LOOPU(e, u, n, E) TPF_LOOPU(e, u, n, E)
 #define TPD_QACC_DIRECT 0
 #endif
+// operands of the next phase fetched into registers before the barrier that ends the current one (0: every load where it is used)
+#ifndef FV3LM_TPD_PREFETCH
+#define FV3LM_TPD_PREFETCH 1
+#endif
+#ifndef FV3LM_TPD_EXP          /* timing experiments (tools/kbench.py --group; results are garbage): a.exp bits switch phases off */
+#define FV3LM_TPD_EXP 0
+#endif
 #ifndef FV3LM_TPD_THREADS
 #define FV3LM_TPD_THREADS 1024
 #endif
@@ -53,7 +60,8 @@ constexpr int TPD_AW = TPD_W + 12, TPD_AH = TPD_H + 12;      // flux-adjoint til
 constexpr int TPD_NQ = TPD_QW * TPD_QH;                      // q; q_i / q_j values, later gi / gj
 constexpr int TPD_NF2 = TPD_QW * (TPD_QH + 1);               // inner flux values, later (in place) their adjoints
 constexpr int TPD_NFA = (TPD_AW * TPD_QH > TPD_AH * TPD_QW ? TPD_AW * TPD_QH : TPD_AH * TPD_QW);    // outer-flux adjoint tile (either orientation)
-constexpr int TPD_NT = 2 * TPD_NQ + TPD_NF2 + 2 * TPD_NFA;   // 64 x 32 cells: 14,210 doubles = 114 KB, one 1024-thread block per CU (measured: 4.55 ms per launch at C192L127 x 6; 64 x 16 / 512 threads / two blocks: 4.81)
+constexpr int TPD_NC = TPD_NFA;                              // Courant numbers of the sweep being transposed (layout of the flux-adjoint tile)
+constexpr int TPD_NT = 2 * TPD_NQ + TPD_NF2 + 2 * TPD_NFA + TPD_NC;   // 64 x 32 cells: 14,210 doubles = 114 KB, one 1024-thread block per CU (measured: 4.55 ms per launch at C192L127 x 6; 64 x 16 / 512 threads / two blocks: 4.81)
 constexpr int TPD_THREADS = FV3LM_TPD_THREADS;
 
 // Transposed 1-D sweep in two stages.  flux(m) of iord 2 is  q_up c'(3 -+ 2c) + al(m) (1 -+ c)^2 -+ al(m -+ 1) c (1 -+ c)  (upper signs: c > 0,
@@ -82,6 +90,7 @@ DEV double tps_q(int iord, bool face, int k, int n1, double f0, double fp, doubl
   if (cp > 0.) s += (iord == 1 ? 1. : cp * (3. - 2. * cp)) * fp;
   if (!(c0 > 0.)) s += (iord == 1 ? 1. : -c0 * (3. + 2. * c0)) * f0;
   if (iord == 1) return s;
+  if (!face || (k >= 4 && k <= n1 - 4)) return s + P2 * al[0] + P1 * al[1] + P1 * al[2] + P2 * al[3];      // the four edge values k-1 .. k+2 away from the cube edges: constant weights
 #pragma unroll
   for (int n = 0; n < 4; ++n) if (al[n] != 0.) s += tps_w(face, k - 1 + n, n1, da, k) * al[n];
   return s;
@@ -93,6 +102,25 @@ DEV double tps_q333(bool face, int k, int n1, const double* f, const double* cc,
 #pragma unroll
   for (int n = 0; n < 4; ++n) { const int m = k - 1 + n; if (m >= 1 && m <= n1 && f[n] != 0.) s += ppm_dq(333, face, m, n1, k, da, cc[n]) * f[n]; }
   return s;
+}
+
+// Scheme-2 flux at interface m of a line held in LDS (cell0 = the element of cell m, S doubles between neighbours): value and derivative
+// with respect to the Courant number from the five cells around the UPWIND cell -- two edge values instead of the three of the generic
+// ppm_flux<Dual>, no dual arithmetic, the cube-edge weights (edges.h ppm_w) only within two cells of an edge.  Same expression as tp2.h.
+template <int S, class D>
+DEV void tpd_flux2(bool face, int m, int n1, const double* cell0, double c, const D& da, double& v, double& dc) {
+  const bool up = c > 0.;
+  const int u = m - (up ? 1 : 0);
+  const double* p = cell0 - (up ? S : 0);
+  double w0[4] = {P2, P1, P1, P2}, w1[4] = {P2, P1, P1, P2};
+  if (face && (u <= 2 || u >= n1 - 2)) { ppm_w(true, u, n1, da, w0); ppm_w(true, u + 1, n1, da, w1); }
+  const double qa = p[-2 * S], qb = p[-S], qt = p[0], qd = p[S], qe = p[2 * S];
+  const double a0 = w0[0] * qa + w0[1] * qb + w0[2] * qt + w0[3] * qd, a1 = w1[0] * qb + w1[1] * qt + w1[2] * qd + w1[3] * qe;
+  const double al0 = up ? a1 : a0, B = up ? a0 : a1, sc = up ? c : -c;
+  const double X = al0 - qt, Y = B + al0 - (qt + qt), Z = X - sc * Y;
+  v = qt + (1. - sc) * Z;
+  const double dsc = -Z - (1. - sc) * Y;
+  dc = up ? dsc : -dsc;
 }
 
 // One block: cells I0..I1 x J0..J1 of level k of one tile (+ the halo cells next to them in the first / last block row and column).
@@ -114,85 +142,131 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
   double* F2 = lds + 2 * TPD_NQ;         // inner flux values, then their adjoints in place
   double* FA = F2 + TPD_NF2;             // outer-flux adjoint 0.5 m f_ad, three more cells either side along the sweep
   double* AL = FA + TPD_NFA;             // adjoint of the edge values of the sweep being transposed
+  // Courant numbers of the sweep being transposed, loaded once per sweep instead of once per use (three phases read them, with neighbours):
+  //   crx, x-faces I0-6 .. I1+6 of rows J0-3 .. J1+3, index cxe (= branch A's fae)      -- outer sweep of branch A, inner sweep of branch B
+  //   cry, y-faces J0-6 .. J1+6 of columns I0-3 .. I1+3, index cye (= branch B's fae)   -- inner sweep of branch A, outer sweep of branch B
+  // zero outside the range of the fluxes (where the flux adjoints are zero as well)
+  double* CT = AL + TPD_NFA;
+  auto cxe = [&](int i, int j) { return (j - (J0 - 3)) * TPD_AW + (i - (I0 - 6)); };
+  auto cye = [&](int i, int j) { return (j - (J0 - 6)) * TPD_QW + (i - (I0 - 3)); };
+  auto load_cx = [&](int e) -> double { const int i = I0 - 6 + e % TPD_AW, j = J0 - 3 + e / TPD_AW; return (i >= 1 && i <= nx + 1 && i <= I1 + 6 && j <= J1 + 3) ? a.crx.t[at(i, j)] : 0.; };
+  auto load_cy = [&](int e) -> double { const int i = I0 - 3 + e % TPD_QW, j = J0 - 6 + e / TPD_QW; return (j >= 1 && j <= ny + 1 && j <= J1 + 6 && i <= I1 + 3) ? a.cry.t[at(i, j)] : 0.; };
+  // Prefetch: the global operands of a phase are loaded into registers during the phase before it, ahead of the barrier between them.
+#if defined(FV3LM_HOST_EMUL) || defined(FV3LM_TPD_NOUNROLL)
+  constexpr bool PRE = false;
+#else
+  constexpr bool PRE = FV3LM_TPD_PREFETCH != 0;
+#endif
+#define TPD_PF(arr, u, expr) (PRE ? arr[u] : (expr))
+  // elements per thread of each phase (trip counts of the unrolled loops; the prefetch arrays have that many slots)
+  constexpr int E_AQ = (TPD_AW * TPD_QH + NTH - 1) / NTH, E_QA = (TPD_QW * TPD_AH + NTH - 1) / NTH, E_Q = (TPD_NQ + NTH - 1) / NTH,
+                E_V = (TPD_QW * (TPD_H + 1) + NTH - 1) / NTH, E_F = ((TPD_W + 1) * TPD_H + NTH - 1) / NTH,
+                E_FB = (TPD_W * (TPD_H + 1) + NTH - 1) / NTH, E_I = (TPD_QW * TPD_H + NTH - 1) / NTH, E_J = (TPD_W * TPD_QH + NTH - 1) / NTH,
+                E_G = (TPD_QW * (TPD_QH - 1) + NTH - 1) / NTH, E_GB = ((TPD_QW - 1) * TPD_QH + NTH - 1) / NTH;
+#define TPD_SLOTS(E) (PRE ? (E) : 1)
   auto qe = [&](int i, int j) { return (j - (J0 - 3)) * TPD_QW + (i - (I0 - 3)); };
   auto corner_cell = [&](int i, int j) { return face && (i < 1 || i > nx) && (j < 1 || j > ny); };
   // q_ad of the owned cells: area term kept by the thread that also finishes the cell (same element loop in both phases)
   constexpr int EQ = (TPD_NQ + NTH - 1) / NTH;
   double qacc[EQ];
 
+  auto cl = [](int m, int n1) { return m < 1 ? 1 : (m > n1 ? n1 : m); };      // face index clamped into its range (used by the iord 333 path only)
+  (void)cl;
   { constexpr int n = TPD_NQ;
     TPD_LOOP(e, n) { const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW; Q[e] = (i <= I1 + 3 && j <= J1 + 3) ? a.q.t[at(i, j)] : 0.; } }
-  TPF_SYNC();
 
   // ============================== branch A: outer sweep in x, inner sweep in y ==============================
   {
     auto f2e = [&](int i, int j) { return (j - (J0 - 2)) * TPD_QW + (i - (I0 - 3)); };          // rows J0-2 .. J1+3
     auto fae = [&](int i, int j) { return (j - (J0 - 3)) * TPD_AW + (i - (I0 - 6)); };          // columns I0-6 .. I1+6, rows J0-3 .. J1+3
     auto ale = [&](int i, int j) { return (j - (J0 - 5)) * TPD_QW + (i - (I0 - 3)); };          // inner sweep: rows J0-5 .. J1+6
-    { constexpr int n = TPD_AW * TPD_QH;
+    { constexpr int n = TPD_AW * TPD_QH;            // outer-flux adjoints and the Courant numbers of the outer sweep
       TPD_LOOP(e, n) {
         const int i = I0 - 6 + e % TPD_AW, j = J0 - 3 + e / TPD_AW;
         FA[e] = (i >= 1 && i <= nx + 1 && j >= 1 && j <= ny && i <= I1 + 6 && j <= J1 + 3) ? 0.5 * a.mx.t[at(i, j)] * a.fx.p[at(i, j)] : 0.;
+        CT[e] = load_cx(e);
       } }
+    double cv[TPD_SLOTS(E_V)];                                 // prefetch: Courant numbers of the inner flux values
+    if constexpr (PRE) { constexpr int n = TPD_QW * (TPD_H + 1);
+      TPD_LOOPU(e, u, n, E_V) { const int i = I0 - 3 + e % TPD_QW, j = J0 + e / TPD_QW; cv[u] = (i <= I1 + 3 && j <= J1 + 1) ? a.cry.t[at(i, j)] : 0.; } }
+    TPF_SYNC();
+    double ar2[TPD_SLOTS(E_I)], y02[TPD_SLOTS(E_I)], y12[TPD_SLOTS(E_I)], ry2[TPD_SLOTS(E_I)];  // prefetch: q_i values
+    if constexpr (PRE) { constexpr int n = TPD_QW * TPD_H;
+      TPD_LOOPU(e, u, n, E_I) { const int i = I0 - 3 + e % TPD_QW, j = J0 + e / TPD_QW; const bool in = i <= I1 + 3 && j <= J1;
+        ar2[u] = in ? MET(area, i, j) : 0.; y02[u] = in ? a.yfx.t[at(i, j)] : 0.; y12[u] = in ? a.yfx.t[at(i, j + 1)] : 0.; ry2[u] = in ? a.ray.t[at(i, j)] : 1.; } }
     { constexpr int n = TPD_QW * (TPD_H + 1);       // inner flux values fy2 on rows J0 .. J1+1
-      TPD_LOOP(e, n) {
+      TPD_LOOPU(e, u, n, E_V) {
         const int i = I0 - 3 + e % TPD_QW, j = J0 + e / TPD_QW;
         if (i > I1 + 3 || j > J1 + 1) continue;
         auto line = [&](int jj) -> double { int ii = i, j2 = jj; if (face) corner_map(g, 2, ii, j2); return Q[qe(ii, j2)]; };
         const MetY da{c.m.dya, c, tile, i};
-        F2[f2e(i, j)] = ppm_flux<double>(iord, face, j, ny + 1, line, da, a.cry.t[at(i, j)]);
+        if (FV3LM_TPD_EXP && (a.exp & 1)) { F2[f2e(i, j)] = line(j) * TPD_PF(cv, u, a.cry.t[at(i, j)]); continue; }
+        const double cc = TPD_PF(cv, u, a.cry.t[at(i, j)]);
+        if (iord == 2 && !(face && (i < 1 || i > nx) && (j <= 3 || j >= ny - 1))) { double v_, d_; tpd_flux2<TPD_QW>(face, j, ny + 1, Q + qe(i, j), cc, da, v_, d_); F2[f2e(i, j)] = v_; }
+        else F2[f2e(i, j)] = ppm_flux<double>(iord, face, j, ny + 1, line, da, cc);
       } }
     TPF_SYNC();
+    double fx3[TPD_SLOTS(E_F)];                                // prefetch: own x-faces
+    if constexpr (PRE) { constexpr int w = TPD_W + 1, n = w * TPD_H;
+      TPD_LOOPU(e, u, n, E_F) { const int i = I0 + e % w, j = J0 + e / w; fx3[u] = (j <= J1 && (i <= I1 || (lastx && i == I1 + 1))) ? a.fx.p[at(i, j)] : 0.; } }
     { constexpr int n = TPD_QW * TPD_H;             // q_i values
-      TPD_LOOP(e, n) {
+      TPD_LOOPU(e, u, n, E_I) {
         const int i = I0 - 3 + e % TPD_QW, j = J0 + e / TPD_QW;
         if (i > I1 + 3 || j > J1) continue;
-        QG[qe(i, j)] = (Q[qe(i, j)] * MET(area, i, j) + a.yfx.t[at(i, j)] * F2[f2e(i, j)] - a.yfx.t[at(i, j + 1)] * F2[f2e(i, j + 1)]) / a.ray.t[at(i, j)];
+        QG[qe(i, j)] = (Q[qe(i, j)] * TPD_PF(ar2, u, MET(area, i, j)) + TPD_PF(y02, u, a.yfx.t[at(i, j)]) * F2[f2e(i, j)] - TPD_PF(y12, u, a.yfx.t[at(i, j + 1)]) * F2[f2e(i, j + 1)]) / TPD_PF(ry2, u, a.ray.t[at(i, j)]);
       } }
     TPF_SYNC();
+    double ry4[TPD_SLOTS(E_Q)], ar4[TPD_SLOTS(E_Q)], ro4[TPD_SLOTS(E_Q)];            // prefetch: gi
+    if constexpr (PRE) { constexpr int n = TPD_NQ;
+      TPD_LOOPU(e, u, n, E_Q) { const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW;
+        const bool in = i >= GI0 && i <= GI1 && j >= 1 && j <= ny && j <= J1 + 3, own = in && j >= J0 && j <= J1;
+        ry4[u] = in ? a.ray.t[at(i, j)] : 1.; ar4[u] = in ? MET(area, i, j) : 0.; ro4[u] = own ? a.ray.p[at(i, j)] : 0.; } }
     auto FX = [&](int m, int j) { return FA[fae(m, j)]; };
     { constexpr int w = TPD_W + 1, n = w * TPD_H;   // own x-faces: Courant-number and mass-flux adjoints of the outer sweep
-      TPD_LOOP(e, n) {
+      TPD_LOOPU(e, u, n, E_F) {
         const int i = I0 + e % w, j = J0 + e / w;
         if (j > J1 || !(i <= I1 || (lastx && i == I1 + 1))) continue;
-        const double fo = FX(i, j), fxad = a.fx.p[at(i, j)];
+        const double fo = FX(i, j), fxad = TPD_PF(fx3, u, a.fx.p[at(i, j)]);
         if (fo == 0. && fxad == 0.) continue;
+        if (FV3LM_TPD_EXP && (a.exp & 2)) continue;
         auto line = [&](int ii) -> Dual { return Dual(QG[qe(ii, j)], 0.); };
         const MetX da{c.m.dxa, c, tile, j};
-        const Dual fl = ppm_flux<Dual>(iord, face, i, nx + 1, line, da, Dual(a.crx.t[at(i, j)], 1.));
+        Dual fl;
+        if (iord == 2) tpd_flux2<1>(face, i, nx + 1, QG + qe(i, j), CT[cxe(i, j)], da, fl.v, fl.d);
+        else fl = ppm_flux<Dual>(iord, face, i, nx + 1, line, da, Dual(CT[cxe(i, j)], 1.));
         a.crx.p[at(i, j)] += fl.d * fo;
         a.mx.p[at(i, j)] += 0.5 * fl.v * fxad;
       } }
-    auto cl = [](int m, int n1) { return m < 1 ? 1 : (m > n1 ? n1 : m); };      // flux index clamped into its range (the flux adjoint is zero outside: the value does not matter, the address must exist)
-    if (iord == 2) {                                // edge-value adjoints of the outer sweep, columns I0-4 .. I1+5
+    if (iord == 2 && !(FV3LM_TPD_EXP && (a.exp & 4))) {                                // edge-value adjoints of the outer sweep, columns I0-4 .. I1+5
       constexpr int n = TPD_AW * TPD_QH;
       TPD_LOOP(e, n) {
         const int x = I0 - 6 + e % TPD_AW, j = J0 - 3 + e / TPD_AW;
         double s = 0.;
-        if (x >= I0 - 4 && x <= I1 + 5 && j >= 1 && j <= ny && j <= J1 + 3) {
-          const double cm = a.crx.t[at(cl(x - 1, nx + 1), j)], c0 = a.crx.t[at(cl(x, nx + 1), j)], cp = a.crx.t[at(cl(x + 1, nx + 1), j)];
-          s = tps_al(FA[e - 1], FA[e], FA[e + 1], cm, c0, cp);
-        }
+        if (x >= I0 - 4 && x <= I1 + 5 && j >= 1 && j <= ny && j <= J1 + 3) s = tps_al(FA[e - 1], FA[e], FA[e + 1], CT[e - 1], CT[e], CT[e + 1]);
         AL[e] = s;
       } }
     TPF_SYNC();
+    double yf5[TPD_SLOTS(E_G)], fy5[TPD_SLOTS(E_G)], mm5[TPD_SLOTS(E_G)];            // prefetch: fy2_ad
+    if constexpr (PRE) { constexpr int n = TPD_QW * (TPD_QH - 1);
+      TPD_LOOPU(e, u, n, E_G) { const int i = I0 - 3 + e % TPD_QW, m = J0 - 2 + e / TPD_QW;
+        const bool on = i >= GI0 && i <= GI1 && m >= 1 && m <= ny + 1 && m <= J1 + 3, in = on && i >= 1 && i <= nx;
+        yf5[u] = on ? a.yfx.t[at(i, m)] : 0.; fy5[u] = in ? a.fy.p[at(i, m)] : 0.; mm5[u] = in ? a.my.t[at(i, m)] : 0.; } }
     { constexpr int n = TPD_NQ;                     // gi = q_i_ad / ra_y on the owned columns; own cells: ra_y_ad, the area term of q_ad
       TPD_LOOPU(e, u, n, EQ) {
         const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW;
         double s = 0., acc = 0.;
         if (i >= GI0 && i <= GI1 && j >= 1 && j <= ny && j <= J1 + 3) {
           const bool own = j >= J0 && j <= J1;
-          const double ry = a.ray.t[at(i, j)], ar = MET(area, i, j), rold = own ? a.ray.p[at(i, j)] : 0.;
+          const double ry = TPD_PF(ry4, u, a.ray.t[at(i, j)]), ar = TPD_PF(ar4, u, MET(area, i, j)), rold = TPD_PF(ro4, u, own ? a.ray.p[at(i, j)] : 0.);
           const MetX da{c.m.dxa, c, tile, j};
           const int b0 = fae(i, j);
           if (iord == 333) {
             const double f[4] = {FA[b0 - 1], FA[b0], FA[b0 + 1], FA[b0 + 2]};
-            const double cc[4] = {a.crx.t[at(cl(i - 1, nx + 1), j)], a.crx.t[at(cl(i, nx + 1), j)], a.crx.t[at(cl(i + 1, nx + 1), j)], a.crx.t[at(cl(i + 2, nx + 1), j)]};
+            const double cc[4] = {CT[b0 - 1], CT[b0], CT[b0 + 1], CT[b0 + 2]};
             s = tps_q333(face, i, nx + 1, f, cc, da);
           } else {
-            const double c0 = a.crx.t[at(cl(i, nx + 1), j)], cp = a.crx.t[at(cl(i + 1, nx + 1), j)];
             const double al[4] = {AL[b0 - 1], AL[b0], AL[b0 + 1], AL[b0 + 2]};
-            s = tps_q(iord, face, i, nx + 1, FA[b0], FA[b0 + 1], c0, cp, al, da);
+            if (!(FV3LM_TPD_EXP && (a.exp & 8))) s = tps_q(iord, face, i, nx + 1, FA[b0], FA[b0 + 1], CT[b0], CT[b0 + 1], al, da);
           }
           s = s / ry;
           if (own) { a.ray.p[at(i, j)] = rold - QG[e] * s; acc = ar * s; }
@@ -201,13 +275,19 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
         QG[e] = s;
       } }
     TPF_SYNC();
+    double cyt[TPD_SLOTS(E_QA)], qo7[TPD_SLOTS(E_Q)];                     // the Courant numbers of the inner sweep (cry) on their way into CT; prefetch: q_ad
+    if constexpr (PRE) {
+      { constexpr int n = TPD_QW * TPD_AH; TPD_LOOPU(e, u, n, E_QA) cyt[u] = load_cy(e); }
+      { constexpr int n = TPD_NQ; TPD_LOOPU(e, u, n, E_Q) { const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW;
+          qo7[u] = (i < GI0 || i > GI1 || j < GJ0 || j > GJ1 || corner_cell(i, j) || i > I1 + 3 || j > J1 + 3) ? 0. : a.q.p[at(i, j)]; } }
+    }
     { constexpr int n = TPD_QW * (TPD_QH - 1);      // fy2_ad on rows J0-2 .. J1+3 of the owned columns, in place of the values; own y-faces: yfx_ad, my_ad (inner part)
-      TPD_LOOP(e, n) {
+      TPD_LOOPU(e, u, n, E_G) {
         const int i = I0 - 3 + e % TPD_QW, m = J0 - 2 + e / TPD_QW;
         double s = 0.;
         if (i >= GI0 && i <= GI1 && m >= 1 && m <= ny + 1 && m <= J1 + 3) {
           const bool in = i >= 1 && i <= nx, own = m >= J0 && (m <= J1 || (lasty && m == J1 + 1));
-          const double yf = a.yfx.t[at(i, m)], fyad = in ? a.fy.p[at(i, m)] : 0., mm = in ? a.my.t[at(i, m)] : 0.;
+          const double yf = TPD_PF(yf5, u, a.yfx.t[at(i, m)]), fyad = TPD_PF(fy5, u, in ? a.fy.p[at(i, m)] : 0.), mm = TPD_PF(mm5, u, in ? a.my.t[at(i, m)] : 0.);
           const double dg = (m <= ny ? QG[qe(i, m)] : 0.) - (m >= 2 ? QG[qe(i, m - 1)] : 0.);
           s = yf * dg + 0.5 * mm * fyad;
           if (own) {          // yfx and my may be one array (the mass transport): two accumulates in program order
@@ -218,17 +298,16 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
         }
         F2[e] = s;
       } }
+    { constexpr int n = TPD_QW * TPD_AH;            // CT <- cry (the outer sweep's crx was last read before the barrier above)
+      TPD_LOOPU(e, u, n, E_QA) CT[e] = TPD_PF(cyt, u, load_cy(e)); }
     TPF_SYNC();
     auto FY2 = [&](int i, int m) { return (m >= J0 - 2 && m <= J1 + 3) ? F2[f2e(i, m)] : 0.; };
-    if (iord == 2) {                                // edge-value adjoints of the inner sweep, rows J0-4 .. J1+5 of the owned columns
+    if (iord == 2 && !(FV3LM_TPD_EXP && (a.exp & 4))) {                                // edge-value adjoints of the inner sweep, rows J0-4 .. J1+5 of the owned columns
       constexpr int n = TPD_QW * TPD_AH;
       TPD_LOOP(e, n) {
         const int i = I0 - 3 + e % TPD_QW, x = J0 - 5 + e / TPD_QW;
         double s = 0.;
-        if (i >= GI0 && i <= GI1 && x >= J0 - 4 && x <= J1 + 5) {
-          const double cm = a.cry.t[at(i, cl(x - 1, ny + 1))], c0 = a.cry.t[at(i, cl(x, ny + 1))], cp = a.cry.t[at(i, cl(x + 1, ny + 1))];
-          s = tps_al(FY2(i, x - 1), FY2(i, x), FY2(i, x + 1), cm, c0, cp);
-        }
+        if (i >= GI0 && i <= GI1 && x >= J0 - 4 && x <= J1 + 5) s = tps_al(FY2(i, x - 1), FY2(i, x), FY2(i, x + 1), CT[e], CT[e + TPD_QW], CT[e + 2 * TPD_QW]);
         AL[e] = s;
       } }
     TPF_SYNC();
@@ -237,18 +316,18 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
         const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW;
         const double acc = TPD_QACC_DIRECT ? 0. : qacc[u];
         if (i < GI0 || i > GI1 || j < GJ0 || j > GJ1 || corner_cell(i, j)) continue;
-        const double qold = a.q.p[at(i, j)];
+        const double qold = TPD_PF(qo7, u, a.q.p[at(i, j)]);
         const MetY da{c.m.dya, c, tile, i};
+        const int cb = cye(i, j);
         double s;
         if (iord == 333) {
           const double f[4] = {FY2(i, j - 1), FY2(i, j), FY2(i, j + 1), FY2(i, j + 2)};
-          const double cc[4] = {a.cry.t[at(i, cl(j - 1, ny + 1))], a.cry.t[at(i, cl(j, ny + 1))], a.cry.t[at(i, cl(j + 1, ny + 1))], a.cry.t[at(i, cl(j + 2, ny + 1))]};
+          const double cc[4] = {CT[cb - TPD_QW], CT[cb], CT[cb + TPD_QW], CT[cb + 2 * TPD_QW]};
           s = tps_q333(face, j, ny + 1, f, cc, da);
         } else {
-          const double c0 = a.cry.t[at(i, cl(j, ny + 1))], cp = a.cry.t[at(i, cl(j + 1, ny + 1))];
           const int b0 = ale(i, j);
           const double al[4] = {AL[b0 - TPD_QW], AL[b0], AL[b0 + TPD_QW], AL[b0 + 2 * TPD_QW]};
-          s = tps_q(iord, face, j, ny + 1, FY2(i, j), FY2(i, j + 1), c0, cp, al, da);
+          if (!(FV3LM_TPD_EXP && (a.exp & 8))) s = tps_q(iord, face, j, ny + 1, FY2(i, j), FY2(i, j + 1), CT[cb], CT[cb + TPD_QW], al, da);
         }
         a.q.p[at(i, j)] = qold + (acc + s);
       } }
@@ -258,14 +337,19 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
         if (i < GI0 || i > GI1 || !(m <= J1 || (lasty && m == J1 + 1))) continue;
         const double f = F2[f2e(i, m)];
         if (f == 0.) continue;
+        if (FV3LM_TPD_EXP && (a.exp & 2)) continue;
         auto line = [&](int jj) -> Dual { int ii = i, j2 = jj; if (face) corner_map(g, 2, ii, j2); return Dual(Q[qe(ii, j2)], 0.); };
         const MetY da{c.m.dya, c, tile, i};
-        a.cry.p[at(i, m)] += ppm_flux<Dual>(iord, face, m, ny + 1, line, da, Dual(a.cry.t[at(i, m)], 1.)).d * f;
+        double v_, d_;
+        if (iord == 2 && !(face && (i < 1 || i > nx) && (m <= 3 || m >= ny - 1))) tpd_flux2<TPD_QW>(face, m, ny + 1, Q + qe(i, m), CT[cye(i, m)], da, v_, d_);
+        else d_ = ppm_flux<Dual>(iord, face, m, ny + 1, line, da, Dual(CT[cye(i, m)], 1.)).d;
+        a.cry.p[at(i, m)] += d_ * f;
       } }
     TPF_SYNC();
   }
 
   // ============================== branch B: outer sweep in y, inner sweep in x ==============================
+  // (CT holds cry from branch A's inner sweep: the Courant numbers of this branch's outer sweep)
   {
     auto f2e = [&](int i, int j) { return (j - (J0 - 3)) * (TPD_QW + 1) + (i - (I0 - 2)); };    // columns I0-2 .. I1+3 (pitch TPD_QW+1), rows J0-3 .. J1+3
     auto fae = [&](int i, int j) { return (j - (J0 - 6)) * TPD_QW + (i - (I0 - 3)); };          // rows J0-6 .. J1+6, columns I0-3 .. I1+3
@@ -275,65 +359,83 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
         const int i = I0 - 3 + e % TPD_QW, j = J0 - 6 + e / TPD_QW;
         FA[e] = (j >= 1 && j <= ny + 1 && i >= 1 && i <= nx && j <= J1 + 6 && i <= I1 + 3) ? 0.5 * a.my.t[at(i, j)] * a.fy.p[at(i, j)] : 0.;
       } }
+    double ar2[TPD_SLOTS(E_J)], x02[TPD_SLOTS(E_J)], x12[TPD_SLOTS(E_J)], rx2[TPD_SLOTS(E_J)];  // prefetch: q_j values
+    if constexpr (PRE) { constexpr int n = TPD_W * TPD_QH;
+      TPD_LOOPU(e, u, n, E_J) { const int i = I0 + e % TPD_W, j = J0 - 3 + e / TPD_W; const bool in = i <= I1 && j <= J1 + 3;
+        ar2[u] = in ? MET(area, i, j) : 0.; x02[u] = in ? a.xfx.t[at(i, j)] : 0.; x12[u] = in ? a.xfx.t[at(i + 1, j)] : 0.; rx2[u] = in ? a.rax.t[at(i, j)] : 1.; } }
     { constexpr int w = TPD_W + 1, n = w * TPD_QH;  // inner flux values fx2 on columns I0 .. I1+1
       TPD_LOOP(e, n) {
         const int i = I0 + e % w, j = J0 - 3 + e / w;
         if (i > I1 + 1 || j > J1 + 3) continue;
         auto line = [&](int ii) -> double { int i2 = ii, jj = j; if (face) corner_map(g, 1, i2, jj); return Q[qe(i2, jj)]; };
         const MetX da{c.m.dxa, c, tile, j};
-        F2[f2e(i, j)] = ppm_flux<double>(iord, face, i, nx + 1, line, da, a.crx.t[at(i, j)]);
+        if (FV3LM_TPD_EXP && (a.exp & 1)) { F2[f2e(i, j)] = line(i) * a.crx.t[at(i, j)]; continue; }
+        const double cc = a.crx.t[at(i, j)];
+        if (iord == 2 && !(face && (j < 1 || j > ny) && (i <= 3 || i >= nx - 1))) { double v_, d_; tpd_flux2<1>(face, i, nx + 1, Q + qe(i, j), cc, da, v_, d_); F2[f2e(i, j)] = v_; }
+        else F2[f2e(i, j)] = ppm_flux<double>(iord, face, i, nx + 1, line, da, cc);
       } }
     TPF_SYNC();
+    double fy3[TPD_SLOTS(E_FB)];                               // prefetch: own y-faces
+    if constexpr (PRE) { constexpr int n = TPD_W * (TPD_H + 1);
+      TPD_LOOPU(e, u, n, E_FB) { const int i = I0 + e % TPD_W, j = J0 + e / TPD_W; fy3[u] = (i <= I1 && (j <= J1 || (lasty && j == J1 + 1))) ? a.fy.p[at(i, j)] : 0.; } }
     { constexpr int n = TPD_W * TPD_QH;             // q_j values
-      TPD_LOOP(e, n) {
+      TPD_LOOPU(e, u, n, E_J) {
         const int i = I0 + e % TPD_W, j = J0 - 3 + e / TPD_W;
         if (i > I1 || j > J1 + 3) continue;
-        QG[qe(i, j)] = (Q[qe(i, j)] * MET(area, i, j) + a.xfx.t[at(i, j)] * F2[f2e(i, j)] - a.xfx.t[at(i + 1, j)] * F2[f2e(i + 1, j)]) / a.rax.t[at(i, j)];
+        QG[qe(i, j)] = (Q[qe(i, j)] * TPD_PF(ar2, u, MET(area, i, j)) + TPD_PF(x02, u, a.xfx.t[at(i, j)]) * F2[f2e(i, j)] - TPD_PF(x12, u, a.xfx.t[at(i + 1, j)]) * F2[f2e(i + 1, j)]) / TPD_PF(rx2, u, a.rax.t[at(i, j)]);
       } }
     TPF_SYNC();
+    double rx4[TPD_SLOTS(E_Q)], ar4[TPD_SLOTS(E_Q)], ro4[TPD_SLOTS(E_Q)];            // prefetch: gj
+    if constexpr (PRE) { constexpr int n = TPD_NQ;
+      TPD_LOOPU(e, u, n, E_Q) { const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW;
+        const bool in = j >= GJ0 && j <= GJ1 && i >= 1 && i <= nx && i <= I1 + 3, own = in && i >= I0 && i <= I1;
+        rx4[u] = in ? a.rax.t[at(i, j)] : 1.; ar4[u] = in ? MET(area, i, j) : 0.; ro4[u] = own ? a.rax.p[at(i, j)] : 0.; } }
     auto FY = [&](int i, int m) { return FA[fae(i, m)]; };
     { constexpr int n = TPD_W * (TPD_H + 1);        // own y-faces: Courant-number and mass-flux adjoints of the outer sweep
-      TPD_LOOP(e, n) {
+      TPD_LOOPU(e, u, n, E_FB) {
         const int i = I0 + e % TPD_W, j = J0 + e / TPD_W;
         if (i > I1 || !(j <= J1 || (lasty && j == J1 + 1))) continue;
-        const double fo = FY(i, j), fyad = a.fy.p[at(i, j)];
+        const double fo = FY(i, j), fyad = TPD_PF(fy3, u, a.fy.p[at(i, j)]);
         if (fo == 0. && fyad == 0.) continue;
+        if (FV3LM_TPD_EXP && (a.exp & 2)) continue;
         auto line = [&](int jj) -> Dual { return Dual(QG[qe(i, jj)], 0.); };
         const MetY da{c.m.dya, c, tile, i};
-        const Dual fl = ppm_flux<Dual>(iord, face, j, ny + 1, line, da, Dual(a.cry.t[at(i, j)], 1.));
+        Dual fl;
+        if (iord == 2) tpd_flux2<TPD_QW>(face, j, ny + 1, QG + qe(i, j), CT[cye(i, j)], da, fl.v, fl.d);
+        else fl = ppm_flux<Dual>(iord, face, j, ny + 1, line, da, Dual(CT[cye(i, j)], 1.));
         a.cry.p[at(i, j)] += fl.d * fo;
         a.my.p[at(i, j)] += 0.5 * fl.v * fyad;
       } }
-    auto cl = [](int m, int n1) { return m < 1 ? 1 : (m > n1 ? n1 : m); };
-    if (iord == 2) {                                // edge-value adjoints of the outer sweep, rows J0-4 .. J1+5
+    if (iord == 2 && !(FV3LM_TPD_EXP && (a.exp & 4))) {                                // edge-value adjoints of the outer sweep, rows J0-4 .. J1+5
       constexpr int n = TPD_QW * TPD_AH;
       TPD_LOOP(e, n) {
         const int i = I0 - 3 + e % TPD_QW, x = J0 - 6 + e / TPD_QW;
         double s = 0.;
-        if (x >= J0 - 4 && x <= J1 + 5 && i >= 1 && i <= nx && i <= I1 + 3) {
-          const double cm = a.cry.t[at(i, cl(x - 1, ny + 1))], c0 = a.cry.t[at(i, cl(x, ny + 1))], cp = a.cry.t[at(i, cl(x + 1, ny + 1))];
-          s = tps_al(FA[e - TPD_QW], FA[e], FA[e + TPD_QW], cm, c0, cp);
-        }
+        if (x >= J0 - 4 && x <= J1 + 5 && i >= 1 && i <= nx && i <= I1 + 3) s = tps_al(FA[e - TPD_QW], FA[e], FA[e + TPD_QW], CT[e - TPD_QW], CT[e], CT[e + TPD_QW]);
         AL[e] = s;
       } }
     TPF_SYNC();
+    double xf5[TPD_SLOTS(E_GB)], fx5[TPD_SLOTS(E_GB)], mm5[TPD_SLOTS(E_GB)];         // prefetch: fx2_ad
+    if constexpr (PRE) { constexpr int w = TPD_QW - 1, n = w * TPD_QH;
+      TPD_LOOPU(e, u, n, E_GB) { const int m = I0 - 2 + e % w, j = J0 - 3 + e / w;
+        const bool on = j >= GJ0 && j <= GJ1 && m >= 1 && m <= nx + 1 && m <= I1 + 3, in = on && j >= 1 && j <= ny;
+        xf5[u] = on ? a.xfx.t[at(m, j)] : 0.; fx5[u] = in ? a.fx.p[at(m, j)] : 0.; mm5[u] = in ? a.mx.t[at(m, j)] : 0.; } }
     { constexpr int n = TPD_NQ;                     // gj = q_j_ad / ra_x on the owned rows; own cells: ra_x_ad, the area term of q_ad
       TPD_LOOPU(e, u, n, EQ) {
         const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW;
         double s = 0., acc = 0.;
         if (j >= GJ0 && j <= GJ1 && i >= 1 && i <= nx && i <= I1 + 3) {
           const bool own = i >= I0 && i <= I1;
-          const double rx = a.rax.t[at(i, j)], ar = MET(area, i, j), rold = own ? a.rax.p[at(i, j)] : 0.;
+          const double rx = TPD_PF(rx4, u, a.rax.t[at(i, j)]), ar = TPD_PF(ar4, u, MET(area, i, j)), rold = TPD_PF(ro4, u, own ? a.rax.p[at(i, j)] : 0.);
           const MetY da{c.m.dya, c, tile, i};
           const int b0 = fae(i, j);
           if (iord == 333) {
             const double f[4] = {FA[b0 - TPD_QW], FA[b0], FA[b0 + TPD_QW], FA[b0 + 2 * TPD_QW]};
-            const double cc[4] = {a.cry.t[at(i, cl(j - 1, ny + 1))], a.cry.t[at(i, cl(j, ny + 1))], a.cry.t[at(i, cl(j + 1, ny + 1))], a.cry.t[at(i, cl(j + 2, ny + 1))]};
+            const double cc[4] = {CT[b0 - TPD_QW], CT[b0], CT[b0 + TPD_QW], CT[b0 + 2 * TPD_QW]};
             s = tps_q333(face, j, ny + 1, f, cc, da);
           } else {
-            const double c0 = a.cry.t[at(i, cl(j, ny + 1))], cp = a.cry.t[at(i, cl(j + 1, ny + 1))];
             const double al[4] = {AL[b0 - TPD_QW], AL[b0], AL[b0 + TPD_QW], AL[b0 + 2 * TPD_QW]};
-            s = tps_q(iord, face, j, ny + 1, FA[b0], FA[b0 + TPD_QW], c0, cp, al, da);
+            if (!(FV3LM_TPD_EXP && (a.exp & 8))) s = tps_q(iord, face, j, ny + 1, FA[b0], FA[b0 + TPD_QW], CT[b0], CT[b0 + TPD_QW], al, da);
           }
           s = s / rx;
           if (own) { a.rax.p[at(i, j)] = rold - QG[e] * s; acc = ar * s; }
@@ -342,13 +444,19 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
         QG[e] = s;
       } }
     TPF_SYNC();
+    double cxt[TPD_SLOTS(E_AQ)], qo7[TPD_SLOTS(E_Q)];                     // the Courant numbers of the inner sweep (crx) on their way into CT; prefetch: q_ad
+    if constexpr (PRE) {
+      { constexpr int n = TPD_AW * TPD_QH; TPD_LOOPU(e, u, n, E_AQ) cxt[u] = load_cx(e); }
+      { constexpr int n = TPD_NQ; TPD_LOOPU(e, u, n, E_Q) { const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW;
+          qo7[u] = (i < GI0 || i > GI1 || j < GJ0 || j > GJ1 || corner_cell(i, j) || i > I1 + 3 || j > J1 + 3) ? 0. : a.q.p[at(i, j)]; } }
+    }
     { constexpr int w = TPD_QW - 1, n = w * TPD_QH; // fx2_ad on columns I0-2 .. I1+3 of the owned rows, in place of the values; own x-faces: xfx_ad, mx_ad (inner part)
-      TPD_LOOP(e, n) {
+      TPD_LOOPU(e, u, n, E_GB) {
         const int m = I0 - 2 + e % w, j = J0 - 3 + e / w;
         double s = 0.;
         if (j >= GJ0 && j <= GJ1 && m >= 1 && m <= nx + 1 && m <= I1 + 3) {
           const bool in = j >= 1 && j <= ny, own = m >= I0 && (m <= I1 || (lastx && m == I1 + 1));
-          const double xf = a.xfx.t[at(m, j)], fxad = in ? a.fx.p[at(m, j)] : 0., mm = in ? a.mx.t[at(m, j)] : 0.;
+          const double xf = TPD_PF(xf5, u, a.xfx.t[at(m, j)]), fxad = TPD_PF(fx5, u, in ? a.fx.p[at(m, j)] : 0.), mm = TPD_PF(mm5, u, in ? a.mx.t[at(m, j)] : 0.);
           const double dg = (m <= nx ? QG[qe(m, j)] : 0.) - (m >= 2 ? QG[qe(m - 1, j)] : 0.);
           s = xf * dg + 0.5 * mm * fxad;
           if (own) {          // xfx and mx may be one array (the mass transport): two accumulates in program order
@@ -359,17 +467,16 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
         }
         F2[f2e(m, j)] = s;
       } }
+    { constexpr int n = TPD_AW * TPD_QH;            // CT <- crx (the outer sweep's cry was last read before the barrier above)
+      TPD_LOOPU(e, u, n, E_AQ) CT[e] = TPD_PF(cxt, u, load_cx(e)); }
     TPF_SYNC();
     auto FX2 = [&](int m, int j) { return (m >= I0 - 2 && m <= I1 + 3) ? F2[f2e(m, j)] : 0.; };
-    if (iord == 2) {                                // edge-value adjoints of the inner sweep, columns I0-4 .. I1+5 of the owned rows
+    if (iord == 2 && !(FV3LM_TPD_EXP && (a.exp & 4))) {                                // edge-value adjoints of the inner sweep, columns I0-4 .. I1+5 of the owned rows
       constexpr int n = TPD_AW * TPD_QH;
       TPD_LOOP(e, n) {
         const int x = I0 - 5 + e % TPD_AW, j = J0 - 3 + e / TPD_AW;
         double s = 0.;
-        if (j >= GJ0 && j <= GJ1 && x >= I0 - 4 && x <= I1 + 5) {
-          const double cm = a.crx.t[at(cl(x - 1, nx + 1), j)], c0 = a.crx.t[at(cl(x, nx + 1), j)], cp = a.crx.t[at(cl(x + 1, nx + 1), j)];
-          s = tps_al(FX2(x - 1, j), FX2(x, j), FX2(x + 1, j), cm, c0, cp);
-        }
+        if (j >= GJ0 && j <= GJ1 && x >= I0 - 4 && x <= I1 + 5) s = tps_al(FX2(x - 1, j), FX2(x, j), FX2(x + 1, j), CT[e], CT[e + 1], CT[e + 2]);
         AL[e] = s;
       } }
     TPF_SYNC();
@@ -378,18 +485,18 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
         const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW;
         const double acc = TPD_QACC_DIRECT ? 0. : qacc[u];
         if (i < GI0 || i > GI1 || j < GJ0 || j > GJ1 || corner_cell(i, j)) continue;
-        const double qold = a.q.p[at(i, j)];
+        const double qold = TPD_PF(qo7, u, a.q.p[at(i, j)]);
         const MetX da{c.m.dxa, c, tile, j};
+        const int cb = cxe(i, j);
         double s;
         if (iord == 333) {
           const double f[4] = {FX2(i - 1, j), FX2(i, j), FX2(i + 1, j), FX2(i + 2, j)};
-          const double cc[4] = {a.crx.t[at(cl(i - 1, nx + 1), j)], a.crx.t[at(cl(i, nx + 1), j)], a.crx.t[at(cl(i + 1, nx + 1), j)], a.crx.t[at(cl(i + 2, nx + 1), j)]};
+          const double cc[4] = {CT[cb - 1], CT[cb], CT[cb + 1], CT[cb + 2]};
           s = tps_q333(face, i, nx + 1, f, cc, da);
         } else {
-          const double c0 = a.crx.t[at(cl(i, nx + 1), j)], cp = a.crx.t[at(cl(i + 1, nx + 1), j)];
           const int b0 = ale(i, j);
           const double al[4] = {AL[b0 - 1], AL[b0], AL[b0 + 1], AL[b0 + 2]};
-          s = tps_q(iord, face, i, nx + 1, FX2(i, j), FX2(i + 1, j), c0, cp, al, da);
+          if (!(FV3LM_TPD_EXP && (a.exp & 8))) s = tps_q(iord, face, i, nx + 1, FX2(i, j), FX2(i + 1, j), CT[cb], CT[cb + 1], al, da);
         }
         a.q.p[at(i, j)] = qold + (acc + s);
       } }
@@ -399,11 +506,17 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
         if (j < GJ0 || j > GJ1 || j > J1 + 3 || !(m <= I1 || (lastx && m == I1 + 1))) continue;
         const double f = F2[f2e(m, j)];
         if (f == 0.) continue;
+        if (FV3LM_TPD_EXP && (a.exp & 2)) continue;
         auto line = [&](int ii) -> Dual { int i2 = ii, jj = j; if (face) corner_map(g, 1, i2, jj); return Dual(Q[qe(i2, jj)], 0.); };
         const MetX da{c.m.dxa, c, tile, j};
-        a.crx.p[at(m, j)] += ppm_flux<Dual>(iord, face, m, nx + 1, line, da, Dual(a.crx.t[at(m, j)], 1.)).d * f;
+        double v_, d_;
+        if (iord == 2 && !(face && (j < 1 || j > ny) && (m <= 3 || m >= nx - 1))) tpd_flux2<1>(face, m, nx + 1, Q + qe(m, j), CT[cxe(m, j)], da, v_, d_);
+        else d_ = ppm_flux<Dual>(iord, face, m, nx + 1, line, da, Dual(CT[cxe(m, j)], 1.)).d;
+        a.crx.p[at(m, j)] += d_ * f;
       } }
   }
+#undef TPD_PF
+#undef TPD_SLOTS
 }
 
 // The corner-alias contributions: source cell s next to a face corner is also read, by the inner sweep of direction dir, as the
@@ -488,6 +601,9 @@ FV3LM_LINK void run_tp_ad(Exec& ex, const TpFusedArgs& a0, const Ctx& c) {
   TpFusedArgs a = a0;
   for (Fld* f : {&a.q, &a.crx, &a.cry, &a.xfx, &a.yfx, &a.rax, &a.ray, &a.mx, &a.my, &a.fx, &a.fy}) *f = ex.sh(*f);
   const int nbx = (c.g.nx + TPD_W - 1) / TPD_W, nby = (c.g.ny + TPD_H - 1) / TPD_H;
+#if FV3LM_TPD_EXP
+  if (const char* e = std::getenv("FV3LM_TP2_EXPERIMENT")) a.exp = std::atoi(e);
+#endif
   // algorithmic bytes: trajectory q, crx, cry, xfx, yfx, ra_x, ra_y, mx, my and the adjoints fx, fy read; the nine input adjoints read-modify-written
   const double cells = double(c.g.nx) * c.g.ny * c.g.ntile * a.nk;
   ex.mark_begin("TpAd", ".ad", 8. * cells * (9. + 2. + 18.));

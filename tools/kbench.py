@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--top", type=int, default=25)
     ap.add_argument("--nh", action="store_true")
     ap.add_argument("--group", default="", help="after one ordinary step: time this kernel group alone (TL and NL), e.g. d_sw")
+    ap.add_argument("--ad", action="store_true", help="group mode: time the adjoint of the group instead of TL + NL")
     ap.add_argument("--experiment", default="", help="comma list of FV3LM_TP2_EXPERIMENT values to time the group with (experiment builds only)")
     args = ap.parse_args()
     if args.lib:
@@ -42,10 +43,14 @@ def main():
     if args.group:
         for ex_ in [e for e in (args.experiment.split(",") if args.experiment else ["0"])]:
             os.environ["FV3LM_TP2_EXPERIMENT"] = ex_
-            c.dy.run_group(args.group, 1); c.dy.run_group(args.group, 0); c.dy.sync()
+            modes = (2,) if args.ad else (1, 0)
+            for m_ in modes:
+                c.dy.run_group(args.group, m_)
+            c.dy.sync()
             c.dy.profile_begin()
             for _ in range(3):
-                c.dy.run_group(args.group, 1); c.dy.run_group(args.group, 0)
+                for m_ in modes:
+                    c.dy.run_group(args.group, m_)
             prof = c.dy.profile_end()
             print("group %s, experiment %s:" % (args.group, ex_))
             for k, (n_, m_, b_) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
