@@ -53,8 +53,12 @@ class Fv3LmLibrary:
 
 
 def load_hip_library():
-    # FV3LM_LIB: another build of the same HIP sources (kernel-tuning variants); never a CPU library -- create() needs a HIP device
-    return Fv3LmLibrary(os.environ.get("FV3LM_LIB", LIB_PATH))
+    """The product library.  FV3LM_LIB names another build of the same HIP sources (kernel-tuning variants, tools/mkvariant.sh); a
+    host-emulation build (tests/_emul, it exports fv3lm_emul_check_boxes) is refused: the package has no CPU path."""
+    lib = Fv3LmLibrary(os.environ.get("FV3LM_LIB", LIB_PATH))
+    if hasattr(lib.L, "fv3lm_emul_check_boxes"):
+        raise Fv3LmError("%s is a host-emulation build (tests only); the package runs the HIP library alone" % lib.path)
+    return lib
 
 
 TRANSPORT_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_dp), C.POINTER(C.c_long), C.POINTER(_dp), C.POINTER(C.c_long))

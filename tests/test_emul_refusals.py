@@ -33,3 +33,12 @@ def test_split_hord_needs_the_fused_transport(monkeypatch):
     with pytest.raises(Exception) as e:
         Case(nx=10, ny=8, npz=12, backend="emul", oracle=False, hord_dp=10)
     assert "split_hord" in str(e.value), str(e.value)
+
+
+def test_package_refuses_a_host_emulation_library(monkeypatch):
+    """FV3LM_LIB may name another HIP build of the sources, never the tests' g++ build: the package has no CPU path"""
+    from common import build_emul
+    from fv3_jedi_linearmodel_amd._lib import load_hip_library, Fv3LmError
+    monkeypatch.setenv("FV3LM_LIB", build_emul())
+    with pytest.raises(Fv3LmError, match="host-emulation"):
+        load_hip_library()

@@ -30,6 +30,11 @@ def short(name):
     m = re.search(r"k_tp_(fused|march)<(fv3::Dual|double)", name)
     if m:       # fv_tp_2d as one launch (tpfused.h): tiled or marching form; Dual = tangent, double = nonlinear (stores the intermediates)
         return "%s.%s" % ("TpFused" if m.group(1) == "fused" else "TpMarch", "tl" if "Dual" in m.group(2) else "nl")
+    m = re.search(r"k_tp2<(fv3::Dual|double)", name)
+    if m:       # fv_tp_2d as one launch, wavefront layout (tp2.h): the same profile name as the first form
+        return "TpFused.%s" % ("tl" if "Dual" in m.group(1) else "nl")
+    if "k_zero16" in name:         # field-sized clears (dycore.h dev_zero)
+        return "clear"
     if "k_tp_ad_corner" in name:   # corner-alias contributions of the fused adjoint (tpad.h)
         return "TpAd.ad_corner"
     if "k_tp_ad" in name:          # the whole adjoint of fv_tp_2d as one launch (tpad.h)
