@@ -380,7 +380,13 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "launches_per_step": cnt, "avg_launch_ms": ms / cnt, "algorithmic_bytes_per_launch": by / cnt,
-                         "share_of_step_time": ms / sum(v[1] for v in prof.values())},
+                         "share_of_step_time": ms / sum(v[1] for v in prof.values()),
+                         # the next kernels by summed time, same accounting (the dominant kernel changed from the tangent to the adjoint
+                         # form of fv_tp_2d when the adjoint became one launch: its fraction is not comparable with earlier rounds' line)
+                         "next": [{"kernel": k, "launches_per_step": v[0], "avg_launch_ms": v[1] / v[0],
+                                   "achieved": (v[2] / 1e9) / (v[1] * 1e-3) if v[1] > 0 else 0.0,
+                                   "frac": ((v[2] / 1e9) / (v[1] * 1e-3) / HBM_PEAK_GBPS) if v[1] > 0 else 0.0}
+                                  for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[1:4]]},
             "contract": {"algorithmic_bytes_per_step": b_step, "achieved_GBps": contract_gbps, "frac": contract_gbps / HBM_PEAK_GBPS,
                          "note": "whole TL+AD step against BASELINE.md §3 (2.75 x B_TL, %d B per cell and acoustic step); state resident in HBM: the host<->device "
                                  "copies of a drop-in step_tl/step_ad (DESIGN.md §6) are outside the timed region" % (1280 if args.nonhydrostatic else 880)},

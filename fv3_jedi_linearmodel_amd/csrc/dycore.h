@@ -54,9 +54,12 @@ __global__ void __launch_bounds__(256) k_zero16(double2* p, size_t n2) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride) p[i] = make_double2(0., 0.);
 }
 inline void dev_zero(Exec& ex, void* p, size_t n) {
-  if (n >= ((size_t)1 << 20) && ((uintptr_t)p & 15) == 0 && (n & 15) == 0) {
+  if (n >= ((size_t)1 << 20) && ((uintptr_t)p & 7) == 0) {
+    char* q = (char*)p;
+    if ((uintptr_t)q & 15) { HIPCHK(hipMemsetAsync(q, 0, 8, ex.stream)); q += 8; n -= 8; }      // fields are 8-byte aligned; the kernel wants 16
     const size_t n2 = n / 16, want = (n2 + 255) / 256;
-    hipLaunchKernelGGL(k_zero16, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, ex.stream, (double2*)p, n2);
+    hipLaunchKernelGGL(k_zero16, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, ex.stream, (double2*)q, n2);
+    if (n & 15) HIPCHK(hipMemsetAsync(q + n2 * 16, 0, n & 15, ex.stream));
     return;
   }
   HIPCHK(hipMemsetAsync(p, 0, n, ex.stream));

@@ -366,7 +366,10 @@ inline double stage_bytes(const S& s, const Ctx& c, const Rect& R, int mode) {
 
 #ifndef FV3LM_HOST_EMUL
 // ---- HIP kernels ---------------------------------------------------------------------------
-constexpr int BX = 64, BY = 4;
+#ifndef FV3LM_BY
+#define FV3LM_BY 4
+#endif
+constexpr int BX = 64, BY = FV3LM_BY;
 // tr: narrow column strips (face-edge stages) run with the 64 lanes of a wave along j instead of i
 // XCD-aware block order.  Workgroups go to the 8 XCDs round-robin by linear id, so with the plain (x, y) order the
 // blocks above and below a block — which re-read 2/3 of its stencil rows — sit on other XCDs and their private L2s
