@@ -262,8 +262,31 @@ struct Dycore {
         bulk = Edged<D, false>(t); have_bulk = true;
       } else strips.push_back(Edged<D, true>(t));
     }
+    const size_t n0 = P.size();
     add_multi(P, grp, strips);
+    const size_t n1 = P.size();
     if (have_bulk) add(P, grp, bulk);
+#ifndef FV3LM_HOST_EMUL
+    // Forward modes: the strips go to the strip stream and run beside the bulk launch (they read the same inputs and write disjoint
+    // regions of the outputs); the main stream waits for them after the bulk launch.  A strip launch is 2 % of the points but
+    // latency-bound (40-140 us): in line it cost 45 ms per step.  The adjoint keeps the order bulk, then strips (the strips accumulate
+    // into what the bulk launch stores).
+    if (have_bulk && n1 == n0 + 1 && P.size() == n1 + 1) {
+      auto fs = P[n0].fn; auto fb = P[n1].fn;
+      P[n0].fn = [fs](Exec& e, int mode) {
+        if (mode == MODE_AD || !e.sstream) { fs(e, mode); return; }
+        HIPCHK(hipEventRecord(e.ev_s0, e.stream)); HIPCHK(hipStreamWaitEvent(e.sstream, e.ev_s0, 0));
+        hipStream_t main = e.stream; e.stream = e.sstream;
+        fs(e, mode);
+        e.stream = main;
+        HIPCHK(hipEventRecord(e.ev_s1, e.sstream)); e.side_pending = true;
+      };
+      P[n1].fn = [fb](Exec& e, int mode) {
+        fb(e, mode);
+        if (e.side_pending) { HIPCHK(hipStreamWaitEvent(e.stream, e.ev_s1, 0)); e.side_pending = false; }
+      };
+    }
+#endif
   }
 
   template <class St>
@@ -753,6 +776,11 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
     if (face && !(env && env[0] == '1')) {
       HIPCHK(hipStreamCreate(&ex.xstream));
       for (int w = 0; w < Exec::NWIN; ++w) { HIPCHK(hipEventCreateWithFlags(&ex.ev_a[w], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ex.ev_b[w], hipEventDisableTiming)); }
+    }
+    const char* es = std::getenv("FV3LM_NO_SIDE_STRIPS");
+    if (face && !(es && es[0] == '1')) {
+      HIPCHK(hipStreamCreate(&ex.sstream));
+      HIPCHK(hipEventCreateWithFlags(&ex.ev_s0, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ex.ev_s1, hipEventDisableTiming));
     } }
 #endif
   lev_host[npz] = lev_host[npz - 1];          // interface npz+1 of the height transport uses the last layer's schemes
@@ -909,6 +937,7 @@ inline void Dycore::destroy() {
   for (double* q_ : traj_slot_p) dev_free(q_);
 #ifndef FV3LM_HOST_EMUL
   if (ex.stream) (void)hipStreamDestroy(ex.stream);
+  if (ex.sstream) { (void)hipStreamDestroy(ex.sstream); if (ex.ev_s0) (void)hipEventDestroy(ex.ev_s0); if (ex.ev_s1) (void)hipEventDestroy(ex.ev_s1); }
   if (ex.xstream) { (void)hipStreamDestroy(ex.xstream); for (int w = 0; w < Exec::NWIN; ++w) { if (ex.ev_a[w]) (void)hipEventDestroy(ex.ev_a[w]); if (ex.ev_b[w]) (void)hipEventDestroy(ex.ev_b[w]); } }
 #endif
 }

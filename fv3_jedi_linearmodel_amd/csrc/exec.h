@@ -35,6 +35,9 @@ struct Exec {
   // exchange stream: a halo exchange whose field nobody touches for a while runs here beside the launches of the main
   // stream (dycore.h add_halo_async); ev_a / ev_b: "main reached the start" / "exchange done", one pair per window
   hipStream_t xstream = nullptr;
+  // strip stream (dycore.h add_face): in the forward modes the edge strips of a stage run beside its bulk launch (disjoint outputs);
+  // ev_s0 = "main reached the strips", ev_s1 = "strips done"
+  hipStream_t sstream = nullptr; hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr; bool side_pending = false;
   static constexpr int NWIN = 4;
   hipEvent_t ev_a[NWIN] = {}, ev_b[NWIN] = {};
 #endif
