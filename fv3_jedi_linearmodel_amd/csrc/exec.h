@@ -698,12 +698,70 @@ __global__ void __launch_bounds__(BX* BY) k_stage_multi_ad(Multi<S> m, Rect Q0, 
   if (2 >= r && 2 < m.n && Q2.has(i, j)) ad_point(m.s[2], c, m.R[2], i, j, blockIdx.z, nkmax);
   if (3 >= r && 3 < m.n && Q3.has(i, j)) ad_point(m.s[3], c, m.R[3], i, j, blockIdx.z, nkmax);
 }
+// Two strips whose input regions are disjoint (south + north, west + east of a face wider than twice the stencil reach) share one adjoint
+// launch: one gather per thread, as in the single-strip launch -- none of the register cost of the four-strip merge below.
+template <class S>
+struct Pair { S s[2]; Rect R[2], Q[2]; int boff[3], gx[2], tr[2]; };
+template <class S>
+__global__ void __launch_bounds__(BX* BY) k_stage_pair_ad(Pair<S> m, Ctx c, int nkmax) {
+  int b = blockIdx.x;
+  if (b < m.boff[1]) {
+    int i, j; thread_point(m.Q[0], m.tr[0], b % m.gx[0], b / m.gx[0], threadIdx.x, threadIdx.y, i, j);
+    if (i <= m.Q[0].i1 && j <= m.Q[0].j1) ad_point(m.s[0], c, m.R[0], i, j, blockIdx.z, nkmax);
+  } else {
+    b -= m.boff[1];
+    int i, j; thread_point(m.Q[1], m.tr[1], b % m.gx[1], b / m.gx[1], threadIdx.x, threadIdx.y, i, j);
+    if (i <= m.Q[1].i1 && j <= m.Q[1].j1) ad_point(m.s[1], c, m.R[1], i, j, blockIdx.z, nkmax);
+  }
+}
+inline bool rects_disjoint(const Rect& a, const Rect& b) { return a.i1 < b.i0 || b.i1 < a.i0 || a.j1 < b.j0 || b.j1 < a.j0; }
 // The merged adjoint (four inlined gathers) measured faster for some stages and much slower for others (register
 // pressure): opt-in per stage with `static constexpr bool MERGE_AD_STRIPS = true`; the forward modes always merge.
 template <class S, class = void> struct merge_ad_strips { static constexpr bool value = false; };
 template <class S> struct merge_ad_strips<S, typename std::enable_if<S::MERGE_AD_STRIPS>::type> { static constexpr bool value = true; };
 template <class S>
 void run_multi(Exec& ex, int mode, const S* s0, int n, const Ctx& c) {
+  if (mode == MODE_AD && !merge_ad_strips<S>::value && n <= MAXSTRIP && !std::getenv("FV3LM_NO_PAIR_STRIPS")) {
+    // strips in pairs with disjoint input regions (add_face hands them over as south, north, west, east); a strip without a partner alone
+    bool done[MAXSTRIP] = {false, false, false, false};
+    for (int r = 0; r < n; ++r) {
+      if (done[r]) continue;
+      S a = s0[r];
+      if (ex.no_wmask) a.wmask = 0;
+      for (int k = 0; k < S::NIN; ++k) a.in[k] = ex.sh(a.in[k]);
+      for (int k = 0; k < S::NOUT; ++k) a.out[k] = ex.sh(a.out[k]);
+      const Rect Ra = rect_union(a.orect, S::NOUT), Qa = ad_input_rect(a, c, Ra);
+      int partner = -1; S b = a; Rect Rb = Ra, Qb = Qa;
+      for (int q = r + 1; q < n && partner < 0; ++q) {
+        if (done[q]) continue;
+        S t = s0[q];
+        if (ex.no_wmask) t.wmask = 0;
+        for (int k = 0; k < S::NIN; ++k) t.in[k] = ex.sh(t.in[k]);
+        for (int k = 0; k < S::NOUT; ++k) t.out[k] = ex.sh(t.out[k]);
+        const Rect Rt = rect_union(t.orect, S::NOUT), Qt = ad_input_rect(t, c, Rt);
+        if (rects_disjoint(Qa, Qt) && a.wmask == 0 && t.wmask == 0) { partner = q; b = t; Rb = Rt; Qb = Qt; }
+      }
+      if (partner < 0) { run(ex, mode, s0[r], c); done[r] = true; continue; }
+      done[r] = done[partner] = true;
+      Pair<S> m; m.s[0] = a; m.s[1] = b; m.R[0] = Ra; m.R[1] = Rb; m.Q[0] = Qa; m.Q[1] = Qb;
+      int nkmax = 0;
+      for (int k = 0; k < S::NIN; ++k) if (a.in[k].nk > nkmax) nkmax = a.in[k].nk;
+      m.boff[0] = 0;
+      for (int q = 0; q < 2; ++q) { m.tr[q] = strip_tr(m.Q[q]); const dim3 gd = grid_for(m.Q[q], 1, m.tr[q]); m.gx[q] = gd.x; m.boff[q + 1] = m.boff[q] + gd.x * gd.y; }
+      ex.mark_begin(S::name(), ".ad", stage_bytes(a, c, Ra, MODE_AD) + stage_bytes(b, c, Rb, MODE_AD));
+      hipLaunchKernelGGL(k_stage_pair_ad<S>, dim3(m.boff[2], 1, c.g.ntile * nkmax), dim3(BX, BY), 0, ex.stream, m, c, nkmax);
+      ex.mark_end();
+      ex.launches++;
+      if constexpr (S::NALIAS > 0) if (c.g.face)
+        for (int q = 0; q < 2; ++q) {
+          ex.mark_begin(S::name(), ".ad_corner", 0.);
+          hipLaunchKernelGGL(k_stage_ad_alias<S>, dim3(4, c.g.ntile * nkmax), dim3(64), 0, ex.stream, m.s[q], c, m.R[q]);
+          ex.mark_end();
+          ex.launches++;
+        }
+    }
+    return;
+  }
   if (n > MAXSTRIP || (mode == MODE_AD && !merge_ad_strips<S>::value)) { for (int r = 0; r < n; ++r) run(ex, mode, s0[r], c); return; }
   Multi<S> m; m.n = n;
   Rect Q[MAXSTRIP]; int nkmax = 0; double bytes = 0.;
