@@ -327,9 +327,14 @@ template <class S, int M>
 struct AdLoop<S, M, true> {
   HD static void run(const S&, const Ctx&, const Rect&, int, int, int, int) {}
 };
+// A stage may bring its own gather adjoint (static constexpr bool HAND_AD; hand_ad(c, R, i, j, z) with the store rules of body_ad_joint):
+// worth it where the stage is linear with constant weights and the seeded re-evaluation per offset costs several times the arithmetic.
+template <class S, class = void> struct hand_ad_of { static constexpr bool value = false; };
+template <class S> struct hand_ad_of<S, typename std::enable_if<S::HAND_AD>::type> { static constexpr bool value = true; };
 template <class S>
 HD void ad_point(const S& s, const Ctx& c, const Rect& R, int i, int j, int z, int nkmax) {
-  if constexpr (joint_ad((const S*)nullptr)) { body_ad_joint<S, 0>(s, c, R, i, j, z); body_ad_joint<S, 1>(s, c, R, i, j, z); }
+  if constexpr (hand_ad_of<S>::value) { (void)nkmax; s.hand_ad(c, R, i, j, z); }
+  else if constexpr (joint_ad((const S*)nullptr)) { body_ad_joint<S, 0>(s, c, R, i, j, z); body_ad_joint<S, 1>(s, c, R, i, j, z); }
   else AdLoop<S, 0>::run(s, c, R, i, j, z, nkmax);
 }
 
