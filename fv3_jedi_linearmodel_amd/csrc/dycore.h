@@ -463,8 +463,8 @@ struct Dycore {
     // hand-written outer adjoint (which re-evaluates them from q_i, q_j in passing) they are neither stored by the nonlinear launch nor
     // part of a trajectory slot; the names then alias fx2 / fy2 for the staged ops that never run.
     const char* aenv = std::getenv("FV3LM_TP_AD_FUSED");
-    // 2: the whole adjoint as one launch (tpad.h; whole faces and the periodic tile); 1: outer half fused, inner half staged (sub-face tiles); 0: staged
-    const int adf = !fused ? 0 : aenv ? (aenv[0] == '0' ? 0 : aenv[0] == '1' ? 1 : (subtile ? 1 : 2)) : (subtile ? 1 : 2);
+    // 2: the whole adjoint as one launch (tpad.h; faces, sub-face tiles and the periodic tile); 1: outer half fused, inner half staged; 0: staged
+    const int adf = !fused ? 0 : aenv ? (aenv[0] == '0' ? 0 : aenv[0] == '1' ? 1 : 2) : 2;
     const bool own_fo = adf == 0, own_mid = adf < 2;
     // the inner fluxes and the intermediate fields are trajectory arrays of their own only while a staged adjoint launch reads them; the
     // fused adjoint recomputes them in LDS, so neither the nonlinear launch stores them nor a trajectory slot holds them -- the names then

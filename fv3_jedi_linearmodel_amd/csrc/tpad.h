@@ -128,11 +128,12 @@ template <int NTH>
 DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx, int by, double* lds, int tid, int nth) {
   (void)nth;
   const Geom& g = c.g;
-  const int nx = g.nx, ny = g.ny;
+  const int nx = g.nx, ny = g.ny;                                     // the FACE: cube-edge weights and corner views test global indices against these
+  const int is = g.is(), ie = g.ie(), js = g.js(), je = g.je();       // the tile's window of the face: ranges of cells and fluxes
   const bool face = g.face != 0;
-  const int I0 = 1 + bx * TPD_W, I1 = (I0 + TPD_W - 1 < nx) ? I0 + TPD_W - 1 : nx;
-  const int J0 = 1 + by * TPD_H, J1 = (J0 + TPD_H - 1 < ny) ? J0 + TPD_H - 1 : ny;
-  const bool firstx = bx == 0, lastx = I1 == nx, firsty = by == 0, lasty = J1 == ny;
+  const int I0 = is + bx * TPD_W, I1 = (I0 + TPD_W - 1 < ie) ? I0 + TPD_W - 1 : ie;
+  const int J0 = js + by * TPD_H, J1 = (J0 + TPD_H - 1 < je) ? J0 + TPD_H - 1 : je;
+  const bool firstx = bx == 0, lastx = I1 == ie, firsty = by == 0, lasty = J1 == je;
   const int GI0 = firstx ? I0 - 3 : I0, GI1 = lastx ? I1 + 3 : I1, GJ0 = firsty ? J0 - 3 : J0, GJ1 = lasty ? J1 + 3 : J1;     // owned cells incl. the halo
   const size_t base = (size_t)(tile * a.nk + k - 1) * g.plane;
   auto at = [&](int i, int j) -> size_t { return base + g.idx(i, j); };
@@ -149,8 +150,8 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
   double* CT = AL + TPD_NFA;
   auto cxe = [&](int i, int j) { return (j - (J0 - 3)) * TPD_AW + (i - (I0 - 6)); };
   auto cye = [&](int i, int j) { return (j - (J0 - 6)) * TPD_QW + (i - (I0 - 3)); };
-  auto load_cx = [&](int e) -> double { const int i = I0 - 6 + e % TPD_AW, j = J0 - 3 + e / TPD_AW; return (i >= 1 && i <= nx + 1 && i <= I1 + 6 && j <= J1 + 3) ? a.crx.t[at(i, j)] : 0.; };
-  auto load_cy = [&](int e) -> double { const int i = I0 - 3 + e % TPD_QW, j = J0 - 6 + e / TPD_QW; return (j >= 1 && j <= ny + 1 && j <= J1 + 6 && i <= I1 + 3) ? a.cry.t[at(i, j)] : 0.; };
+  auto load_cx = [&](int e) -> double { const int i = I0 - 6 + e % TPD_AW, j = J0 - 3 + e / TPD_AW; return (i >= is && i <= ie + 1 && i <= I1 + 6 && j <= J1 + 3) ? a.crx.t[at(i, j)] : 0.; };
+  auto load_cy = [&](int e) -> double { const int i = I0 - 3 + e % TPD_QW, j = J0 - 6 + e / TPD_QW; return (j >= js && j <= je + 1 && j <= J1 + 6 && i <= I1 + 3) ? a.cry.t[at(i, j)] : 0.; };
   // Prefetch: the global operands of a phase are loaded into registers during the phase before it, ahead of the barrier between them.
 #if defined(FV3LM_HOST_EMUL) || defined(FV3LM_TPD_NOUNROLL)
   constexpr bool PRE = false;
@@ -183,7 +184,7 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
     { constexpr int n = TPD_AW * TPD_QH;            // outer-flux adjoints and the Courant numbers of the outer sweep
       TPD_LOOP(e, n) {
         const int i = I0 - 6 + e % TPD_AW, j = J0 - 3 + e / TPD_AW;
-        FA[e] = (i >= 1 && i <= nx + 1 && j >= 1 && j <= ny && i <= I1 + 6 && j <= J1 + 3) ? 0.5 * a.mx.t[at(i, j)] * a.fx.p[at(i, j)] : 0.;
+        FA[e] = (i >= is && i <= ie + 1 && j >= js && j <= je && i <= I1 + 6 && j <= J1 + 3) ? 0.5 * a.mx.t[at(i, j)] * a.fx.p[at(i, j)] : 0.;
         CT[e] = load_cx(e);
       } }
     double cv[TPD_SLOTS(E_V)];                                 // prefetch: Courant numbers of the inner flux values
@@ -219,7 +220,7 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
     double ry4[TPD_SLOTS(E_Q)], ar4[TPD_SLOTS(E_Q)], ro4[TPD_SLOTS(E_Q)];            // prefetch: gi
     if constexpr (PRE) { constexpr int n = TPD_NQ;
       TPD_LOOPU(e, u, n, E_Q) { const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW;
-        const bool in = i >= GI0 && i <= GI1 && j >= 1 && j <= ny && j <= J1 + 3, own = in && j >= J0 && j <= J1;
+        const bool in = i >= GI0 && i <= GI1 && j >= js && j <= je && j <= J1 + 3, own = in && j >= J0 && j <= J1;
         ry4[u] = in ? a.ray.t[at(i, j)] : 1.; ar4[u] = in ? MET(area, i, j) : 0.; ro4[u] = own ? a.ray.p[at(i, j)] : 0.; } }
     auto FX = [&](int m, int j) { return FA[fae(m, j)]; };
     { constexpr int w = TPD_W + 1, n = w * TPD_H;   // own x-faces: Courant-number and mass-flux adjoints of the outer sweep
@@ -242,20 +243,20 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
       TPD_LOOP(e, n) {
         const int x = I0 - 6 + e % TPD_AW, j = J0 - 3 + e / TPD_AW;
         double s = 0.;
-        if (x >= I0 - 4 && x <= I1 + 5 && j >= 1 && j <= ny && j <= J1 + 3) s = tps_al(FA[e - 1], FA[e], FA[e + 1], CT[e - 1], CT[e], CT[e + 1]);
+        if (x >= I0 - 4 && x <= I1 + 5 && j >= js && j <= je && j <= J1 + 3) s = tps_al(FA[e - 1], FA[e], FA[e + 1], CT[e - 1], CT[e], CT[e + 1]);
         AL[e] = s;
       } }
     TPF_SYNC();
     double yf5[TPD_SLOTS(E_G)], fy5[TPD_SLOTS(E_G)], mm5[TPD_SLOTS(E_G)];            // prefetch: fy2_ad
     if constexpr (PRE) { constexpr int n = TPD_QW * (TPD_QH - 1);
       TPD_LOOPU(e, u, n, E_G) { const int i = I0 - 3 + e % TPD_QW, m = J0 - 2 + e / TPD_QW;
-        const bool on = i >= GI0 && i <= GI1 && m >= 1 && m <= ny + 1 && m <= J1 + 3, in = on && i >= 1 && i <= nx;
+        const bool on = i >= GI0 && i <= GI1 && m >= js && m <= je + 1 && m <= J1 + 3, in = on && i >= is && i <= ie;
         yf5[u] = on ? a.yfx.t[at(i, m)] : 0.; fy5[u] = in ? a.fy.p[at(i, m)] : 0.; mm5[u] = in ? a.my.t[at(i, m)] : 0.; } }
     { constexpr int n = TPD_NQ;                     // gi = q_i_ad / ra_y on the owned columns; own cells: ra_y_ad, the area term of q_ad
       TPD_LOOPU(e, u, n, EQ) {
         const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW;
         double s = 0., acc = 0.;
-        if (i >= GI0 && i <= GI1 && j >= 1 && j <= ny && j <= J1 + 3) {
+        if (i >= GI0 && i <= GI1 && j >= js && j <= je && j <= J1 + 3) {
           const bool own = j >= J0 && j <= J1;
           const double ry = TPD_PF(ry4, u, a.ray.t[at(i, j)]), ar = TPD_PF(ar4, u, MET(area, i, j)), rold = TPD_PF(ro4, u, own ? a.ray.p[at(i, j)] : 0.);
           const MetX da{c.m.dxa, c, tile, j};
@@ -285,10 +286,10 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
       TPD_LOOPU(e, u, n, E_G) {
         const int i = I0 - 3 + e % TPD_QW, m = J0 - 2 + e / TPD_QW;
         double s = 0.;
-        if (i >= GI0 && i <= GI1 && m >= 1 && m <= ny + 1 && m <= J1 + 3) {
-          const bool in = i >= 1 && i <= nx, own = m >= J0 && (m <= J1 || (lasty && m == J1 + 1));
+        if (i >= GI0 && i <= GI1 && m >= js && m <= je + 1 && m <= J1 + 3) {
+          const bool in = i >= is && i <= ie, own = m >= J0 && (m <= J1 || (lasty && m == J1 + 1));
           const double yf = TPD_PF(yf5, u, a.yfx.t[at(i, m)]), fyad = TPD_PF(fy5, u, in ? a.fy.p[at(i, m)] : 0.), mm = TPD_PF(mm5, u, in ? a.my.t[at(i, m)] : 0.);
-          const double dg = (m <= ny ? QG[qe(i, m)] : 0.) - (m >= 2 ? QG[qe(i, m - 1)] : 0.);
+          const double dg = (m <= je ? QG[qe(i, m)] : 0.) - (m >= js + 1 ? QG[qe(i, m - 1)] : 0.);
           s = yf * dg + 0.5 * mm * fyad;
           if (own) {          // yfx and my may be one array (the mass transport): two accumulates in program order
             const double f2v = F2[e];
@@ -357,7 +358,7 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
     { constexpr int n = TPD_QW * TPD_AH;
       TPD_LOOP(e, n) {
         const int i = I0 - 3 + e % TPD_QW, j = J0 - 6 + e / TPD_QW;
-        FA[e] = (j >= 1 && j <= ny + 1 && i >= 1 && i <= nx && j <= J1 + 6 && i <= I1 + 3) ? 0.5 * a.my.t[at(i, j)] * a.fy.p[at(i, j)] : 0.;
+        FA[e] = (j >= js && j <= je + 1 && i >= is && i <= ie && j <= J1 + 6 && i <= I1 + 3) ? 0.5 * a.my.t[at(i, j)] * a.fy.p[at(i, j)] : 0.;
       } }
     double ar2[TPD_SLOTS(E_J)], x02[TPD_SLOTS(E_J)], x12[TPD_SLOTS(E_J)], rx2[TPD_SLOTS(E_J)];  // prefetch: q_j values
     if constexpr (PRE) { constexpr int n = TPD_W * TPD_QH;
@@ -388,7 +389,7 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
     double rx4[TPD_SLOTS(E_Q)], ar4[TPD_SLOTS(E_Q)], ro4[TPD_SLOTS(E_Q)];            // prefetch: gj
     if constexpr (PRE) { constexpr int n = TPD_NQ;
       TPD_LOOPU(e, u, n, E_Q) { const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW;
-        const bool in = j >= GJ0 && j <= GJ1 && i >= 1 && i <= nx && i <= I1 + 3, own = in && i >= I0 && i <= I1;
+        const bool in = j >= GJ0 && j <= GJ1 && i >= is && i <= ie && i <= I1 + 3, own = in && i >= I0 && i <= I1;
         rx4[u] = in ? a.rax.t[at(i, j)] : 1.; ar4[u] = in ? MET(area, i, j) : 0.; ro4[u] = own ? a.rax.p[at(i, j)] : 0.; } }
     auto FY = [&](int i, int m) { return FA[fae(i, m)]; };
     { constexpr int n = TPD_W * (TPD_H + 1);        // own y-faces: Courant-number and mass-flux adjoints of the outer sweep
@@ -411,20 +412,20 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
       TPD_LOOP(e, n) {
         const int i = I0 - 3 + e % TPD_QW, x = J0 - 6 + e / TPD_QW;
         double s = 0.;
-        if (x >= J0 - 4 && x <= J1 + 5 && i >= 1 && i <= nx && i <= I1 + 3) s = tps_al(FA[e - TPD_QW], FA[e], FA[e + TPD_QW], CT[e - TPD_QW], CT[e], CT[e + TPD_QW]);
+        if (x >= J0 - 4 && x <= J1 + 5 && i >= is && i <= ie && i <= I1 + 3) s = tps_al(FA[e - TPD_QW], FA[e], FA[e + TPD_QW], CT[e - TPD_QW], CT[e], CT[e + TPD_QW]);
         AL[e] = s;
       } }
     TPF_SYNC();
     double xf5[TPD_SLOTS(E_GB)], fx5[TPD_SLOTS(E_GB)], mm5[TPD_SLOTS(E_GB)];         // prefetch: fx2_ad
     if constexpr (PRE) { constexpr int w = TPD_QW - 1, n = w * TPD_QH;
       TPD_LOOPU(e, u, n, E_GB) { const int m = I0 - 2 + e % w, j = J0 - 3 + e / w;
-        const bool on = j >= GJ0 && j <= GJ1 && m >= 1 && m <= nx + 1 && m <= I1 + 3, in = on && j >= 1 && j <= ny;
+        const bool on = j >= GJ0 && j <= GJ1 && m >= is && m <= ie + 1 && m <= I1 + 3, in = on && j >= js && j <= je;
         xf5[u] = on ? a.xfx.t[at(m, j)] : 0.; fx5[u] = in ? a.fx.p[at(m, j)] : 0.; mm5[u] = in ? a.mx.t[at(m, j)] : 0.; } }
     { constexpr int n = TPD_NQ;                     // gj = q_j_ad / ra_x on the owned rows; own cells: ra_x_ad, the area term of q_ad
       TPD_LOOPU(e, u, n, EQ) {
         const int i = I0 - 3 + e % TPD_QW, j = J0 - 3 + e / TPD_QW;
         double s = 0., acc = 0.;
-        if (j >= GJ0 && j <= GJ1 && i >= 1 && i <= nx && i <= I1 + 3) {
+        if (j >= GJ0 && j <= GJ1 && i >= is && i <= ie && i <= I1 + 3) {
           const bool own = i >= I0 && i <= I1;
           const double rx = TPD_PF(rx4, u, a.rax.t[at(i, j)]), ar = TPD_PF(ar4, u, MET(area, i, j)), rold = TPD_PF(ro4, u, own ? a.rax.p[at(i, j)] : 0.);
           const MetY da{c.m.dya, c, tile, i};
@@ -454,10 +455,10 @@ DEV void tp_ad_block(const TpFusedArgs& a, const Ctx& c, int tile, int k, int bx
       TPD_LOOPU(e, u, n, E_GB) {
         const int m = I0 - 2 + e % w, j = J0 - 3 + e / w;
         double s = 0.;
-        if (j >= GJ0 && j <= GJ1 && m >= 1 && m <= nx + 1 && m <= I1 + 3) {
-          const bool in = j >= 1 && j <= ny, own = m >= I0 && (m <= I1 || (lastx && m == I1 + 1));
+        if (j >= GJ0 && j <= GJ1 && m >= is && m <= ie + 1 && m <= I1 + 3) {
+          const bool in = j >= js && j <= je, own = m >= I0 && (m <= I1 || (lastx && m == I1 + 1));
           const double xf = TPD_PF(xf5, u, a.xfx.t[at(m, j)]), fxad = TPD_PF(fx5, u, in ? a.fx.p[at(m, j)] : 0.), mm = TPD_PF(mm5, u, in ? a.mx.t[at(m, j)] : 0.);
-          const double dg = (m <= nx ? QG[qe(m, j)] : 0.) - (m >= 2 ? QG[qe(m - 1, j)] : 0.);
+          const double dg = (m <= ie ? QG[qe(m, j)] : 0.) - (m >= is + 1 ? QG[qe(m - 1, j)] : 0.);
           s = xf * dg + 0.5 * mm * fxad;
           if (own) {          // xfx and mx may be one array (the mass transport): two accumulates in program order
             const double f2v = F2[f2e(m, j)];
@@ -533,6 +534,7 @@ DEV void tp_ad_corner_point(const TpFusedArgs& a, const Ctx& c, int tile, int k,
   // the 3 x 3 sources of corner cn for this direction: dir 2 reads them from the south / north halo rows next to the corner columns,
   // dir 1 from the west / east halo columns next to the corner rows (edges.h corner_alias)
   const bool west = (cn == 0 || cn == 3), south = (cn < 2);
+  if ((west ? g.is() != 1 : g.ie() != nx) || (south ? g.js() != 1 : g.je() != ny)) return;      // a sub-face tile holds at most one face corner
   int si, sj;
   if (dir == 2) { si = (west ? 1 : nx - ng + 1) + n % ng; sj = (south ? 1 - ng : ny + 1) + n / ng; }
   else { si = (west ? 1 - ng : nx + 1) + n % ng; sj = (south ? 1 : ny - ng + 1) + n / ng; }
@@ -600,12 +602,12 @@ __global__ void __launch_bounds__(64) k_tp_ad_corner(TpFusedArgs a, Ctx c) {
 FV3LM_LINK void run_tp_ad(Exec& ex, const TpFusedArgs& a0, const Ctx& c) {
   TpFusedArgs a = a0;
   for (Fld* f : {&a.q, &a.crx, &a.cry, &a.xfx, &a.yfx, &a.rax, &a.ray, &a.mx, &a.my, &a.fx, &a.fy}) *f = ex.sh(*f);
-  const int nbx = (c.g.nx + TPD_W - 1) / TPD_W, nby = (c.g.ny + TPD_H - 1) / TPD_H;
+  const int nbx = (c.g.tx + TPD_W - 1) / TPD_W, nby = (c.g.ty + TPD_H - 1) / TPD_H;
 #if FV3LM_TPD_EXP
   if (const char* e = std::getenv("FV3LM_TP2_EXPERIMENT")) a.exp = std::atoi(e);
 #endif
   // algorithmic bytes: trajectory q, crx, cry, xfx, yfx, ra_x, ra_y, mx, my and the adjoints fx, fy read; the nine input adjoints read-modify-written
-  const double cells = double(c.g.nx) * c.g.ny * c.g.ntile * a.nk;
+  const double cells = double(c.g.tx) * c.g.ty * c.g.ntile * a.nk;
   ex.mark_begin("TpAd", ".ad", 8. * cells * (9. + 2. + 18.));
 #ifdef FV3LM_HOST_EMUL
   std::vector<double> lds((size_t)TPD_NT);
