@@ -171,6 +171,13 @@ def scheme_string(o, nh):
     return s
 
 
+def default_layout(world):
+    """Whole faces while they deal out evenly (1, 2, 3, 6 GPUs); otherwise the 24 sub-face tiles of a 2 x 2 layout, dealt in position-major
+    order: 4 GPUs hold the six tiles of one position each (one tile class, balanced -- six faces on four GPUs would be 2 + 2 + 1 + 1),
+    8 GPUs three tiles each."""
+    return 1 if 6 % world == 0 else 2
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,7 +198,7 @@ def main():
     ap.add_argument("--nord-traj", type=int, default=0, help="trajectory divergence-damping order (2 or 3) beside nord_pert = 1: split_damp (not the headline configuration)")
     ap.add_argument("--split-damp", action="store_true", help="split_damp = .true. (the reference's default) with equal namelist values: the perturbation sponge rules differ")
     ap.add_argument("--layout", type=int, default=0,
-                    help="tiles per face edge (fv_flags_type%%layout): 1 = whole faces, 2 = 24 sub-face tiles ... Default: 1 up to 6 GPUs (a face or more "
+                    help="tiles per face edge (fv_flags_type%%layout): 1 = whole faces, 2 = 24 sub-face tiles ... Default: 1 where six faces deal out evenly over the GPUs (1, 2, 3, 6), else 2 ("
                          "per GPU), 2 beyond (24 tiles, three per GPU at 8: all of the node works; six whole faces would idle two GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-host-transport", action="store_true",
@@ -262,7 +269,7 @@ def main():
                 for r, h in stage:
                     assert hip.hipMemcpy(r.ctypes.data, h.data_ptr(), r.size * 8, 1) == 0
             set_transport_callback(lib, transport)
-            layout_ = args.layout if args.layout > 0 else (1 if world <= 6 else 2)
+            layout_ = args.layout if args.layout > 0 else default_layout(world)
             grp = dist.new_group(ranks=list(range(min(world, 6 * layout_ * layout_))))
             if rank < min(world, 6 * layout_ * layout_):
                 def allmax(buf):
@@ -277,14 +284,14 @@ def main():
                     t.copy_(torch.tensor(list(data), dtype=torch.uint8))
                 dist.broadcast(t, src=0)
                 return bytes(t.cpu().tolist())
-            layout_ = args.layout if args.layout > 0 else (1 if world <= 6 else 2)
+            layout_ = args.layout if args.layout > 0 else default_layout(world)
             nact = min(world, 6 * layout_ * layout_)      # ranks without a tile stay out of the communicator
             if rank < nact:
                 comm_init_rccl(lib, rank, nact, bcast)
             else:
                 bcast(None)
             # tracer_2d's per-level max Courant number over all faces: ncclAllReduce(max) inside the library, on the same communicator
-        layout = args.layout if args.layout > 0 else (1 if world <= 6 else 2)
+        layout = args.layout if args.layout > 0 else default_layout(world)
         ntiles = 6 * layout * layout
         active = len(cube.faces_of(rank, world, ntiles)) > 0
         if active:
