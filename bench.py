@@ -198,8 +198,8 @@ def main():
     ap.add_argument("--nord-traj", type=int, default=0, help="trajectory divergence-damping order (2 or 3) beside nord_pert = 1: split_damp (not the headline configuration)")
     ap.add_argument("--split-damp", action="store_true", help="split_damp = .true. (the reference's default) with equal namelist values: the perturbation sponge rules differ")
     ap.add_argument("--layout", type=int, default=0,
-                    help="tiles per face edge (fv_flags_type%%layout): 1 = whole faces, 2 = 24 sub-face tiles ... Default: 1 where six faces deal out evenly over the GPUs (1, 2, 3, 6), else 2 ("
-                         "per GPU), 2 beyond (24 tiles, three per GPU at 8: all of the node works; six whole faces would idle two GPUs)")
+                    help="tiles per face edge (fv_flags_type%%layout): 1 = whole faces, 2 = 24 sub-face tiles ... Default: 1 where six faces deal out evenly over the GPUs (1, 2, 3, 6), "
+                         "else 2 (24 tiles: six per GPU at 4, three at 8 -- six whole faces would leave GPUs idle or half loaded)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-host-transport", action="store_true",
                     help="multi-rank rehearsal on ONE GPU (RCCL refuses two ranks per device): gloo process group, halo messages staged "
