@@ -378,6 +378,12 @@ inline double stage_bytes(const S& s, const Ctx& c, const Rect& R, int mode) {
 #define FV3LM_BY 4
 #endif
 constexpr int BX = 64, BY = FV3LM_BY;
+// experiment switch: minimum waves per SIMD asked of the compiler for the generic stage kernels (register cap); unset = the compiler's choice
+#ifdef FV3LM_STAGE_WAVES
+#define FV3LM_STAGE_ATTR __attribute__((amdgpu_waves_per_eu(FV3LM_STAGE_WAVES, 8)))
+#else
+#define FV3LM_STAGE_ATTR
+#endif
 // tr: narrow column strips (face-edge stages) run with the 64 lanes of a wave along j instead of i
 // XCD-aware block order.  Workgroups go to the 8 XCDs round-robin by linear id, so with the plain (x, y) order the
 // blocks above and below a block — which re-read 2/3 of its stencil rows — sit on other XCDs and their private L2s
@@ -396,12 +402,12 @@ HD void thread_point(const Rect& R, int tr, int bx, int by, int tx, int ty, int&
   else { i = R.i0 + bx * BX + tx; j = R.j0 + by * BY + ty; }
 }
 template <class S>
-__global__ void __launch_bounds__(BX* BY) k_stage_nl(S s, Ctx c, Rect R, int tr) {
+__global__ void __launch_bounds__(BX* BY) FV3LM_STAGE_ATTR k_stage_nl(S s, Ctx c, Rect R, int tr) {
   int i, j, bx = blockIdx.x, by = blockIdx.y; xcd_block(gridDim.x, gridDim.y, bx, by); thread_point(R, tr, bx, by, threadIdx.x, threadIdx.y, i, j);
   if (i <= R.i1 && j <= R.j1) body_nl(s, c, i, j, blockIdx.z);
 }
 template <class S>
-__global__ void __launch_bounds__(BX* BY) k_stage_tl(S s, Ctx c, Rect R, int tr) {
+__global__ void __launch_bounds__(BX* BY) FV3LM_STAGE_ATTR k_stage_tl(S s, Ctx c, Rect R, int tr) {
   int i, j, bx = blockIdx.x, by = blockIdx.y; xcd_block(gridDim.x, gridDim.y, bx, by); thread_point(R, tr, bx, by, threadIdx.x, threadIdx.y, i, j);
   if (i <= R.i1 && j <= R.j1) body_tl(s, c, i, j, blockIdx.z);
 }
@@ -495,7 +501,7 @@ __global__ void __launch_bounds__(BX* S::LDS_BY) k_stage_fw_lds(S s, Ctx c, Rect
   }
 }
 template <class S>
-__global__ void __launch_bounds__(BX* BY) k_stage_ad(S s, Ctx c, Rect R, Rect Q, int nkmax, int tr) {
+__global__ void __launch_bounds__(BX* BY) FV3LM_STAGE_ATTR k_stage_ad(S s, Ctx c, Rect R, Rect Q, int nkmax, int tr) {
   int i, j, bx = blockIdx.x, by = blockIdx.y; xcd_block(gridDim.x, gridDim.y, bx, by); thread_point(Q, tr, bx, by, threadIdx.x, threadIdx.y, i, j);
   if (i <= Q.i1 && j <= Q.j1) ad_point(s, c, R, i, j, blockIdx.z, nkmax);
 }

@@ -38,3 +38,17 @@ def test_cpu_baseline_worker_runs():
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline_worker.py"), "8", "6", "2", "1", "1", "450", "1", "3"],
                                   text=True)
     assert json.loads(out.strip().splitlines()[-1])["columns"] == 64
+
+
+def test_default_layout_balances_the_gpus():
+    """whole faces where six deal out evenly, the 24 sub-face tiles elsewhere; every GPU then holds the same number of tiles at 4 and 8"""
+    from fv3_jedi_linearmodel_amd import cube
+    assert [bench.default_layout(w) for w in range(1, 9)] == [1, 1, 1, 2, 2, 1, 2, 2]
+    for w in (1, 2, 3, 6):
+        assert len({len(cube.faces_of(r, w, 6)) for r in range(w)}) == 1
+    for w in (4, 8):
+        assert len({len(cube.faces_of(r, w, 24)) for r in range(w)}) == 1
+    # position-major order: the six tiles of a 4-GPU rank share one window of their faces (one tile class)
+    tl = cube.tiles(48, 2)
+    for r in range(4):
+        assert len({(tl[t][1], tl[t][2]) for t in cube.faces_of(r, 4, 24)}) == 1
