@@ -875,6 +875,54 @@ struct TpDamp {
   HD static constexpr bool uses(int, int di, int dj, int) { return !(di == -1 && dj == -1); }
   HD static constexpr unsigned wants(int) { return 0x3u; }
   HD static constexpr Box box(int) { return Box{-1, 0, -1, 0, 0, 0}; }
+  // Hand-written gather adjoint (the stage only ever runs in the adjoint mode): the damping flux at a face is a metric factor times a
+  // two-point difference of q (nord 0) or of the damping Laplacian, optionally times the mean mass of the two cells -- each input adjoint
+  // is a sum over the four faces of its cell.  Store rules of exec.h body_ad_joint.
+  static constexpr bool HAND_AD = true;
+  HD void hand_ad(const Ctx& c, const Rect& R, int i, int j, int z) const {
+    const int nk = in[0].nk;
+    if (z >= c.g.ntile * nk) return;
+    const int tile = z / nk, k = 1 + z % nk;
+    if (!wmask && (i < R.i0 - 1 || i > R.i1 || j < R.j0 - 1 || j > R.j1)) return;
+    const size_t pb = (size_t)(tile * nk + k - 1) * c.g.plane;
+    double acc[3] = {0., 0., 0.};
+    if (k >= k0 && k <= k1) {
+      int nord; double dc; damp_of(c.lev[k - 1], dsel, nord, dc, hsel >= 0 && level_split(c.lev[k - 1], hsel, dsel));
+      if ((dsel != DAMP_NONE) && (dc > 1.e-4)) {
+        const double damp = damp_pow(dc * c.m.da_min, nord);
+        auto tr = [&](int m, int ii, int jj) { return in[m].t[pb + c.g.idx(ii, jj)]; };
+        // face (ii, jj) of direction dir (0: x-face between cells ii-1, ii; 1: y-face between jj-1, jj): sgn = +1 if the point is the face's
+        // upper cell (ii / jj), -1 if it is the lower one
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const int dir = f >> 1, up = f & 1;                 // up: the face on the high side of cell (i, j), where the cell is the LOWER one
+          const int ii = i + (dir == 0 ? up : 0), jj = j + (dir == 1 ? up : 0);
+          if (!orect[dir].has(ii, jj)) continue;
+          const double fa = out[dir].p[pb + c.g.idx(ii, jj)];
+          const int li = ii - (dir == 0 ? 1 : 0), lj = jj - (dir == 1 ? 1 : 0);      // the face's lower cell
+          const double d6 = dir == 0 ? MET(del6_v, ii, jj) : MET(del6_u, ii, jj);
+          const double mm = use_mass ? 0.5 * damp * (tr(2, li, lj) + tr(2, ii, jj)) : 1.;
+          const double sgn = up ? -1. : 1.;                   // the cell is the face's upper cell (+) or its lower cell (-) in  (upper - lower)
+          if (nord == 0) {           // f2 = d6 (q_lower - q_upper) [damp]; flux = mm f2 (use_mass) | f2
+            const double kq = d6 * (use_mass ? mm : damp);
+            acc[0] += -sgn * kq * fa;
+            if (use_mass) acc[2] += 0.5 * damp * (d6 * (tr(0, li, lj) - tr(0, ii, jj))) * fa;
+          } else {                   // f2 = d6 (d2_upper - d2_lower); flux = mm f2 | f2
+            acc[1] += sgn * d6 * mm * fa;
+            if (use_mass) acc[2] += 0.5 * damp * (d6 * (tr(1, ii, jj) - tr(1, li, lj))) * fa;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+      if (in[m].p) {
+        const bool in_m = !(i < R.i0 - 1 || i > R.i1 || j < R.j0 - 1 || j > R.j1);
+        double* q = &in[m].p[pb + c.g.idx(i, j)];
+        if ((wmask >> m) & 1u) *q = in_m ? acc[m] : 0.0;
+        else if (in_m) *q += acc[m];
+      }
+  }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     int nord; double dc; damp_of(c.lev[k - 1], dsel, nord, dc, hsel >= 0 && level_split(c.lev[k - 1], hsel, dsel));
