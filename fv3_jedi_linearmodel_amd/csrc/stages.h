@@ -1113,6 +1113,29 @@ struct A2bA_ {
     }
     return std4(m);
   }
+  // Hand-written gather adjoint of the bulk form: two 4-point interpolations with the constant weights B1, B2 -- q_ad is the weighted sum
+  // of the four qx adjoints along i and the four qy adjoints along j (the generic gather evaluated the stage seven times per point).
+  static constexpr bool HAND_AD = !EDGE;
+  HD void hand_ad(const Ctx& c, const Rect& R, int i, int j, int z) const {
+    const int nk = in[0].nk;
+    if (z >= c.g.ntile * nk || !in[0].p) return;
+    const int tile = z / nk, k = 1 + z % nk;
+    const bool in_m = !(i < R.i0 - 2 || i > R.i1 + 1 || j < R.j0 - 2 || j > R.j1 + 1);
+    if (!in_m && !wmask) return;
+    const size_t pb = (size_t)(tile * nk + k - 1) * c.g.plane;
+    double acc = 0.;
+    if (in_m && k >= k0 && k <= k1) {
+      const double w[4] = {B2, B1, B1, B2};        // output at offset -1, 0, +1, +2 from the point
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int m = i - 1 + d, n = j - 1 + d;
+        if (orect[0].has(m, j)) acc += w[d] * out[0].p[pb + c.g.idx(m, j)];
+        if (orect[1].has(i, n)) acc += w[d] * out[1].p[pb + c.g.idx(i, n)];
+      }
+    }
+    double* q = &in[0].p[pb + c.g.idx(i, j)];
+    if (wmask & 1u) *q = in_m ? acc : 0.0; else if (in_m) *q += acc;
+  }
   template <class T, class A>
   HD void eval(const A& a, const Ctx& c, int tile, int i, int j, int k, T* o) const {
     o[0] = o[1] = T(0.);
