@@ -587,15 +587,13 @@ __global__ void __launch_bounds__(TPD_THREADS) k_tp_ad(TpFusedArgs a, Ctx c) {
   int bx = blockIdx.x, by = blockIdx.y; xcd_block(gridDim.x, gridDim.y, bx, by);
   tp_ad_block<TPD_THREADS>(a, c, blockIdx.z / a.nk, 1 + blockIdx.z % a.nk, bx, by, tpd_lds, threadIdx.x, TPD_THREADS);
 }
-__global__ void __launch_bounds__(64) k_tp_ad_corner(TpFusedArgs a, Ctx c) {
-  // 4 corners x 9 sources: threads 0..35 direction 2, then a second pass direction 1 (the two passes of one thread touch different
-  // sources in general, but a source of both directions -- none exists: the direction-2 sources lie in the south / north halo rows,
-  // the direction-1 sources in the west / east halo columns)
-  const int t = threadIdx.x;
+__global__ void __launch_bounds__(128) k_tp_ad_corner(TpFusedArgs a, Ctx c) {
+  // 4 corners x 9 sources per direction: the first wave takes direction 2, the second direction 1 (no source belongs to both: the
+  // direction-2 sources lie in the south / north halo rows, the direction-1 sources in the west / east halo columns)
+  const int t = threadIdx.x & 63, dir = threadIdx.x < 64 ? 2 : 1;
   if (t >= 36) return;
   const int tile = blockIdx.x / a.nk, k = 1 + blockIdx.x % a.nk;
-  tp_ad_corner_point(a, c, tile, k, t / 9, t % 9, 2);
-  tp_ad_corner_point(a, c, tile, k, t / 9, t % 9, 1);
+  tp_ad_corner_point(a, c, tile, k, t / 9, t % 9, dir);
 }
 #endif
 
@@ -627,7 +625,7 @@ FV3LM_LINK void run_tp_ad(Exec& ex, const TpFusedArgs& a0, const Ctx& c) {
 #ifndef FV3LM_HOST_EMUL
   if (c.g.face) {
     ex.mark_begin("TpAd", ".ad_corner", 0.);
-    hipLaunchKernelGGL(k_tp_ad_corner, dim3(c.g.ntile * a.nk), dim3(64), 0, ex.stream, a, c);
+    hipLaunchKernelGGL(k_tp_ad_corner, dim3(c.g.ntile * a.nk), dim3(128), 0, ex.stream, a, c);
     ex.mark_end();
     ex.launches++;
   }
