@@ -35,7 +35,7 @@ FV3LM_LINK void run_tp_fused(Exec& ex, int mode, const TpFusedArgs& a0, const Ct
 FV3LM_LINK void run_tp_outer_ad(Exec& ex, const TpFusedArgs& a0, const Ctx& c);
 // the same routine laid out for the wavefront (tp2.h): takes the nonlinear and tangent launches that store nothing for the staged adjoint
 FV3LM_LINK void run_tp2(Exec& ex, int mode, const TpFusedArgs& a0, const Ctx& c);
-inline bool tp2_enabled() { static const bool on = [] { const char* e = std::getenv("FV3LM_TP2"); return !(e && e[0] == '0'); }(); return on; }
+inline bool tp2_enabled() { const char* e = std::getenv("FV3LM_TP2"); return !(e && e[0] == '0'); }      // read per launch: a test switches it between two models
 }  // namespace fv3
 
 #ifdef FV3LM_HOST_EMUL

@@ -23,3 +23,17 @@ def test_strip_streams_do_not_change_results(hydro, monkeypatch):
         else:
             e = float(np.max(np.abs(a[key] - b[key])) / np.max(np.abs(b[key])))
             assert e <= 1e-13, (key, e)
+
+
+def test_fused_transport_forms_agree(monkeypatch):
+    """fv_tp_2d in its current forms (tp2.h forward kernels, tpad.h one-launch adjoint) against round 2's (first tiled forward kernel,
+    outer adjoint fused + inner adjoint staged): different kernels, same arithmetic up to the contraction of a*b+c"""
+    from common import CubeCase
+    from layout_checks import run_steps
+    kw = dict(n=70, npz=6, n_split=2, k_split=1, dt=600.0, backend="hip", oracle=False, nq=1)
+    a = run_steps(CubeCase(**kw))
+    monkeypatch.setenv("FV3LM_TP2", "0"); monkeypatch.setenv("FV3LM_TP_AD_FUSED", "1")
+    b = run_steps(CubeCase(**kw))
+    for key in b:
+        e = float(np.max(np.abs(a[key] - b[key])) / np.max(np.abs(b[key])))
+        assert np.isfinite(a[key]).all() and e <= (1e-12 if key[0] == "tl" else 1e-11), (key, e)
