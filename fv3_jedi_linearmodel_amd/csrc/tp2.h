@@ -386,7 +386,7 @@ FV3LM_LINK void run_tp2(Exec& ex, int mode, const TpFusedArgs& a0, const Ctx& c)
   const dim3 grid(nbx, nby, c.g.ntile * a.nk);
   static bool attr = false;      // more LDS per block than the 64 KB default limit of a launch
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)k_tp2<Dual, FV3LM_TP2_WAVES_TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp2_lds_bytes<Dual>()) != hipSuccess ||
+    if ((tp2_lds_bytes<Dual>() <= 160 * 1024 && hipFuncSetAttribute((const void*)k_tp2<Dual, FV3LM_TP2_WAVES_TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp2_lds_bytes<Dual>()) != hipSuccess) ||
         hipFuncSetAttribute((const void*)k_tp2<double, FV3LM_TP2_WAVES_NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp2_lds_bytes<double>()) != hipSuccess) set_sticky("hipFuncSetAttribute(k_tp2) failed");
     attr = true;
   }

@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(NTH) k_tp_fused(TpFusedArgs a, Ctx c) {
 #endif
 
 FV3LM_LINK void run_tp_fused(Exec& ex, int mode, const TpFusedArgs& a0, const Ctx& c, bool traj) {
-  if (!traj && (mode == MODE_TL || !a0.store_mid) && tp2_enabled()) { run_tp2(ex, mode, a0, c); return; }
+  if (!traj && (mode == MODE_TL || !a0.store_mid) && tp2_enabled() && !(mode == MODE_TL && std::getenv("FV3LM_TP2_NL_ONLY"))) { run_tp2(ex, mode, a0, c); return; }
   TpFusedArgs a = a0;
   for (Fld* f : {&a.q, &a.crx, &a.cry, &a.xfx, &a.yfx, &a.rax, &a.ray, &a.mx, &a.my, &a.mass, &a.d2b, &a.d2b_t, &a.fx, &a.fy, &a.fy2, &a.q_i, &a.fxo, &a.fx2, &a.q_j, &a.fyo, &a.acx, &a.acy, &a.amfx, &a.amfy}) *f = ex.sh(*f);
   a.do_acc = (a.acx.t && !ex.skip_accum) ? 1 : 0;
