@@ -814,11 +814,18 @@ __global__ void __launch_bounds__(BX* BY) k_points(F f, Rect R) {
   const int i = R.i0 + blockIdx.x * BX + threadIdx.x, j = R.j0 + blockIdx.y * BY + threadIdx.y;
   if (i <= R.i1 && j <= R.j1) f(i, j, (int)blockIdx.z);
 }
+// one row of points (exchange tables, per-level reductions): the whole block along i
+template <class F>
+__global__ void __launch_bounds__(BX* BY) k_points_row(F f, Rect R) {
+  const int i = R.i0 + blockIdx.x * (BX * BY) + threadIdx.x;
+  if (i <= R.i1) f(i, R.j0, (int)blockIdx.z);
+}
 template <class F>
 void for_points(Exec& ex, const Rect& R, int nz, const F& f, const char* tag = "points", double bytes = 0.) {
   if (nz <= 0) return;
   ex.mark_begin(tag, "", bytes);
-  hipLaunchKernelGGL(k_points<F>, grid_for(R, nz), dim3(BX, BY), 0, ex.stream, f, R);
+  if (R.j0 == R.j1) hipLaunchKernelGGL(k_points_row<F>, dim3((R.i1 - R.i0 + BX * BY) / (BX * BY), 1, nz), dim3(BX * BY), 0, ex.stream, f, R);
+  else hipLaunchKernelGGL(k_points<F>, grid_for(R, nz), dim3(BX, BY), 0, ex.stream, f, R);
   ex.mark_end();
   ex.launches++;
 }
