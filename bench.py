@@ -204,6 +204,9 @@ def main():
     ap.add_argument("--rehearse-host-transport", action="store_true",
                     help="multi-rank rehearsal on ONE GPU (RCCL refuses two ranks per device): gloo process group, halo messages staged "
                          "through host memory by a transport callback; exercises everything but the RCCL send/recv calls themselves")
+    ap.add_argument("--rccl-loopback", action="store_true",
+                    help="one GPU: every halo row between two resident tiles travels as a message through ncclSend / ncclRecv on a one-rank communicator "
+                         "(the rank as its own peer) instead of the local gather -- the cost of the message path itself, not the headline configuration")
     ap.add_argument("--profile-out", default="")
     args = ap.parse_args()
 
@@ -291,6 +294,9 @@ def main():
             else:
                 bcast(None)
             # tracer_2d's per-level max Courant number over all faces: ncclAllReduce(max) inside the library, on the same communicator
+        if args.rccl_loopback:
+            assert world == 1, "--rccl-loopback is a one-GPU measurement"
+            comm_init_rccl(lib, 0, 1, lambda data: data)
         layout = args.layout if args.layout > 0 else default_layout(world)
         ntiles = 6 * layout * layout
         active = len(cube.faces_of(rank, world, ntiles)) > 0
@@ -305,7 +311,7 @@ def main():
             if args.hord_traj:
                 nhkw.update(hord_mt=args.hord_traj, hord_vt=args.hord_traj, hord_tm=args.hord_traj, hord_dp=args.hord_traj, hord_tr=args.hord_traj)
             c = CubeCase(n=args.nx, npz=args.npz, n_split=args.n_split, k_split=args.k_split, dt=args.dt, backend="hip", nq=args.nq,
-                         rank=rank, world=world, layout=layout, **nhkw)
+                         rank=rank, world=world, layout=layout, loopback=args.rccl_loopback, **nhkw)
             T, P = cube_step_state(c)
             if args.nonhydrostatic:
                 Tn, Pn = cube_nh_state(c)
@@ -378,7 +384,7 @@ def main():
                                    % (args.nx, args.npz, "non-hydrostatic" if args.nonhydrostatic else "hydrostatic", ("six cube faces%s dealt over %d GPU(s) (%s per rank), table-driven exchange%s"
                                                            % ("" if layout == 1 else " cut into %d sub-face tiles (layout %d x %d)" % (ntiles, layout, layout), world,
                                                               "/".join(str(len(cube.faces_of(r, world, ntiles))) for r in range(world)),
-                                                              "" if world == 1 else (", halo messages staged through host memory over gloo (rehearsal on one GPU, NOT RCCL)"
+                                                              (", every row between two tiles as an ncclSend / ncclRecv message of the rank to itself (--rccl-loopback)" if args.rccl_loopback else "") if world == 1 else (", halo messages staged through host memory over gloo (rehearsal on one GPU, NOT RCCL)"
                                                                                     if args.rehearse_host_transport else ", RCCL point-to-point between ranks"))) if cube_mode
                                       else "1 doubly-periodic tile per GPU", cols_rank, args.k_split, args.n_split, args.dt, args.nq, scheme_string(c.opt, args.nonhydrostatic)),
                        "columns_per_gpu": cols_rank, "launches_per_step": sum(v[0] for v in prof.values()),

@@ -302,10 +302,10 @@ class Dycore:
         self.lib.L.fv3lm_set_exchange.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
         self._chk(self.lib.L.fv3lm_set_exchange(self.h, self.HALO_KINDS[kind], r.ctypes.data_as(C.POINTER(C.c_int)), r.shape[0]))
 
-    def set_exchange_split(self, kind, table, rank, world, ntiles=6):
+    def set_exchange_split(self, kind, table, rank, world, ntiles=6, loopback=False):
         """Install one exchange kind for this rank's tiles: local rows + per-peer send/receive lists (cube.split_table)."""
         from . import cube
-        local, peers, send, recv = cube.split_table(table, rank, world, ntiles)
+        local, peers, send, recv = cube.split_table(table, rank, world, ntiles, loopback)
         self.set_exchange(kind, local)
         ip = C.POINTER(C.c_int)
         pe = np.array(peers, dtype=np.int32)

@@ -509,17 +509,22 @@ def face_owner(world, ntiles=6):
     return own
 
 
-def split_table(tab, rank, world, ntiles=6):
+def split_table(tab, rank, world, ntiles=6, loopback=False):
     """One exchange table of the whole cube -> what `rank` needs: (local rows [n,7] with local tile numbers,
     peers, {peer: send rows [m,3] = field, local tile, index}, {peer: recv rows [m,4] = field, local tile, index, sign}).
-    Both ends walk the global table in the same order, so message layouts agree without negotiation."""
+    Both ends walk the global table in the same order, so message layouts agree without negotiation.
+    loopback: the rows between two tiles of this rank travel as messages too, with the rank as its own peer (pack -> send to
+    self / receive from self -> unpack) — the message path exercised end to end where only one GPU is at hand."""
     own = face_owner(world, ntiles)
     mine = faces_of(rank, world, ntiles)
     loc = {f: n for n, f in enumerate(mine)}
     local, send, recv = [], {}, {}
     for r in tab:
         do, so = own[int(r[1])], own[int(r[4])]
-        if do == rank and so == rank:
+        if do == rank and so == rank and loopback:
+            recv.setdefault(rank, []).append((r[0], loc[int(r[1])], r[2], r[6]))
+            send.setdefault(rank, []).append((r[3], loc[int(r[4])], r[5]))
+        elif do == rank and so == rank:
             local.append((r[0], loc[int(r[1])], r[2], r[3], loc[int(r[4])], r[5], r[6]))
         elif do == rank:
             recv.setdefault(so, []).append((r[0], loc[int(r[1])], r[2], r[6]))

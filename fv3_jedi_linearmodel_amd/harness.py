@@ -87,9 +87,10 @@ class CubeCase:
     case are then the tiles' windows [ntile, nk, n/L+7, n/L+7] of the same global fields (gather() puts results back on faces)."""
 
     def __init__(self, n=12, npz=6, n_split=2, k_split=1, dt=1800.0, backend="hip", seed=20250114, nq=0, oracle=False, rank=0, world=1,
-                 layout=1, **optkw):
+                 layout=1, loopback=False, **optkw):
         """rank/world: this process holds only cube.faces_of(rank, world, ntiles) (one process per GPU); state and metrics are the
-        corresponding slices of the same global fields, so results can be compared with a single-process run."""
+        corresponding slices of the same global fields, so results can be compared with a single-process run.
+        loopback: the rows between this rank's own tiles go through the message path too (cube.split_table)."""
         from . import cube
         self.n = n
         self.layout = layout
@@ -143,8 +144,8 @@ class CubeCase:
         self.dy.set_face_data(self.edge, self.ecorner)
         self._after_create(backend)
         for k, t in self.tables.items():
-            if world > 1:
-                self.dy.set_exchange_split(k, t, rank, world, ntiles)
+            if world > 1 or loopback:
+                self.dy.set_exchange_split(k, t, rank, world, ntiles, loopback)
             else:
                 self.dy.set_exchange(k, t)
 

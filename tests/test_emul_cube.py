@@ -57,3 +57,30 @@ def test_cube_tracer_subcycling(ccase_q):
     cube_check_tracer(ccase_q, TL, 1e-11, scale=80.0)
     cube_check_tracer(ccase_q, AD, 1e-10, scale=80.0)
     assert ccase_q.dy.lib.L.fv3lm_tracer_nsplt(ccase_q.dy.h) >= 2
+
+
+def test_cube_loopback_message_path():
+    """Every row between two faces travels as a message with the rank as its own peer (cube.split_table loopback): pack -> transport ->
+    unpack, the adjoint back the other way — the N > 1 path of exchange.h on one rank, against the six-face oracle.  The same test runs
+    through ncclSend / ncclRecv on the device (test_gpu_parity.py)."""
+    import ctypes as C
+    from fv3_jedi_linearmodel_amd._lib import set_transport_callback, TRANSPORT_FN
+    c = CubeCase(n=8, npz=6, n_split=2, k_split=2, backend="emul", oracle=True, nq=2, loopback=True)
+    calls = [0]
+
+    def transport(peers, sbufs, rbufs):
+        assert peers == [0]
+        for s, r in zip(sbufs, rbufs):
+            assert s.size == r.size
+            r[:] = s
+        calls[0] += 1
+    set_transport_callback(c.lib, transport)
+    try:
+        cube_check_fv_dynamics(c, TL, 1e-10)
+        cube_check_fv_dynamics(c, AD, 1e-10)
+        cube_check_tracer(c, TL, 1e-11, scale=80.0)
+        lhs, rhs = cube_dot_product_step(c)
+        assert abs(lhs - rhs) <= 1e-11 * abs(lhs), (lhs, rhs)
+        assert calls[0] > 0
+    finally:
+        c.lib.L.fv3lm_set_transport_callback(C.cast(None, TRANSPORT_FN), None)
