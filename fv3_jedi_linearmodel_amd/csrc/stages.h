@@ -167,8 +167,49 @@ HD void mono_blbr(int iord, bool face, int i, int n1, const double* v, const D& 
 }
 // flux at interface m with the trajectory scheme: the differentiable schemes through ppm_flux, 8 / 10 through the slopes of the upwind
 // cell (:944-952).  The six cells q(m-3 .. m+2) are read once; the upwind cell's window is picked by selects, never by a dynamic index.
+// The limited low-order schemes of the NONLINEAR routines, iord 3 .. 7 (xppm tp_core_tlm.F90:442-590, yppm :1060-1336; xtp_u
+// sw_core_tlm.F90:4483-4612, ytp_v :5147-5360) -- values only, like 8 / 10: the edge values and slopes of the linear scheme 2, and the tests
+// smt5 / smt6 on the slopes of the two cells beside the interface decide which of them keeps its parabola.  (blm, brm): cell m-1, (bl0, br0): cell m;
+// x = the Courant number of the flux formula (c, or c * rd(upwind) for the momentum fluxes).
+HD double low_flux(int iord, double qm, double q0, double blm, double brm, double bl0, double br0, bool up, double x) {
+  const double b0m = blm + brm, b00 = bl0 + br0;
+  if (iord == 3 || iord == 4) {
+    const double xm = fabs(blm - brm), x0 = fabs(bl0 - br0);
+    const bool s5m = fabs(b0m) < xm, s6m = 3. * fabs(b0m) < xm, s50 = fabs(b00) < x0, s60 = 3. * fabs(b00) < x0;
+    if (iord == 4) {
+      if (up) return (s6m || s50) ? qm + (1. - x) * (brm - x * b0m) : qm;
+      return (s60 || s5m) ? q0 + (1. + x) * (bl0 + x * b00) : q0;
+    }
+    double fx1 = 0.;
+    if (up) {
+      if (s6m || s50) fx1 = brm - x * b0m;
+      else if (s5m) fx1 = mono_sign(fmin(fabs(blm), fabs(brm)), brm);
+      return qm + (1. - x) * fx1;
+    }
+    if (s60 || s5m) fx1 = bl0 + x * b00;
+    else if (s50) fx1 = mono_sign(fmin(fabs(bl0), fabs(br0)), bl0);
+    return q0 + (1. + x) * fx1;
+  }
+  const bool s5m = iord == 5 ? blm * brm < 0. : fabs(3. * b0m) < fabs(blm - brm), s50 = iord == 5 ? bl0 * br0 < 0. : fabs(3. * b00) < fabs(bl0 - br0);
+  const double fx1 = up ? (1. - x) * (brm - x * b0m) : (1. + x) * (bl0 + x * b00);
+  const double f = up ? qm : q0;
+  return (s5m || s50) ? f + fx1 : f;
+}
+HD constexpr bool hord_low(int iord) { return iord >= 3 && iord <= 7; }
+template <class Q, class D>
+HD double ppm_al7(int iord, bool face, int x, int n1, const Q& q, const D& da) {      // iord 7: edge values kept non-negative (tp_core_tlm.F90:345-349, :357-373, :382-405)
+  const double al = ppm_al<double>(face, x, n1, q, da);
+  if (iord != 7) return al;
+  if (face && (x <= 2 || x >= n1 - 1)) return fmax(0., al);
+  return al < 0. ? 0.5 * (q(x - 1) + q(x)) : al;
+}
 template <class Q, class D>
 HD double ppm_flux_traj(int iord, bool face, int m, int n1, const Q& q, const D& da, double cc) {
+  if (hord_low(iord)) {
+    const double alm = ppm_al7(iord, face, m - 1, n1, q, da), al0 = ppm_al7(iord, face, m, n1, q, da), alp = ppm_al7(iord, face, m + 1, n1, q, da);
+    const double qm = q(m - 1), q0 = q(m);
+    return low_flux(iord, qm, q0, alm - qm, al0 - qm, al0 - q0, alp - q0, cc > 0., cc);
+  }
   if (iord != 8 && iord != 10) return ppm_flux<double>(iord, face, m, n1, q, da, cc);
   const double w0 = q(m - 3), w1 = q(m - 2), w2 = q(m - 1), w3 = q(m), w4 = q(m + 1), w5 = q(m + 2);
   const bool up = cc > 0.;
@@ -238,6 +279,13 @@ HD void uv_mono_blbr(int iord, bool face, int i, int n1, bool row_edge, const do
 }
 template <class Q, class D>
 HD double tp_uv_flux_traj(int iord, bool face, int m, int n1, bool row_edge, const Q& q, const D& dd, double cc, double rd_m, double rd_0) {
+  if (hord_low(iord)) {
+    double blm, brm, bl0, br0;
+    uv_blbr<double>(face, m - 1, n1, row_edge, q, dd, blm, brm);
+    uv_blbr<double>(face, m, n1, row_edge, q, dd, bl0, br0);
+    const bool up = cc > 0.;
+    return low_flux(iord, q(m - 1), q(m), blm, brm, bl0, br0, up, cc * (up ? rd_m : rd_0));
+  }
   if (iord != 8 && iord != 10) return tp_uv_flux<double>(iord, face, m, n1, row_edge, q, dd, cc, rd_m, rd_0);
   const double w0 = q(m - 3), w1 = q(m - 2), w2 = q(m - 1), w3 = q(m), w4 = q(m + 1), w5 = q(m + 2);
   const bool up = cc > 0.;

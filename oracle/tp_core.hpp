@@ -2,8 +2,8 @@
 // Restatement of model_tlmadm/tp_core_tlm.F90: fv_tp_2d (:83-236 / _TLM :2123-2324), xppm
 // (_TLM :2328-2492), yppm (_TLM :2496-2669), deln_flux (:1918-2043 / _TLM :2673-2837),
 // copy_corners (:2046-2118).  Only the schemes the TL/AD code implements are restated:
-// iord/jord in {1, 2, 333} (tp_core_tlm.F90:2393,2431,2441,2467); on double (the nonlinear routine) also the monotone
-// iord 8 / 10 of tp_mono.hpp, which fv_tp_2d_split below runs for the trajectory values when the schemes are split.
+// iord/jord in {1, 2, 333} (tp_core_tlm.F90:2393,2431,2441,2467); on double (the nonlinear routine) also the limited
+// iord 3 .. 7 and the monotone 8 / 10 of tp_mono.hpp, which fv_tp_2d_split below runs for the trajectory values when the schemes are split.
 #pragma once
 #include "arrays.hpp"
 #include "tp_mono.hpp"
@@ -45,7 +45,7 @@ void copy_corners(Arr2<T>& q, int dir, const Bounds& bd) {
 template <class T>
 void xppm(Arr2<T>& flux, const Arr2<T>& q, const Arr2<T>& c, int iord, int is, int ie, int jfirst, int jlast,
           const Bounds& bd, const Grid& g) {
-  if (iord == 8 || iord == 10) { Mono<T>::x(flux, q, c, iord, is, ie, jfirst, jlast, bd, g); return; }
+  if ((iord >= 3 && iord <= 8) || iord == 10) { Mono<T>::x(flux, q, c, iord, is, ie, jfirst, jlast, bd, g); return; }
   assert(iord == 1 || iord == 2 || iord == 333);
   const int npx = bd.npx;
   int is1 = is - 1, ie3 = ie + 2;
@@ -100,7 +100,7 @@ void xppm(Arr2<T>& flux, const Arr2<T>& q, const Arr2<T>& c, int iord, int is, i
 template <class T>
 void yppm(Arr2<T>& flux, const Arr2<T>& q, const Arr2<T>& c, int jord, int ifirst, int ilast, int js, int je,
           const Bounds& bd, const Grid& g) {
-  if (jord == 8 || jord == 10) { Mono<T>::y(flux, q, c, jord, ifirst, ilast, js, je, bd, g); return; }
+  if ((jord >= 3 && jord <= 8) || jord == 10) { Mono<T>::y(flux, q, c, jord, ifirst, ilast, js, je, bd, g); return; }
   assert(jord == 1 || jord == 2 || jord == 333);
   const int npy = bd.npy;
   int js1 = js - 1, je3 = je + 2;

@@ -108,15 +108,26 @@ void ppm_line_mono(int iord, int first, int last, int np, bool any_edge, bool ed
   }
 }
 
+template <class FQ, class FC, class FD, class FOut>
+void ppm_line_low(int iord, int first, int last, int np, bool any_edge, bool edge_lo, bool edge_hi, const FQ& q, const FC& c, const FD& da, const FOut& flux);
+
 inline void xppm_mono(Arr2<double>& flux, const Arr2<double>& q, const Arr2<double>& c, int iord, int is, int ie, int jfirst, int jlast,
                       const Bounds& bd, const Grid& g) {
   for (int j = jfirst; j <= jlast; ++j)
+    if (iord >= 3 && iord <= 7)
+      ppm_line_low(iord, is, ie, bd.npx, bd.any_edge(), bd.edge_w, bd.edge_e, [&](int i) { return q(i, j); }, [&](int i) { return c(i, j); },
+                   [&](int i) { return g.dxa(i, j); }, [&](int i, double f) { flux(i, j) = f; });
+    else
     ppm_line_mono(iord, is, ie, bd.npx, bd.any_edge(), bd.edge_w, bd.edge_e, [&](int i) { return q(i, j); }, [&](int i) { return c(i, j); },
                   [&](int i) { return g.dxa(i, j); }, [&](int i, double f) { flux(i, j) = f; });
 }
 inline void yppm_mono(Arr2<double>& flux, const Arr2<double>& q, const Arr2<double>& c, int jord, int ifirst, int ilast, int js, int je,
                       const Bounds& bd, const Grid& g) {
   for (int i = ifirst; i <= ilast; ++i)
+    if (jord >= 3 && jord <= 7)
+      ppm_line_low(jord, js, je, bd.npy, bd.any_edge(), bd.edge_s, bd.edge_n, [&](int j) { return q(i, j); }, [&](int j) { return c(i, j); },
+                   [&](int j) { return g.dya(i, j); }, [&](int j, double f) { flux(i, j) = f; });
+    else
     ppm_line_mono(jord, js, je, bd.npy, bd.any_edge(), bd.edge_s, bd.edge_n, [&](int j) { return q(i, j); }, [&](int j) { return c(i, j); },
                   [&](int j) { return g.dya(i, j); }, [&](int j, double f) { flux(i, j) = f; });
 }
@@ -201,6 +212,124 @@ void uv_line_mono(int iord, int first, int last, int np, bool any_edge, bool edg
     if (c(i) > 0.) { const double cfl = c(i) * rd(i - 1); flux(i, q(i - 1) + (1. - cfl) * (br(i - 1) - cfl * (bl(i - 1) + br(i - 1)))); }
     else { const double cfl = c(i) * rd(i); flux(i, q(i) + (1. + cfl) * (bl(i) + cfl * (bl(i) + br(i)))); }
   }
+}
+
+// ---- the limited low-order schemes of the NONLINEAR routines, iord = 3 .. 7 (xppm: tp_core_tlm.F90:339-408 edge values, :442-590 fluxes;
+// yppm :1060-1336; xtp_u: sw_core_tlm.F90:4406-4470 slopes, :4483-4612 fluxes; ytp_v :5147-5360).  Like 8 / 10 they are never differentiated:
+// a trajectory scheme in 3 .. 7 beside a perturbation scheme in {1, 2, 333} gives the values only (split_hord).  Same edge values al as the
+// linear scheme 2; what differs is which cells keep their parabola: smt5 / smt6 tests on (bl, br) of the two cells beside the interface.
+static const double low_p1 = 7. / 12., low_p2 = -1. / 12., low_c1 = -2. / 14., low_c2 = 11. / 14., low_c3 = 5. / 14.;
+
+// fluxes of one line from the slopes bl, br (cells first-1 .. last+1); cf(i, upwind cell) = the Courant number used in the flux formula
+template <class FQ, class FC, class FBL, class FBR, class FCfl, class FOut>
+void low_fluxes(int iord, int first, int last, const FQ& q, const FC& c, const FBL& bl, const FBR& br, const FCfl& cf, const FOut& flux) {
+  const int lo = first - 1, n = last - first + 3;
+  std::vector<double> b0_(n); std::vector<char> s5_(n), s6_(n);
+  auto b0 = [&](int i) -> double& { return b0_[i - lo]; };
+  auto smt5 = [&](int i) -> char& { return s5_[i - lo]; };
+  auto smt6 = [&](int i) -> char& { return s6_[i - lo]; };
+  for (int i = first - 1; i <= last + 1; ++i) {
+    b0(i) = bl(i) + br(i);
+    const double x0 = std::fabs(b0(i)), xt = std::fabs(bl(i) - br(i));
+    if (iord == 3 || iord == 4) { smt5(i) = x0 < xt; smt6(i) = 3. * x0 < xt; }
+    else if (iord == 5) smt5(i) = bl(i) * br(i) < 0.;
+    else smt5(i) = std::fabs(3. * b0(i)) < xt;                 // 6 and 7
+  }
+  for (int i = first; i <= last + 1; ++i) {
+    const bool up = c(i) > 0.;
+    const double xt = up ? cf(i, i - 1) : cf(i, i);
+    if (iord == 3) {                                           // tp_core :442-517, sw_core :4483-4549
+      double fx1 = 0.;
+      if (up) {
+        if (smt6(i - 1) || smt5(i)) fx1 = br(i - 1) - xt * b0(i - 1);
+        else if (smt5(i - 1)) fx1 = f_sign(std::min(std::fabs(bl(i - 1)), std::fabs(br(i - 1))), br(i - 1));
+        flux(i, q(i - 1) + (1. - xt) * fx1);
+      } else {
+        if (smt6(i) || smt5(i - 1)) fx1 = bl(i) + xt * b0(i);
+        else if (smt5(i)) fx1 = f_sign(std::min(std::fabs(bl(i)), std::fabs(br(i))), bl(i));
+        flux(i, q(i) + (1. + xt) * fx1);
+      }
+    } else if (iord == 4) {                                    // tp_core :518-552, sw_core :4550-4582
+      if (up) flux(i, (smt6(i - 1) || smt5(i)) ? q(i - 1) + (1. - xt) * (br(i - 1) - xt * b0(i - 1)) : q(i - 1));
+      else flux(i, (smt6(i) || smt5(i - 1)) ? q(i) + (1. + xt) * (bl(i) + xt * b0(i)) : q(i));
+    } else {                                                   // 5, 6, 7: tp_core :553-590, sw_core :4583-4612
+      const double fx1 = up ? (1. - xt) * (br(i - 1) - xt * b0(i - 1)) : (1. + xt) * (bl(i) + xt * b0(i));
+      double f = up ? q(i - 1) : q(i);
+      if (smt5(i - 1) || smt5(i)) f = f + fx1;
+      flux(i, f);
+    }
+  }
+}
+
+template <class FQ, class FC, class FD, class FOut>
+void ppm_line_low(int iord, int first, int last, int np, bool any_edge, bool edge_lo, bool edge_hi, const FQ& q, const FC& c, const FD& da,
+                  const FOut& flux) {
+  assert(iord >= 3 && iord <= 7);
+  int is1 = first - 1, ie3 = last + 2;
+  if (any_edge) { is1 = std::max(3, first - 1); ie3 = std::min(np - 2, last + 2); }      // :314-330
+  const int lo = first - 4, n = last - first + 10;
+  std::vector<double> al_(n, 0.);
+  auto al = [&](int i) -> double& { return al_[i - lo]; };
+  for (int i = is1; i <= ie3; ++i) al(i) = low_p1 * (q(i - 1) + q(i)) + low_p2 * (q(i - 2) + q(i + 1));      // :342-344
+  if (iord == 7) for (int i = is1; i <= ie3; ++i) if (al(i) < 0.) al(i) = 0.5 * (q(i - 1) + q(i));           // :345-349
+  auto two_sided = [&](int e) {
+    return 0.5 * (((2. * da(e - 1) + da(e - 2)) * q(e - 1) - da(e - 1) * q(e - 2)) / (da(e - 2) + da(e - 1)) +
+                  ((2. * da(e) + da(e + 1)) * q(e) - da(e) * q(e + 1)) / (da(e) + da(e + 1)));
+  };
+  if (any_edge && edge_lo) {        // :351-374
+    al(0) = low_c1 * q(-2) + low_c2 * q(-1) + low_c3 * q(0);
+    al(1) = two_sided(1);
+    al(2) = low_c3 * q(1) + low_c2 * q(2) + low_c1 * q(3);
+    if (iord == 7) for (int i = 0; i <= 2; ++i) al(i) = std::max(0., al(i));
+  }
+  if (any_edge && edge_hi) {        // :376-406
+    al(np - 1) = low_c1 * q(np - 3) + low_c2 * q(np - 2) + low_c3 * q(np - 1);
+    al(np) = two_sided(np);
+    al(np + 1) = low_c3 * q(np) + low_c2 * q(np + 1) + low_c1 * q(np + 2);
+    if (iord == 7) for (int i = np - 1; i <= np + 1; ++i) al(i) = std::max(0., al(i));
+  }
+  low_fluxes(iord, first, last, q, c, [&](int i) { return al(i) - q(i); }, [&](int i) { return al(i + 1) - q(i); }, [&](int i, int) { return c(i); }, flux);
+}
+
+template <class FQ, class FC, class FD, class FR, class FOut>
+void uv_line_low(int iord, int first, int last, int np, bool any_edge, bool edge_lo, bool edge_hi, bool row_edge, const FQ& q, const FC& c,
+                 const FD& dd, const FR& rd, const FOut& flux) {
+  assert(iord >= 3 && iord <= 7);
+  int is3 = first - 1, ie3 = last + 1;
+  if (any_edge) { is3 = std::max(3, first - 1); ie3 = std::min(np - 3, last + 1); }      // :4384-4395
+  const int lo = first - 4, n = last - first + 10;
+  std::vector<double> al_(n, 0.), bl_(n, 0.), br_(n, 0.);
+  auto al = [&](int i) -> double& { return al_[i - lo]; };
+  auto bl = [&](int i) -> double& { return bl_[i - lo]; };
+  auto br = [&](int i) -> double& { return br_[i - lo]; };
+  for (int i = is3; i <= ie3 + 1; ++i) al(i) = low_p1 * (q(i - 1) + q(i)) + low_p2 * (q(i - 2) + q(i + 1));      // :4408-4411
+  for (int i = is3; i <= ie3; ++i) { bl(i) = al(i) - q(i); br(i) = al(i + 1) - q(i); }
+  auto two_sided = [&](int e) {
+    return 0.5 * (((2. * dd(e - 1) + dd(e - 2)) * q(e - 1) - dd(e - 1) * q(e - 2)) / (dd(e - 1) + dd(e - 2)) +
+                  ((2. * dd(e) + dd(e + 1)) * q(e) - dd(e) * q(e + 1)) / (dd(e) + dd(e + 1)));
+  };
+  if (any_edge && edge_lo) {        // :4417-4440
+    double xt = low_c3 * q(1) + low_c2 * q(2) + low_c1 * q(3);
+    br(1) = xt - q(1); bl(2) = xt - q(2); br(2) = al(3) - q(2);
+    if (row_edge) { bl(0) = 0.; br(0) = 0.; bl(1) = 0.; br(1) = 0.; }
+    else {
+      bl(0) = low_c1 * q(-2) + low_c2 * q(-1) + low_c3 * q(0) - q(0);
+      xt = two_sided(1);
+      br(0) = xt - q(0); bl(1) = xt - q(1);
+    }
+  }
+  if (any_edge && edge_hi) {        // :4441-4466
+    bl(np - 2) = al(np - 2) - q(np - 2);
+    double xt = low_c1 * q(np - 3) + low_c2 * q(np - 2) + low_c3 * q(np - 1);
+    br(np - 2) = xt - q(np - 2); bl(np - 1) = xt - q(np - 1);
+    if (row_edge) { bl(np - 1) = 0.; br(np - 1) = 0.; bl(np) = 0.; br(np) = 0.; }
+    else {
+      xt = two_sided(np);
+      br(np - 1) = xt - q(np - 1); bl(np) = xt - q(np);
+      br(np) = low_c3 * q(np) + low_c2 * q(np + 1) + low_c1 * q(np + 2) - q(np);
+    }
+  }
+  low_fluxes(iord, first, last, q, c, [&](int i) { return bl(i); }, [&](int i) { return br(i); }, [&](int i, int cell) { return c(i) * rd(cell); }, flux);
 }
 
 }  // namespace orc
