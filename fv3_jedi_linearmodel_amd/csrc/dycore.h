@@ -758,7 +758,7 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
   //   reference's namelist but used nowhere on the path (fv_control_tlmadm.F90:166-172), so they are accepted and ignored here too
   //   advection schemes: the tangent / adjoint exists for 1, 2, 333 (tp_core_tlm.F90:2393-2487); a trajectory scheme that differs
   //   (split_hord) gives the values -- a second pass of fv_tp_2d, a second evaluation inside the xtp_u / ytp_v stage -- and may
-  //   also be one of the limited 3 .. 7 or the monotone 8 or 10
+  //   also be one of the limited 3 .. 7 or the monotone 8 .. 13
   lev_host.resize(npz + 1);
   for (int k = 1; k <= npz; ++k) {
     resolve_level(o, k, npz, lev_host[k - 1]);
@@ -766,7 +766,7 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
     for (int h : {l.hord_mt, l.hord_vt, l.hord_tm, l.hord_dp, l.hord_tr, l.hord_tm_g})
       if (h != 1 && h != 2 && h != 333) { err = "perturbation hord must be 1, 2 or 333 (the schemes the TL/AD reference implements)"; return false; }
     for (int h : {l.hord_mt_t, l.hord_vt_t, l.hord_tm_t, l.hord_dp_t, l.hord_tr_t, l.hord_tm_g_t})
-      if (h != 1 && h != 2 && h != 333 && !(h >= 3 && h <= 8) && h != 10) { err = "trajectory hord must be 1, 2, 333 (differentiated) or, with a different perturbation scheme, 3 .. 8 or 10"; return false; }
+      if (h != 333 && !(h >= 1 && h <= 13)) { err = "trajectory hord must be 1, 2, 333 (differentiated) or, with a different perturbation scheme, 3 .. 13"; return false; }
     const int pairs[6][2] = {{l.hord_mt_t, l.hord_mt}, {l.hord_vt_t, l.hord_vt}, {l.hord_tm_t, l.hord_tm}, {l.hord_dp_t, l.hord_dp}, {l.hord_tr_t, l.hord_tr}, {l.hord_tm_g_t, l.hord_tm_g}};
     for (auto& pr : pairs) if (pr[0] == pr[1] && pr[0] != 1 && pr[0] != 2 && pr[0] != 333) { err = "hord must be 1, 2 or 333 where trajectory and perturbation share the scheme"; return false; }
   }

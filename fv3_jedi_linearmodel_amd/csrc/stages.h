@@ -150,21 +150,34 @@ HD void mono_blbr(int iord, bool face, int i, int n1, const double* v, const D& 
     return;
   }
   const double qi = v[2], al0 = 0.5 * (v[1] + v[2]) + MONO_R3 * (dm_m - dm_0), al1 = 0.5 * (v[2] + v[3]) + MONO_R3 * (dm_0 - dm_p);   // :641-642
-  if (iord == 8) {                             // Lin's fast monotone constraint (:643-678)
-    const double xt = 2. * dm_0;
+  if (iord == 8 || iord == 11) {               // Lin's fast monotone constraint (:643-678); 11 (:679-715): the same with ppm_fac = 1.5 (:35) in place of 2
+    const double xt = (iord == 8 ? 2. : 1.5) * dm_0;
     bl = -mono_sign(fmin(fabs(xt), fabs(al0 - qi)), xt);
     br = mono_sign(fmin(fabs(xt), fabs(al1 - qi)), xt);
     return;
   }
-  bl = al0 - qi; br = al1 - qi;                // iord = 10: Huynh's second constraint (:716-823)
-  if (fabs(dm_m) + fabs(dm_0) + fabs(dm_p) < MONO_NEAR_ZERO) { bl = 0.; br = 0.; return; }
-  if (fabs(3. * (bl + br)) > fabs(bl - br)) {
+  bl = al0 - qi; br = al1 - qi;                // iord = 9, 10, 12, 13: Huynh's second constraint (:716-823)
+  if (fabs(dm_m) + fabs(dm_0) + fabs(dm_p) < MONO_NEAR_ZERO) { bl = 0.; br = 0.; }
+  else if (fabs(3. * (bl + br)) > fabs(bl - br)) {
     const double pmp_2 = 2. * (v[2] - v[1]), lac_2 = pmp_2 - 0.75 * (2. * (v[1] - v[0]));
     br = fmin(fmax(0., fmax(pmp_2, lac_2)), fmax(br, fmin(0., fmin(pmp_2, lac_2))));
     const double pmp_1 = -(2. * (v[3] - v[2])), lac_1 = pmp_1 + 0.75 * (2. * (v[4] - v[3]));
     bl = fmin(fmax(0., fmax(pmp_1, lac_1)), fmax(bl, fmin(0., fmin(pmp_1, lac_1))));
   }
+  if (iord == 9 || iord == 13) {               // positive definite constraint: pert_ppm with iv = 0 on the cells away from a cube edge (:826-828, :1867-1892)
+    if (qi <= 0.) { bl = 0.; br = 0.; return; }
+    const double a4 = -3. * (br + bl), da1 = br - bl;
+    if (fabs(da1) < -a4) {
+      const double fmn = qi + 0.25 / a4 * da1 * da1 + a4 * (1. / 12.);
+      if (fmn < 0.) {
+        if (br > 0. && bl > 0.) { br = 0.; bl = 0.; }
+        else if (da1 > 0.) br = -2. * bl;
+        else bl = -2. * br;
+      }
+    }
+  }
 }
+HD constexpr bool hord_mono(int iord) { return iord >= 8 && iord <= 13; }
 // flux at interface m with the trajectory scheme: the differentiable schemes through ppm_flux, 8 / 10 through the slopes of the upwind
 // cell (:944-952).  The six cells q(m-3 .. m+2) are read once; the upwind cell's window is picked by selects, never by a dynamic index.
 // The limited low-order schemes of the NONLINEAR routines, iord 3 .. 7 (xppm tp_core_tlm.F90:442-590, yppm :1060-1336; xtp_u
@@ -210,7 +223,7 @@ HD double ppm_flux_traj(int iord, bool face, int m, int n1, const Q& q, const D&
     const double qm = q(m - 1), q0 = q(m);
     return low_flux(iord, qm, q0, alm - qm, al0 - qm, al0 - q0, alp - q0, cc > 0., cc);
   }
-  if (iord != 8 && iord != 10) return ppm_flux<double>(iord, face, m, n1, q, da, cc);
+  if (!hord_mono(iord)) return ppm_flux<double>(iord, face, m, n1, q, da, cc);
   const double w0 = q(m - 3), w1 = q(m - 2), w2 = q(m - 1), w3 = q(m), w4 = q(m + 1), w5 = q(m + 2);
   const bool up = cc > 0.;
   const double v[5] = {up ? w0 : w1, up ? w1 : w2, up ? w2 : w3, up ? w3 : w4, up ? w4 : w5};
@@ -268,6 +281,14 @@ HD void uv_mono_blbr(int iord, bool face, int i, int n1, bool row_edge, const do
     return;
   }
   bl = al0 - qi; br = al1 - qi;
+  if (iord >= 11) return;                      // "un-limited: 11" -- the ELSE of the chain (sw_core_tlm.F90:4890-4896): 11, 12, 13
+  if (iord == 9) {                             // the constraint everywhere, no 2-delta-x test (:4710-4780)
+    const double pmp_1 = -(2. * (v[3] - v[2])), lac_1 = pmp_1 + 1.5 * (v[4] - v[3]);
+    bl = fmin(fmax(0., fmax(pmp_1, lac_1)), fmax(bl, fmin(0., fmin(pmp_1, lac_1))));
+    const double pmp_2 = 2. * (v[2] - v[1]), lac_2 = pmp_2 - 1.5 * (v[1] - v[0]);
+    br = fmin(fmax(0., fmax(pmp_2, lac_2)), fmax(br, fmin(0., fmin(pmp_2, lac_2))));
+    return;
+  }
   if (fabs(dm_0) < MONO_NEAR_ZERO) {
     if (fabs(dm_m) + fabs(dm_p) < MONO_NEAR_ZERO) { bl = 0.; br = 0.; }
   } else if (fabs(3. * (bl + br)) > fabs(bl - br)) {
@@ -286,7 +307,7 @@ HD double tp_uv_flux_traj(int iord, bool face, int m, int n1, bool row_edge, con
     const bool up = cc > 0.;
     return low_flux(iord, q(m - 1), q(m), blm, brm, bl0, br0, up, cc * (up ? rd_m : rd_0));
   }
-  if (iord != 8 && iord != 10) return tp_uv_flux<double>(iord, face, m, n1, row_edge, q, dd, cc, rd_m, rd_0);
+  if (!hord_mono(iord)) return tp_uv_flux<double>(iord, face, m, n1, row_edge, q, dd, cc, rd_m, rd_0);
   const double w0 = q(m - 3), w1 = q(m - 2), w2 = q(m - 1), w3 = q(m), w4 = q(m + 1), w5 = q(m + 2);
   const bool up = cc > 0.;
   const double v[5] = {up ? w0 : w1, up ? w1 : w2, up ? w2 : w3, up ? w3 : w4, up ? w4 : w5};

@@ -682,7 +682,7 @@ void compute_divergence_damping(int nord, double d2_bg, double d4_bg, double ddd
 // split_hord for the momentum fluxes (sw_core_tlm.F90:1987-2002 ytp_v, :2059-2072 xtp_u): the _TLM routine with the perturbation scheme,
 // then the nonlinear routine with the trajectory scheme -- which may be the monotone 8 / 10 (tp_mono.hpp uv_line_mono) -- for the values.
 inline void xtp_u_traj(const Arr2<double>& c, const Arr2<double>& u, Arr2<double>& flux, int iord, const Grid& g, const Bounds& bd) {
-  if (iord != 8 && iord != 10 && !(iord >= 3 && iord <= 7)) { xtp_u<double>(c, u, flux, iord, g, bd); return; }
+  if (!(iord >= 3 && iord <= 13)) { xtp_u<double>(c, u, flux, iord, g, bd); return; }
   for (int j = bd.js; j <= bd.je + 1; ++j)
     if (iord <= 7)
       uv_line_low(iord, bd.is, bd.ie, bd.npx, bd.any_edge(), bd.edge_w, bd.edge_e, bd.any_edge() && (j == 1 || j == bd.npy), [&](int i) { return u(i, j); },
@@ -692,7 +692,7 @@ inline void xtp_u_traj(const Arr2<double>& c, const Arr2<double>& u, Arr2<double
                  [&](int i) { return c(i, j); }, [&](int i) { return g.dx(i, j); }, [&](int i) { return g.rdx(i, j); }, [&](int i, double f) { flux(i, j) = f; });
 }
 inline void ytp_v_traj(const Arr2<double>& c, const Arr2<double>& v, Arr2<double>& flux, int jord, const Grid& g, const Bounds& bd) {
-  if (jord != 8 && jord != 10 && !(jord >= 3 && jord <= 7)) { ytp_v<double>(c, v, flux, jord, g, bd); return; }
+  if (!(jord >= 3 && jord <= 13)) { ytp_v<double>(c, v, flux, jord, g, bd); return; }
   for (int i = bd.is; i <= bd.ie + 1; ++i)
     if (jord <= 7)
       uv_line_low(jord, bd.js, bd.je, bd.npy, bd.any_edge(), bd.edge_s, bd.edge_n, bd.any_edge() && (i == 1 || i == bd.npx), [&](int j) { return v(i, j); },

@@ -45,7 +45,7 @@ void copy_corners(Arr2<T>& q, int dir, const Bounds& bd) {
 template <class T>
 void xppm(Arr2<T>& flux, const Arr2<T>& q, const Arr2<T>& c, int iord, int is, int ie, int jfirst, int jlast,
           const Bounds& bd, const Grid& g) {
-  if ((iord >= 3 && iord <= 8) || iord == 10) { Mono<T>::x(flux, q, c, iord, is, ie, jfirst, jlast, bd, g); return; }
+  if (iord >= 3 && iord <= 13) { Mono<T>::x(flux, q, c, iord, is, ie, jfirst, jlast, bd, g); return; }
   assert(iord == 1 || iord == 2 || iord == 333);
   const int npx = bd.npx;
   int is1 = is - 1, ie3 = ie + 2;
@@ -100,7 +100,7 @@ void xppm(Arr2<T>& flux, const Arr2<T>& q, const Arr2<T>& c, int iord, int is, i
 template <class T>
 void yppm(Arr2<T>& flux, const Arr2<T>& q, const Arr2<T>& c, int jord, int ifirst, int ilast, int js, int je,
           const Bounds& bd, const Grid& g) {
-  if ((jord >= 3 && jord <= 8) || jord == 10) { Mono<T>::y(flux, q, c, jord, ifirst, ilast, js, je, bd, g); return; }
+  if (jord >= 3 && jord <= 13) { Mono<T>::y(flux, q, c, jord, ifirst, ilast, js, je, bd, g); return; }
   assert(jord == 1 || jord == 2 || jord == 333);
   const int npy = bd.npy;
   int js1 = js - 1, je3 = je + 2;

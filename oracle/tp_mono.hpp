@@ -27,13 +27,29 @@ inline void pert_ppm_std(int im, double* al, double* ar) {
   }
 }
 
+// pert_ppm with iv = 0 (positive definite constraint, tp_core_tlm.F90:1867-1892): iord 9 and 13 of xppm / yppm, interior cells
+inline void pert_ppm_pos(int im, const double* a0, double* al, double* ar) {
+  for (int i = 0; i < im; ++i) {
+    if (a0[i] <= 0.) { al[i] = 0.; ar[i] = 0.; continue; }
+    const double a4 = -3. * (ar[i] + al[i]), da1 = ar[i] - al[i];
+    if (std::fabs(da1) < -a4) {
+      const double fmin = a0[i] + 0.25 / a4 * da1 * da1 + a4 * (1. / 12.);
+      if (fmin < 0.) {
+        if (ar[i] > 0. && al[i] > 0.) { ar[i] = 0.; al[i] = 0.; }
+        else if (da1 > 0.) ar[i] = -2. * al[i];
+        else al[i] = -2. * ar[i];
+      }
+    }
+  }
+}
+
 // One line.  Cells are numbered as in the reference (first..last = is..ie or js..je, three halo cells each side);
 // q(n), c(n) (n = first..last+1), da(n) = dxa or dya along the line; edge_lo: first == 1 on a cube edge,
 // edge_hi: last + 1 == np on a cube edge; any_edge: the tile is part of a cubed-sphere face (is1 / ie1 clipping, :314-330).
 template <class FQ, class FC, class FD, class FOut>
 void ppm_line_mono(int iord, int first, int last, int np, bool any_edge, bool edge_lo, bool edge_hi, const FQ& q, const FC& c, const FD& da,
                    const FOut& flux) {
-  assert(iord == 8 || iord == 10);
+  assert(iord >= 8 && iord <= 13);
   int is1 = first - 1, ie1 = last + 1;
   if (any_edge) { is1 = std::max(3, first - 1); ie1 = std::min(np - 3, last + 1); }
   const int lo = first - 4, n = last - first + 10;
@@ -49,13 +65,13 @@ void ppm_line_mono(int iord, int first, int last, int np, bool any_edge, bool ed
     dm(i) = f_sign(std::min(std::min(std::fabs(xt), hi), lw), xt);
   }
   for (int i = is1; i <= ie1 + 1; ++i) al(i) = 0.5 * (q(i - 1) + q(i)) + mono_r3 * (dm(i - 1) - dm(i));     // :641-642
-  if (iord == 8) {                                   // :643-678
+  if (iord == 8 || iord == 11) {                     // :643-678; 11 ("2nd van Leer scheme using PPM codes", :679-715): ppm_fac = 1.5 (:35) in place of 2
     for (int i = is1; i <= ie1; ++i) {
-      const double xt = 2. * dm(i);
+      const double xt = (iord == 8 ? 2. : 1.5) * dm(i);
       bl(i) = -f_sign(std::min(std::fabs(xt), std::fabs(al(i) - q(i))), xt);
       br(i) = f_sign(std::min(std::fabs(xt), std::fabs(al(i + 1) - q(i))), xt);
     }
-  } else {                                           // iord = 10: Huynh's second constraint, :716-823
+  } else {                                           // iord = 9, 10, 12, 13: Huynh's second constraint, :716-823
     for (int i = is1 - 2; i <= ie1 + 1; ++i) dq(i) = 2. * (q(i + 1) - q(i));
     for (int i = is1; i <= ie1; ++i) {
       bl(i) = al(i) - q(i);
@@ -68,6 +84,11 @@ void ppm_line_mono(int iord, int first, int last, int np, bool any_edge, bool ed
         bl(i) = std::min(std::max(0., std::max(pmp_1, lac_1)), std::max(bl(i), std::min(0., std::min(pmp_1, lac_1))));
       }
     }
+  }
+  if (iord == 9 || iord == 13) {                     // positive definite constraint on the cells is1 .. ie1, :826-828
+    std::vector<double> a0(ie1 - is1 + 1);
+    for (int i = is1; i <= ie1; ++i) a0[i - is1] = q(i);
+    pert_ppm_pos(ie1 - is1 + 1, a0.data(), &bl(is1), &br(is1));
   }
   auto two_sided = [&](int e) {     // the dxa-weighted value on a cube edge between cells e-1 and e (:833-835, :892-895)
     return 0.5 * (((2. * da(e - 1) + da(e - 2)) * q(e - 1) - da(e - 1) * q(e - 2)) / (da(e - 2) + da(e - 1)) +
@@ -139,7 +160,7 @@ inline void yppm_mono(Arr2<double>& flux, const Arr2<double>& q, const Arr2<doub
 template <class FQ, class FC, class FD, class FR, class FOut>
 void uv_line_mono(int iord, int first, int last, int np, bool any_edge, bool edge_lo, bool edge_hi, bool row_edge, const FQ& q, const FC& c,
                   const FD& dd, const FR& rd, const FOut& flux) {
-  assert(iord == 8 || iord == 10);
+  assert(iord >= 8 && iord <= 13);
   int is3 = first - 1, ie3 = last + 1;
   if (any_edge) { is3 = std::max(3, first - 1); ie3 = std::min(np - 3, last + 1); }
   const int lo = first - 4, n = last - first + 10;
@@ -162,7 +183,16 @@ void uv_line_mono(int iord, int first, int last, int np, bool any_edge, bool edg
       bl(i) = -f_sign(std::min(std::fabs(xt), std::fabs(al(i) - q(i))), xt);
       br(i) = f_sign(std::min(std::fabs(xt), std::fabs(al(i + 1) - q(i))), xt);
     }
-  } else {                                           // :4781-4890
+  } else if (iord == 9) {                            // :4710-4780: the constraint applied everywhere, no 2-delta-x test
+    for (int i = is3; i <= ie3; ++i) {
+      const double pmp_1 = -(2. * dq(i)), lac_1 = pmp_1 + 1.5 * dq(i + 1);
+      bl(i) = std::min(std::max(0., std::max(pmp_1, lac_1)), std::max(al(i) - q(i), std::min(0., std::min(pmp_1, lac_1))));
+      const double pmp_2 = 2. * dq(i - 1), lac_2 = pmp_2 - 1.5 * dq(i - 2);
+      br(i) = std::min(std::max(0., std::max(pmp_2, lac_2)), std::max(al(i + 1) - q(i), std::min(0., std::min(pmp_2, lac_2))));
+    }
+  } else if (iord >= 11) {                           // :4890-4896 "un-limited: 11" (the ELSE of the chain: 11, 12, 13)
+    for (int i = is3; i <= ie3; ++i) { bl(i) = al(i) - q(i); br(i) = al(i + 1) - q(i); }
+  } else {                                           // iord = 10, :4781-4890
     for (int i = is3; i <= ie3; ++i) {
       bl(i) = al(i) - q(i);
       br(i) = al(i + 1) - q(i);

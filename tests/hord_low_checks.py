@@ -1,5 +1,6 @@
 """Shared by test_emul_hord_low.py / test_gpu_hord_low.py: trajectory advection schemes 3 .. 7 (the limited low-order schemes of the nonlinear
-xppm / yppm, tp_core_tlm.F90:442-590, and xtp_u / ytp_v, sw_core_tlm.F90:4483-4612) beside a perturbation scheme of {1, 2, 333} (split_hord).
+xppm / yppm, tp_core_tlm.F90:442-590, and xtp_u / ytp_v, sw_core_tlm.F90:4483-4612) and 9, 11, 12, 13 (the variants of the monotone schemes:
+tp_core_tlm.F90:679-715, :826-828; sw_core_tlm.F90:4710-4780, :4890-4896) beside a perturbation scheme of {1, 2, 333} (split_hord).
 Which cells keep their parabola is decided by tests on the slopes (smt5 / smt6), so the checks run on ROUGH fields: grid-scale noise on the
 trajectory makes every branch of every scheme fire (asserted below by the schemes giving pairwise different steps)."""
 import numpy as np
@@ -12,7 +13,7 @@ def hord_kw(h, pert=2):
     return kw
 
 
-def roughen(c, seed=7, periodic=True):
+def roughen(c, seed=7, periodic=True, qamp=0.3):
     """grid-scale noise on the trajectory of a single-tile case (periodic images kept equal) or of a six-face case (compute domains; the halos are
     exchanged by product and oracle alike)"""
     rng = np.random.default_rng(seed)
@@ -35,7 +36,7 @@ def roughen(c, seed=7, periodic=True):
                 r[..., :, 3] = 0.0; r[..., :, 3 + c.nx] = 0.0
         c.traj[n] = c.traj[n] + 2.0 * r
     for m in range(c.nq):
-        c.qtraj[m] = c.qtraj[m] * (1.0 + 0.3 * noise(c.qtraj[m]))
+        c.qtraj[m] = c.qtraj[m] * (1.0 + qamp * noise(c.qtraj[m]))      # qamp > 1: zero crossings, for the positive-definite constraint of 9 / 13
     return c
 
 

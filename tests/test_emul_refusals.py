@@ -7,8 +7,8 @@ from common import Case
 @pytest.mark.parametrize("kw, needle", [
     (dict(nord=2), "nord"),
     (dict(hord_dp=10, hord_dp_pert=10), "hord"),          # the tangent / adjoint exists for 1, 2, 333 only
-    (dict(hord_dp=9), "hord"),                            # trajectory schemes built: 1, 2, 333, 3 .. 8, 10
-    (dict(hord_mt=12, hord_mt_pert=2), "hord"),
+    (dict(hord_dp=14), "hord"),                           # trajectory schemes built: 1 .. 13, 333
+    (dict(hord_mt=0, hord_mt_pert=2), "hord"),
     (dict(hord_tm=5, hord_tm_pert=5), "hord"),            # 3 .. 7 are trajectory schemes only
     (dict(hydrostatic=0, a_imp=0.4), "a_imp"),
     (dict(kord_tm=-8), "kord"),                          # trajectory profiles built: linear (> 16) and the limited 9, 10, 11
