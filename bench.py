@@ -194,7 +194,7 @@ def main():
                     help="BASELINE config 3: w, delz prognostic, nh_core active (hydrostatic = 0); not the headline workload")
     ap.add_argument("--hord-traj", type=int, default=0,
                     help="trajectory advection scheme (3 .. 13) with the perturbation schemes left at their defaults: split_hord (not the headline configuration)")
-    ap.add_argument("--kord-traj", type=int, default=0, help="trajectory remap profile (9, 10 or 11) with the linear perturbation profile: split_kord, hydrostatic only")
+    ap.add_argument("--kord-traj", type=int, default=0, help="trajectory remap profile (8 .. 15) with the linear perturbation profile: split_kord, hydrostatic only")
     ap.add_argument("--nord-traj", type=int, default=0, help="trajectory divergence-damping order (2 or 3) beside nord_pert = 1: split_damp (not the headline configuration)")
     ap.add_argument("--split-damp", action="store_true", help="split_damp = .true. (the reference's default) with equal namelist values: the perturbation sponge rules differ")
     ap.add_argument("--layout", type=int, default=0,

@@ -751,7 +751,7 @@ inline bool Dycore::init(int nx, int ny, int npz, int ntile, int face, int nq_, 
     if ((kd < 0 ? -kd : kd) <= 16) { err = "kord_*_pert: only |kord| > 16 (the linear profile, the one the TL/AD reference differentiates) is built"; return false; }
   for (int kd : {o.kord_tm, o.kord_mt, o.kord_wz, o.kord_tr}) {
     const int ak = kd < 0 ? -kd : kd;
-    if (ak <= 16 && !(ak >= 9 && ak <= 11)) { err = "kord_tm/kord_mt/kord_wz/kord_tr: the linear profile (|kord| > 16) or, for the trajectory, the limited profiles 9, 10, 11"; return false; }
+    if (ak <= 16 && !(ak >= 8 && ak <= 15)) { err = "kord_tm/kord_mt/kord_wz/kord_tr: the linear profile (|kord| > 16) or, for the trajectory, the limited profiles 8 .. 15 of cs_profile / scalar_profile (not 16, not ppm_profile's 7 and below)"; return false; }
     if (ak <= 16 && npz < 6) { err = "kord: limited trajectory profiles need npz >= 6"; return false; }
   }
   //   tracer advection: hord_tr / hord_tr_pert split like the others (fv_tracer2d_tlm.F90:1047-1110); hord_tr_ks_* are read by the

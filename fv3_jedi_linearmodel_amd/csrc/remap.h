@@ -183,7 +183,22 @@ HD void lim_layer(const LimProfile& P, int k, int km, const FA& a1, const FE& qe
       a4 = 6. * a - 3. * (a2 + a3);
       if (fabs(a4) > fabs(a2 - a3)) { huynh(); a4 = 6. * a - 3. * (a2 + a3); }
     }
-  } else {      // 11
+  } else if (ak == 8) {      // |kord| < 9: the constraint on every interior layer (model/fv_mapz_nlm.F90:2301-2315; scalar_profile :1925-1939)
+    huynh(); a4 = 3. * (2. * a - (a2 + a3));
+  } else if (ak == 12) {     // :2370-2390 (:2002-2023): flat at every local extremum
+    if (ex) { a2 = a; a3 = a; a4 = 0.; }
+    else {
+      a4 = 6. * a - 3. * (a2 + a3);
+      if (fabs(a4) > fabs(a2 - a3)) { huynh(); a4 = 6. * a - 3. * (a2 + a3); }
+    }
+  } else if (ak == 13) {     // :2391-2420 (:2024-2048)
+    if (ex) {
+      if (extm(k - 1) && extm(k + 1)) { a2 = a; a3 = a; a4 = 0.; }
+      else { huynh(); a4 = 3. * (2. * a - (a2 + a3)); }
+    } else a4 = 3. * (2. * a - (a2 + a3));
+  } else if (ak == 14) {     // :2421-2424 (:2049-2052): no constraint in the interior
+    a4 = 3. * (2. * a - (a2 + a3));
+  } else {      // 11, and 15 through the same ELSE (:2425-2436; scalar_profile :2071-2082)
     if (ex && (extm(k - 1) || extm(k + 1) || small)) { a2 = a; a3 = a; a4 = 0.; }
     else a4 = 3. * (2. * a - (a2 + a3));
   }

@@ -90,7 +90,7 @@ inline void cs_limiters(bool extm, double a1, double& a2, double& a3, double& a4
 inline void cs_profile_limited(const std::vector<double>& a1, std::vector<double>& a2, std::vector<double>& a3, std::vector<double>& a4, int km, int iv,
                                int kord, bool scalar, double qmin) {
   const int ak = std::abs(kord);
-  assert(ak == 9 || ak == 10 || ak == 11);
+  assert(ak >= 8 && ak <= 15);      // 16: scalar_profile has its own edge values (:1878); <= 7: ppm_profile
   std::vector<double> q(km + 2), gam(km + 3, 0.);
   std::vector<char> extm(km + 2, 0);
   for (int k = 1; k <= km; ++k) q[k] = a2[k];
@@ -138,7 +138,23 @@ inline void cs_profile_limited(const std::vector<double>& a1, std::vector<double
         a4[k] = 6. * a1[k] - 3. * (a2[k] + a3[k]);
         if (std::fabs(a4[k]) > std::fabs(a2[k] - a3[k])) { huynh(k); a4[k] = 6. * a1[k] - 3. * (a2[k] + a3[k]); }
       }
-    } else {                               // 11
+    } else if (ak < 9) {                   // 8 (7 and below never get here: ppm_profile), model/fv_mapz_nlm.F90:2301-2315 == :1925-1939
+      huynh(k);
+      a4[k] = 3. * (2. * a1[k] - (a2[k] + a3[k]));
+    } else if (ak == 12) {                 // :2370-2390 == :2002-2023
+      if (extm[k]) flat();
+      else {
+        a4[k] = 6. * a1[k] - 3. * (a2[k] + a3[k]);
+        if (std::fabs(a4[k]) > std::fabs(a2[k] - a3[k])) { huynh(k); a4[k] = 6. * a1[k] - 3. * (a2[k] + a3[k]); }
+      }
+    } else if (ak == 13) {                 // :2391-2420 == :2024-2048
+      if (extm[k]) {
+        if (extm[k - 1] && extm[k + 1]) flat();
+        else { huynh(k); a4[k] = 3. * (2. * a1[k] - (a2[k] + a3[k])); }
+      } else a4[k] = 3. * (2. * a1[k] - (a2[k] + a3[k]));
+    } else if (ak == 14) {                 // :2421-2424 == :2049-2052
+      a4[k] = 3. * (2. * a1[k] - (a2[k] + a3[k]));
+    } else {                               // 11 and, through the same ELSE, 15 (:2425-2436; scalar_profile :2071-2082 with the q < qmin test)
       if (extm[k] && (extm[k - 1] || extm[k + 1] || small)) flat();
       else a4[k] = 3. * (2. * a1[k] - (a2[k] + a3[k]));
     }

@@ -11,10 +11,10 @@ from common import Case
     (dict(hord_mt=0, hord_mt_pert=2), "hord"),
     (dict(hord_tm=5, hord_tm_pert=5), "hord"),            # 3 .. 7 are trajectory schemes only
     (dict(hydrostatic=0, a_imp=0.4), "a_imp"),
-    (dict(kord_tm=-8), "kord"),                          # trajectory profiles built: linear (> 16) and the limited 9, 10, 11
+    (dict(kord_tm=-7), "kord"),                          # trajectory profiles built: linear (> 16) and the limited 8 .. 15 of cs_profile / scalar_profile
     (dict(kord_tm_pert=-9), "kord"),                     # the perturbation profile is the linear one
-    (dict(hydrostatic=0, kord_wz=12), "kord"),
-    (dict(kord_tr=8), "kord"),
+    (dict(hydrostatic=0, kord_wz=16), "kord"),
+    (dict(kord_tr=16), "kord"),
 ])
 def test_unsupported_options_are_refused(kw, needle):
     with pytest.raises(Exception) as e:

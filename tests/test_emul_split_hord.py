@@ -122,7 +122,7 @@ def test_nh_cube():
 
 # ---- split_kord: the trajectory remapped with the limited profiles (cs_profile / scalar_profile, kord 9 / 10 / 11), the perturbation with
 #      the linear one (fv_mapz_tlm.F90:494-523, :596-637, :780-827)
-@pytest.fixture(scope="module", params=[9, 10, 11])
+@pytest.fixture(scope="module", params=[8, 9, 10, 11, 12, 13, 14, 15])
 def kcase(request):
     k = request.param
     return Case(nx=12, ny=10, npz=14, n_split=2, k_split=2, dt=1800.0, backend="emul", nq=3, kord_tm=-k, kord_mt=k, kord_tr=k, kord_wz=17)
@@ -157,10 +157,10 @@ def test_operational_pairing_on_the_cube():
     assert abs(lhs - rhs) <= 1e-12 * abs(lhs), (lhs, rhs)
 
 
-@pytest.mark.parametrize("kord", [9, 10, 11])
+@pytest.mark.parametrize("kord", [8, 9, 10, 11, 12, 13, 14, 15])
 def test_kord_remap_noisy_columns(monkeypatch, kord):
     """columns with 2-delta-z noise, local extrema, zero and negative tracer values: every branch of the limited profiles (extrema tests,
-    Huynh's constraint, the positive-definite limiter, q < qmin) -- where kord 9, 10 and 11 differ from each other"""
+    Huynh's constraint, the positive-definite limiter, q < qmin) -- where the profiles 8 .. 15 differ from each other"""
     import groups
     c = Case(nx=12, ny=10, npz=16, n_split=1, k_split=1, dt=900.0, backend="emul", nq=3, kord_tm=-kord, kord_mt=kord, kord_tr=kord)
     rng = np.random.default_rng(5)
@@ -196,3 +196,25 @@ def test_nh_split_kord():
     c = Case(nx=10, ny=8, npz=12, n_split=2, k_split=1, dt=600.0, nq=1, backend="emul", hydrostatic=0, kord_tm=-10, kord_mt=10, kord_tr=11, kord_wz=10)
     N.check_nh_fv_tangent(c)
     N.check_nh_fv_adjoint(c)
+    c = Case(nx=10, ny=8, npz=12, n_split=2, k_split=1, dt=600.0, nq=1, backend="emul", hydrostatic=0, kord_tm=-13, kord_mt=12, kord_tr=14, kord_wz=8)
+    N.check_nh_fv_tangent(c)
+    N.check_nh_fv_adjoint(c)
+
+
+def test_every_limited_profile_is_its_own():
+    """on columns with grid-scale noise the trajectory profiles 8 .. 14 give pairwise different nonlinear steps; 15 takes the branch of 11
+    (model/fv_mapz_nlm.F90:2425: the ELSE of the chain) and equals it"""
+    from hord_low_checks import roughen, nl_step
+    out = {}
+    for k in (8, 9, 10, 11, 12, 13, 14, 15, 17):
+        c = roughen(Case(nx=12, ny=10, npz=16, n_split=1, k_split=1, dt=900.0, backend="emul", oracle=False, nq=1, kord_tm=-k, kord_mt=k, kord_tr=k), qamp=0.8)
+        out[k] = nl_step(c)
+    ks = sorted(out)
+    for a in ks:
+        for b in ks:
+            if a < b:
+                d = max(np.max(np.abs(out[a][n] - out[b][n])) / np.max(np.abs(out[b][n])) for n in ("pt", "u", "q1"))
+                if (a, b) == (11, 15):
+                    assert d == 0.0, d
+                else:
+                    assert d > 1e-9, (a, b, d)

@@ -62,7 +62,7 @@ def test_dot_product_c96l32_six_faces():
     assert abs(lhs - rhs) <= 1e-11 * abs(lhs), (lhs, rhs)
 
 
-@pytest.mark.parametrize("kord", [9, 10, 11])
+@pytest.mark.parametrize("kord", [8, 9, 10, 11, 12, 13, 14, 15])
 def test_split_kord(kord):
     """trajectory remapped with the limited profiles, perturbation with the linear one: remap alone and the whole step"""
     from common import Case
