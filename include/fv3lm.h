@@ -32,13 +32,14 @@ typedef struct fv3lm_handle fv3lm_handle;
  * the path: the JEDI set (utils/fv3jedi_lm_const_mod.F90:17-41, passed at
  * DYN/fv3jedi_lm_dynamics_mod.F90:423-424) and FMS constants_mod — both are runtime inputs. */
 typedef struct fv3lm_options {
-  int hord_mt, hord_vt, hord_tm, hord_dp, hord_tr;
+  int hord_mt, hord_vt, hord_tm, hord_dp, hord_tr;                 /* trajectory advection schemes: 1, 2, 333 (the differentiated ones) or, beside a different
+                                                                      perturbation scheme (split_hord), any of the nonlinear routines' 3 .. 13 -- values only */
   int nord, do_vort_damp, n_sponge;
-  int hord_mt_pert, hord_vt_pert, hord_tm_pert, hord_dp_pert, hord_tr_pert;
+  int hord_mt_pert, hord_vt_pert, hord_tm_pert, hord_dp_pert, hord_tr_pert;      /* perturbation schemes: 1, 2 or 333 (tp_core_tlm.F90:2393-2487) */
   int nord_pert, do_vort_damp_pert, n_sponge_pert, hord_ks_traj, hord_ks_pert;
   int hord_mt_ks_traj, hord_vt_ks_traj, hord_tm_ks_traj, hord_dp_ks_traj, hord_tr_ks_traj;
   int hord_mt_ks_pert, hord_vt_ks_pert, hord_tm_ks_pert, hord_dp_ks_pert, hord_tr_ks_pert;
-  int kord_tm, kord_mt, kord_wz, kord_tr;                          /* trajectory remap profiles */
+  int kord_tm, kord_mt, kord_wz, kord_tr;                          /* trajectory remap profiles: |kord| > 16 (linear) or the limited 8 .. 15 of cs_profile / scalar_profile (split_kord) */
   int kord_tm_pert, kord_mt_pert, kord_wz_pert, kord_tr_pert;      /* perturbation remap profiles (fv_flags_pert_type): |kord| > 16, the linear one */
   int hydrostatic;
   int split_damp;   /* fv_flags_pert_type%split_damp (fv_arrays_tlmadm.F90:76; the reference's default is .true.).  1: the perturbation takes its own damping
